@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures by RUNNING THE REFERENCE (read-only, imported from
+/root/reference).  Run in the build container only:
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Writes small .npz/.json files next to this script.  Nothing from the reference other
+than its *outputs* on seeded inputs is stored (G1..G5).  The GPU box has no
+/root/reference: tests only read the committed fixtures.
+"""
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get('ISTGCN_REFERENCE', '/root/reference')
+sys.path.insert(0, HERE)
+sys.path.insert(1, REF)
+sys.dont_write_bytecode = True
+
+from detinit import det_fill_, det_tensor, det_labels  # noqa: E402
+
+torch.set_num_threads(8)
+
+LAYOUTS = ['openpose', 'openpose_gravity', 'openpose_sym', 'ntu-rgb+d', 'ntu-rgb+d_half',
+           'ntu-rgb+d_gravity', 'ntu-rgb+d_sym', 'ntu_edge']
+STRATEGIES = ['uniform', 'distance', 'spatial', 'spatial_half', 'openpose_gravity',
+              'ntu-rgb+d_gravity', 'spatial_3', 'spatial_sym', 'spatial_3_sym']
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print('%-34s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------- G1 graph
+def g1_graph():
+    from net.utils.graph import Graph
+    out, manifest = {}, {}
+    for lay, st in itertools.product(LAYOUTS, STRATEGIES):
+        tag = '%s|%s' % (lay, st)
+        try:
+            g = Graph(layout=lay, strategy=st)
+        except Exception as e:  # noqa: BLE001 - the exception type IS the fixture
+            manifest[tag] = {'error': type(e).__name__}
+            continue
+        rec = {'num_node': g.num_node, 'center': g.center, 'K': int(g.A.shape[0]), 'has_A23': hasattr(g, 'A2')}
+        out[tag + '|A'] = g.A.astype(np.float64)
+        out[tag + '|edge'] = np.asarray(g.edge, dtype=np.int64)
+        if hasattr(g, 'A2'):
+            out[tag + '|A2'] = g.A2.astype(np.float64)
+            out[tag + '|A3'] = g.A3.astype(np.float64)
+        manifest[tag] = rec
+    # non-default ctor args used nowhere upstream but part of the signature
+    g = Graph(layout='ntu-rgb+d', strategy='spatial', max_hop=2)
+    out['ntu-rgb+d|spatial|max_hop2|A'] = g.A
+    save('graph_g1.npz', **out)
+    with open(os.path.join(HERE, 'graph_g1.json'), 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    ok = sum('error' not in v for v in manifest.values())
+    print('G1: %d working layout x strategy pairs, %d failing' % (ok, len(manifest) - ok))
+
+
+# ----------------------------------------------------------------------------- G2 units
+def _A_for(V, strategy='spatial'):
+    from net.utils.graph import Graph
+    g = Graph(layout='ntu-rgb+d' if V == 25 else 'openpose', strategy=strategy)
+    A = torch.tensor(g.A, dtype=torch.float32)
+    extra = ()
+    if hasattr(g, 'A2'):
+        extra = (torch.tensor(g.A2, dtype=torch.float32), torch.tensor(g.A3, dtype=torch.float32))
+    return (A,) + extra
+
+
+def g2_units():
+    import importlib
+    out = {}
+    cases = [(2, 3, 16, 12, 25), (2, 16, 16, 12, 25), (2, 16, 16, 12, 18), (1, 24, 40, 7, 25)]
+    for ci, (n, cin, cout, T, V) in enumerate(cases):
+        A, A2, A3 = _A_for(V, 'spatial_3')
+        K = A.shape[0]
+        x = det_tensor('g2.x.%d' % ci, (n, cin, T, V))
+        r = det_tensor('g2.r.%d' % ci, (n, cout, T, V))
+        W = det_tensor('g2.W.%d' % ci, (K * cout, cin, 1, 1), scale=cin ** -0.5)
+        b = det_tensor('g2.b.%d' % ci, (K * cout,), scale=0.1)
+        imps = [0.5 + torch.rand((K, V, V), generator=torch.Generator().manual_seed(100 + ci * 3 + j))
+                for j in range(3)]
+        base = 'c%d.' % ci
+        out[base + 'x'], out[base + 'r'], out[base + 'W'], out[base + 'b'] = x, r, W, b
+        out[base + 'A'], out[base + 'A2'], out[base + 'A3'] = A, A2, A3
+        for j in range(3):
+            out[base + 'imp%d' % (j + 1)] = imps[j]
+
+        def run(unit_mod, cls, call):
+            mod = importlib.import_module(unit_mod)
+            u = getattr(mod, cls)(cin, cout, K)
+            conv = u.conv if hasattr(u, 'conv') else u.branch.conv
+            with torch.no_grad():
+                conv.weight.copy_(W)
+                conv.bias.copy_(b)
+            xx = x.clone().requires_grad_(True)
+            leaves = [t.clone().requires_grad_(True) for t in imps]
+            y = call(u, xx, leaves)
+            (y * r).sum().backward()
+            return y, xx.grad, conv.weight.grad, conv.bias.grad, [t.grad for t in leaves]
+
+        # a2  ConvTemporalGraphical: caller passes A*importance (st_gcnold.py:86)
+        y, dx, dW, db, dimp = run('net.utils.tgcn', 'ConvTemporalGraphical',
+                                  lambda u, xx, L: u(xx, A * L[0])[0])
+        out.update({base + 'tgcn.y': y, base + 'tgcn.dx': dx, base + 'tgcn.dW': dW,
+                    base + 'tgcn.db': db, base + 'tgcn.dimp1': dimp[0]})
+        # a3  3A unit: raw A + three importances (tgcn_multi3_fix_3A.py:76-92)
+        y, dx, dW, db, dimp = run('net.utils.tgcn_multi3_fix_3A', 'ConvTemporalGraphical',
+                                  lambda u, xx, L: u(xx, A, L[0], L[1], L[2])[0])
+        out.update({base + '3a.y': y, base + '3a.dx': dx, base + '3a.dW': dW, base + '3a.db': db})
+        for j in range(3):
+            out[base + '3a.dimp%d' % (j + 1)] = dimp[j]
+        # a4  Inception2: caller pre-multiplies (st_gcn_msgcn.py:116-117)
+        for tag, modname in (('inc', 'net.utils.inceptionv2_gcn'), ('incnew', 'net.utils.inceptionv2_gcn_new')):
+            y, dx, dW, db, dimp = run(modname, 'Inception2',
+                                      lambda u, xx, L: u(xx, A * L[0], A2 * L[1], A3 * L[2])[0])
+            out.update({base + tag + '.y': y, base + tag + '.dx': dx, base + tag + '.dW': dW, base + tag + '.db': db})
+            for j in range(3):
+                out[base + tag + '.dimp%d' % (j + 1)] = dimp[j]
+        # the "free" variants: same kernel, different folded adjacency
+        for tag, modname in (('multi3', 'net.utils.tgcn_multi3'), ('multi3fix', 'net.utils.tgcn_multi3_fix'),
+                             ('only3', 'net.utils.tgcn_only3')):
+            y, dx, dW, db, dimp = run(modname, 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A * L[0])[0])
+            out.update({base + tag + '.y': y, base + tag + '.dx': dx, base + tag + '.dimp1': dimp[0]})
+    save('units_g2.npz', **out)
+
+
+# ----------------------------------------------------------------------------- G3 blocks
+BLOCK_KINDS = {
+    # kind: (module, forward-arg builder)
+    'st_gcnold': 'net.st_gcnold',
+    'st_gcn_msgcn': 'net.st_gcn_msgcn',
+    'st_gcn_mstcn': 'net.st_gcn_mstcn',
+    'st_gcn_mstcn_1x1': 'net.st_gcn_mstcn_1x1',
+    'st_gcn_multi3_fix_3A_mstcn': 'net.st_gcn_multi3_fix_3A_mstcn',
+}
+BLOCK_SHAPES = [(3, 16, 1, False), (16, 16, 1, True), (8, 16, 2, True)]
+
+
+def block_args(kind, A, A2, A3, imps, mst):
+    if kind == 'st_gcnold':
+        return (A * imps[0],)
+    if kind == 'st_gcn_msgcn':
+        return (A * imps[0], A2 * imps[1], A3 * imps[2])
+    if kind in ('st_gcn_mstcn', 'st_gcn_mstcn_1x1'):
+        return (A * imps[0], mst)
+    if kind == 'st_gcn_multi3_fix_3A_mstcn':
+        return (A, imps[0], imps[1], imps[2], mst)
+    raise KeyError(kind)
+
+
+def g3_blocks():
+    import importlib
+    for kind, modname in BLOCK_KINDS.items():
+        mod = importlib.import_module(modname)
+        out = {}
+        for V in (25, 18):
+            A, A2, A3 = _A_for(V, 'spatial_3')
+            K = A.shape[0]
+            for si, (cin, cout, stride, residual) in enumerate(BLOCK_SHAPES):
+                if V == 18 and si != 1:
+                    continue
+                n, T = 2, 16
+                base = 'v%d.s%d.' % (V, si)
+                blk = mod.st_gcn(cin, cout, (9, K), stride, dropout=0, residual=residual)
+                sd = blk.state_dict()
+                det_fill_(sd, salt=si + 10 * V)
+                blk.load_state_dict(sd)
+                x = det_tensor('g3.x' + base, (n, cin, T, V))
+                r = det_tensor('g3.r' + base, (n, cout, T // stride, V))
+                imps = [(0.5 + torch.rand((K, V, V), generator=torch.Generator().manual_seed(7 + j))).requires_grad_(True)
+                        for j in range(3)]
+                mst = (0.5 + torch.rand(3, generator=torch.Generator().manual_seed(11))).requires_grad_(True)
+                for k, v in sd.items():
+                    out[base + 'sd.' + k] = v.clone()
+                out[base + 'x'], out[base + 'r'] = x, r
+                out[base + 'A'], out[base + 'A2'], out[base + 'A3'] = A, A2, A3
+                out[base + 'mst'] = mst.detach().clone()
+                for j in range(3):
+                    out[base + 'imp%d' % (j + 1)] = imps[j].detach().clone()
+                # eval forward (running stats)
+                blk.eval()
+                with torch.no_grad():
+                    out[base + 'y_eval'] = blk(x, *block_args(kind, A, A2, A3, imps, mst))[0]
+                # train forward + backward (batch stats, dropout 0)
+                blk.train()
+                xx = x.clone().requires_grad_(True)
+                y = blk(xx, *block_args(kind, A, A2, A3, imps, mst))[0]
+                (y * r).sum().backward()
+                out[base + 'y_train'] = y
+                out[base + 'dx'] = xx.grad
+                for k, p in blk.named_parameters():
+                    if p.grad is not None:
+                        out[base + 'grad.' + k] = p.grad
+                for j in range(3):
+                    if imps[j].grad is not None:
+                        out[base + 'dimp%d' % (j + 1)] = imps[j].grad
+                if mst.grad is not None:
+                    out[base + 'dmst'] = mst.grad
+                for k, v in blk.state_dict().items():
+                    if 'running' in k:
+                        out[base + 'after.' + k] = v.clone()
+        save('block_g3_%s.npz' % kind, **out)
+
+
+# ----------------------------------------------------------------------------- G4/G5 models
+MODELS = {
+    # tag: (module, graph_args, num_class, (N,T,V) for the eval fixture)
+    'st_gcnold': ('net.st_gcnold', dict(layout='ntu-rgb+d', strategy='spatial'), 60, (2, 300, 25)),
+    'st_gcn_msgcn': ('net.st_gcn_msgcn', dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, (2, 300, 25)),
+    'st_gcn_mstcn_1x1': ('net.st_gcn_mstcn_1x1', dict(layout='openpose', strategy='spatial'), 400, (2, 300, 18)),
+    'st_gcn_multi3_fix_3A_mstcn': ('net.st_gcn_multi3_fix_3A_mstcn', dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, (2, 300, 25)),
+    'st_gcn_mstcn_1x1_deep': ('net.st_gcn_mstcn_1x1_deep', dict(layout='ntu-rgb+d', strategy='spatial'), 60, (2, 600, 25)),
+    # not BASELINE configs, same kernels
+    'st_gcn_mstcn': ('net.st_gcn_mstcn', dict(layout='ntu-rgb+d', strategy='spatial'), 60, (2, 300, 25)),
+    'st_gcn_msgcn_new': ('net.st_gcn_msgcn_new', dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, (2, 300, 25)),
+    'st_gcn_deep_msgcn': ('net.st_gcn_deep_msgcn', dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, (2, 300, 25)),
+}
+TRAIN_SHAPE = (4, 48)  # (N, T) of the one-SGD-step fixture
+
+
+def g45_models():
+    import importlib
+    manifest = {}
+    for tag, (modname, gargs, nc, (N, T, V)) in MODELS.items():
+        mod = importlib.import_module(modname)
+        torch.manual_seed(0)
+        m = mod.Model(3, nc, gargs, True, dropout=0)
+        sd = m.state_dict()
+        manifest[tag] = {k: list(v.shape) for k, v in sd.items()}
+        manifest[tag + '#nparam'] = int(sum(p.numel() for p in m.parameters()))
+        det_fill_(sd)
+        m.load_state_dict(sd)
+        out = {}
+        # G4a: eval-mode logits at the full clip shape
+        x = det_tensor('g4.x.' + tag, (N, 3, T, V, 2))
+        m.eval()
+        with torch.no_grad():
+            out['eval_logits'] = m(x)
+        out['eval_shape'] = np.asarray([N, 3, T, V, 2])
+        # G4b: one training step = recognition.py:249-296 (train mode, CE, SGD nesterov)
+        n2, t2 = TRAIN_SHAPE
+        xt = det_tensor('g4.xt.' + tag, (n2, 3, t2, V, 2))
+        lab = det_labels('g4.lab.' + tag, n2, nc)
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        logits = m(xt)
+        loss = torch.nn.functional.cross_entropy(logits, lab)
+        opt.zero_grad()
+        loss.backward()
+        names = [k for k, _ in m.named_parameters()]
+        out['train_logits'] = logits
+        out['train_loss'] = loss.detach()
+        out['train_shape'] = np.asarray([n2, 3, t2, V, 2])
+        out['train_labels'] = lab
+        out['grad_norms'] = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) for p in m.parameters()])
+        out['grad_none'] = np.asarray([p.grad is None for p in m.parameters()])
+        opt.step()
+        after = m.state_dict()
+        out['param_norms_after'] = np.asarray([float(after[k].double().norm()) for k in names])
+        out['buffer_norms_after'] = np.asarray([float(v.double().norm()) for k, v in after.items()
+                                                if 'running' in k])
+        for k in ('fcn.bias', 'edge_importance.0', 'st_gcn_networks.0.gcn.conv.weight', 'data_bn.running_mean',
+                  'st_gcn_networks.0.gcn.branch.conv.weight', 'mstcn_importance.1'):
+            if k in after:
+                out['after.' + k] = after[k]
+        manifest[tag + '#param_names'] = names
+        save('model_g4_%s.npz' % tag, **out)
+    with open(os.path.join(HERE, 'state_dict_g5.json'), 'w') as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45']
+    if 'g1' in what:
+        g1_graph()
+    if 'g2' in what:
+        g2_units()
+    if 'g3' in what:
+        g3_blocks()
+    if 'g45' in what:
+        g45_models()
