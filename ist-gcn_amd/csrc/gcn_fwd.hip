@@ -1,0 +1,399 @@
+// Graph-convolution unit, forward: y = einsum('nkctv,kvw->nctw', conv1x1(x), A)  (+ per-joint bias term)
+// computed aggregate-first:
+//     xa[p=(t,w)][(k,i)] = sum_v A[k][v][w] * x[(t,v)][i]          sparse VALU pass, LDS -> LDS
+//     y[p][c]            = sum_(k,i) Wr[c][(k,i)] * xa[p][(k,i)]   MFMA 32x32, fp32 accumulate
+// Replaces (reference file:line): net/utils/tgcn.py:76-89, net/utils/tgcn_multi3_fix_3A.py:76-92,
+// net/utils/inceptionv2_gcn.py:64-89 (all variants fold into one effective adjacency A, host side),
+// and -- with K=1, A=I and a frame stride -- the residual 1x1 strided Conv2d of st_gcnold.py:186-193.
+// The same kernel run on dy with A^T and the transposed weights is the unit's data gradient.
+//
+// One workgroup (4 waves) owns a tile of F = floor(128/V) whole frames of one sequence (<=128 rows
+// of the NTVC tensor, contiguous in HBM) x all output channels of its grid.y block; workgroups walk
+// tiles in a grid-stride loop so that the adjacency lists, BatchNorm partial sums and the
+// weight-fragment working set are amortised.  Wave w owns rows [32w, 32w+32) (the MFMA "column" axis);
+// output channels are the MFMA "row" axis, so each lane ends up with 4 consecutive channels of one
+// row per register quad, which is what the LDS-staged, fully coalesced epilogue wants.
+#include "common.hpp"
+
+namespace {
+
+struct GcnFwdParams {
+  const void* x;
+  const float* A;        // [K][V][V]  A[k][v][w]
+  const void* Wp;        // fragment-ordered weights, see istgcn.h
+  const float* bterm;    // [V][Cout] or null
+  const void* addend;    // same layout as y or null (may alias y)
+  void* y;
+  double* stats;         // [stats_rep][2][Cout] or null
+  int* status;           // overflow flag or null
+  int NM, Tin, Tout, Tlog, V, Cin, Cout, K;
+  int in_t_stride, out_t_stride;
+  int nnz_cap, stats_rep;
+  int F, tiles_per_seq, total_tiles;
+  int CCeff, nch, KKp, NKG, MTtot;
+  int xs_stride, xa_stride, out_stride;   // in elements
+  int off_csr_v, off_csr_a, off_stat, off_rows, off_work;  // LDS byte offsets
+};
+
+constexpr int TILE_ROWS = 128;
+constexpr int NTHREADS = 256;
+
+template <typename T, int MT, bool VEC_IN, bool VEC_OUT>
+__global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  constexpr int KGS = E::KGS;
+  typedef typename E::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int* csr_off = reinterpret_cast<int*>(smem);                       // [K*V+1]
+  unsigned char* csr_v = smem + P.off_csr_v;                         // [nnz_cap]
+  float* csr_a = reinterpret_cast<float*>(smem + P.off_csr_a);       // [nnz_cap]
+  float* stat = reinterpret_cast<float*>(smem + P.off_stat);         // [2][MT*32]
+  unsigned char* row_f = smem + P.off_rows;                          // [128]
+  unsigned char* row_w = row_f + TILE_ROWS;                          // [128]
+  T* xs = reinterpret_cast<T*>(smem + P.off_work);                   // [128][xs_stride]
+  T* xa = xs + TILE_ROWS * P.xs_stride;                              // [128][xa_stride]
+  T* outs = xs;                                                      // [128][out_stride] (aliases xs/xa)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int V = P.V, K = P.K;
+  const int KV = K * V;
+  const int mt0 = blockIdx.y * MT;
+  const int cbase_blk = mt0 * 32;
+
+  // ---- one-time setup: CSR lists of the adjacency columns, row tables, stat accumulators ----
+  for (int c = tid; c <= KV; c += NTHREADS) csr_off[c] = 0;
+  for (int c = tid; c < 2 * MT * 32; c += NTHREADS) stat[c] = 0.f;
+  for (int r = tid; r < TILE_ROWS; r += NTHREADS) {
+    int f = r / V;
+    row_f[r] = (unsigned char)f;
+    row_w[r] = (unsigned char)(r - f * V);
+  }
+  __syncthreads();
+  for (int col = tid; col < KV; col += NTHREADS) {
+    int k = col / V, w = col - k * V, cnt = 0;
+    for (int v = 0; v < V; ++v) cnt += (P.A[(k * V + v) * V + w] != 0.f);
+    csr_off[col + 1] = cnt;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 0; c < KV; ++c) { int n = csr_off[c + 1]; csr_off[c] = run; run += n; }
+    csr_off[KV] = run;
+    if (run > P.nnz_cap && P.status) *P.status = 1;
+  }
+  __syncthreads();
+  for (int col = tid; col < KV; col += NTHREADS) {
+    int k = col / V, w = col - k * V, e = csr_off[col];
+    for (int v = 0; v < V; ++v) {
+      float a = P.A[(k * V + v) * V + w];
+      if (a != 0.f) {
+        if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
+        ++e;
+      }
+    }
+  }
+  __syncthreads();
+
+  // aggregation thread map: 8 rows x 32 vector slots per pass; a thread owns <=2 vector slots
+  const int Q = P.CCeff / EPL;            // channel vectors per partition
+  const int NV = P.KKp / EPL;             // vectors per xa row (incl. zero padding)
+  const int a_slot = tid & 31;
+  const int a_row0 = tid >> 5;
+  int a_k[2], a_q[2];
+  bool a_on[2], a_real[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    int vq = a_slot + 32 * s;
+    a_on[s] = vq < NV;
+    a_real[s] = vq < K * Q;
+    a_k[s] = a_real[s] ? vq / Q : 0;
+    a_q[s] = a_real[s] ? vq - a_k[s] * Q : 0;
+  }
+
+  const T* xg = reinterpret_cast<const T*>(P.x);
+  const T* Wp = reinterpret_cast<const T*>(P.Wp);
+  T* yg = reinterpret_cast<T*>(P.y);
+  const T* addg = reinterpret_cast<const T*>(P.addend);
+
+  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    const int n = tile / P.tiles_per_seq;
+    const int t0 = (tile - n * P.tiles_per_seq) * P.F;
+    const int nf = min(P.F, P.Tlog - t0);
+    const int rows = nf * V;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    for (int ch = 0; ch < P.nch; ++ch) {
+      const int cb = ch * P.CCeff;
+      // ---- stage x chunk: rows x CCeff channels -> xs (zero beyond Cin) ----
+      {
+        const int tot = rows * Q;
+        for (int it = tid; it < tot; it += NTHREADS) {
+          int r = it / Q, q = it - r * Q;
+          int f = row_f[r], v = row_w[r];
+          size_t g = ((size_t)(n * P.Tin + (t0 + f) * P.in_t_stride) * V + v) * P.Cin + cb + q * EPL;
+          frag_t val;
+          if (VEC_IN) {
+            if (cb + q * EPL < P.Cin) val = *reinterpret_cast<const frag_t*>(xg + g);
+            else zero_frag<T>(val);
+          } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) val[j] = (cb + q * EPL + j < P.Cin) ? xg[g + j] : E::from_f(0.f);
+          }
+          *reinterpret_cast<frag_t*>(xs + r * P.xs_stride + q * EPL) = val;
+        }
+      }
+      __syncthreads();
+      // ---- sparse aggregation xs -> xa (all 128 rows written: pad rows / pad columns are zero) ----
+      for (int r = a_row0; r < TILE_ROWS; r += 8) {
+        const int f = row_f[r], w = row_w[r];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (!a_on[s]) continue;
+          float sum[EPL];
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
+          if (a_real[s] && r < rows) {
+            const int col = a_k[s] * V + w;
+            const int e1 = min(csr_off[col + 1], P.nnz_cap);
+            for (int e = csr_off[col]; e < e1; ++e) {
+              const float a = csr_a[e];
+              const frag_t xv = *reinterpret_cast<const frag_t*>(xs + (f * V + csr_v[e]) * P.xs_stride + a_q[s] * EPL);
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) sum[j] += a * E::to_f(xv[j]);
+            }
+          }
+          frag_t o;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
+          *reinterpret_cast<frag_t*>(xa + r * P.xa_stride + (a_slot + 32 * s) * EPL) = o;
+        }
+      }
+      __syncthreads();
+      // ---- channel contraction on the matrix cores ----
+      {
+        const T* brow = xa + (wave * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
+        const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
+        for (int kg = 0; kg < P.NKG; ++kg) {
+          const frag_t b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const frag_t a = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
+            mma_kgroup(acc[m], a, b);
+          }
+        }
+      }
+      __syncthreads();   // xa / xs free again (next chunk or the epilogue's staging buffer)
+    }
+
+    // ---- epilogue: accumulators -> LDS (row-major, channels innermost) -> coalesced HBM store ----
+    constexpr int NPASS = (MT + 1) / 2;
+    constexpr int VPR = 64 / EPL;                // vectors per staged row
+    constexpr int RSTEP = NTHREADS / VPR;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      {
+        const int p = wave * 32 + (lane & 31);
+        const int w = row_w[p];
+#pragma unroll
+        for (int ml = 0; ml < 2; ++ml) {
+          const int m = 2 * ps + ml;
+          if (m < MT) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
+              const int cg = cbase_blk + ps * 64 + cl;
+              float v4[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float bv = 0.f;
+                if (P.bterm && p < rows && cg + j < P.Cout) bv = P.bterm[w * P.Cout + cg + j];
+                v4[j] = acc[m][4 * g + j] + bv;
+              }
+              store4(outs + p * P.out_stride + cl, v4);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int vq = tid % VPR;
+        const int cg = cbase_blk + ps * 64 + vq * EPL;
+        float s1[EPL], s2[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        const bool col_live = (2 * ps * 32 + vq * EPL) < MT * 32 && cg < P.Cout;
+        if (col_live) {
+          for (int r = tid / VPR; r < rows; r += RSTEP) {
+            const int f = row_f[r], w = row_w[r];
+            const size_t g = ((size_t)(n * P.Tout + (t0 + f) * P.out_t_stride) * V + w) * P.Cout + cg;
+            const frag_t sv = *reinterpret_cast<const frag_t*>(outs + r * P.out_stride + vq * EPL);
+            if (VEC_OUT) {
+              frag_t o = sv;
+              if (addg) {
+                const frag_t av = *reinterpret_cast<const frag_t*>(addg + g);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) o[j] = E::from_f(E::to_f(sv[j]) + E::to_f(av[j]));
+              }
+              *reinterpret_cast<frag_t*>(yg + g) = o;
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) { float fv = E::to_f(o[j]); s1[j] += fv; s2[j] += fv * fv; }
+            } else {
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) {
+                if (cg + j < P.Cout) {
+                  float fv = E::to_f(sv[j]);
+                  if (addg) fv += E::to_f(addg[g + j]);
+                  const T o = E::from_f(fv);
+                  yg[g + j] = o;
+                  fv = E::to_f(o);
+                  s1[j] += fv; s2[j] += fv * fv;
+                }
+              }
+            }
+          }
+        }
+        if (P.stats) {
+          // lanes that share a channel vector differ by multiples of VPR
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+#pragma unroll
+            for (int msk = VPR; msk < 64; msk <<= 1) {
+              s1[j] += __shfl_xor(s1[j], msk);
+              s2[j] += __shfl_xor(s2[j], msk);
+            }
+          }
+          if (lane < VPR && col_live) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+              const int cl = ps * 64 + vq * EPL + j;
+              if (cbase_blk + cl < P.Cout) {
+                atomicAdd(&stat[cl], s1[j]);
+                atomicAdd(&stat[MT * 32 + cl], s2[j]);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (P.stats) {
+    __syncthreads();
+    double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
+    for (int c = tid; c < MT * 32; c += NTHREADS) {
+      if (cbase_blk + c < P.Cout) {
+        atomic_add_f64(dst + cbase_blk + c, (double)stat[c]);
+        atomic_add_f64(dst + P.Cout + cbase_blk + c, (double)stat[MT * 32 + c]);
+      }
+    }
+  }
+}
+
+template <typename T, int MT>
+int launch_mt(const GcnFwdParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+  constexpr int EPL = Elem<T>::EPL;
+  const bool vin = (P.Cin % EPL) == 0, vout = (P.Cout % EPL) == 0;
+#define GO(VI, VO)                                                                                          \
+  do {                                                                                                      \
+    auto kfn = gcn_fwd_kernel<T, MT, VI, VO>;                                                               \
+    static bool attr_done = false;                                                                          \
+    if (!attr_done) {                                                                                       \
+      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
+          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      attr_done = true;                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+  } while (0)
+  if (vin && vout) GO(true, true);
+  else if (vin) GO(true, false);
+  else if (vout) GO(false, true);
+  else GO(false, false);
+#undef GO
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+template <typename T>
+int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  P.CCeff = P.Cin >= E::CC ? E::CC : round_up(P.Cin, EPL);
+  P.nch = ceil_div(P.Cin, P.CCeff);
+  P.KKp = round_up(P.K * P.CCeff, E::KGS);
+  P.NKG = P.KKp / E::KGS;
+  if (P.KKp / EPL > 64) return ISTGCN_EINVAL;
+  int MT = P.Cout <= 32 ? 1 : P.Cout <= 64 ? 2 : P.Cout <= 128 ? 4 : 8;
+  int gy = ceil_div(P.Cout, MT * 32);
+  P.MTtot = gy * MT;
+  P.F = TILE_ROWS / P.V;
+  P.tiles_per_seq = ceil_div(P.Tlog, P.F);
+  P.total_tiles = P.NM * P.tiles_per_seq;
+  P.xs_stride = P.CCeff + EPL;
+  P.xa_stride = P.KKp + EPL;
+  P.out_stride = 64 + EPL;
+  size_t off = (size_t)(P.K * P.V + 1) * sizeof(int);
+  off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
+  off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
+  off = (off + 15) & ~(size_t)15; P.off_stat = (int)off; off += (size_t)2 * MT * 32 * 4;
+  off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TILE_ROWS;
+  off = (off + 15) & ~(size_t)15; P.off_work = (int)off;
+  size_t work = (size_t)TILE_ROWS * (P.xs_stride + P.xa_stride) * sizeof(T);
+  size_t ost = (size_t)TILE_ROWS * P.out_stride * sizeof(T);
+  off += work > ost ? work : ost;
+  if (off > 160 * 1024) return ISTGCN_EINVAL;
+  int gx = P.total_tiles < grid_x_cap ? P.total_tiles : grid_x_cap;
+  if (gx < 1) return ISTGCN_OK;
+  dim3 grid(gx, gy);
+  switch (MT) {
+    case 1: return launch_mt<T, 1>(P, grid, off, stream);
+    case 2: return launch_mt<T, 2>(P, grid, off, stream);
+    case 4: return launch_mt<T, 4>(P, grid, off, stream);
+    default: return launch_mt<T, 8>(P, grid, off, stream);
+  }
+}
+
+}  // namespace
+
+extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* bterm,
+                              const void* addend, void* y, double* stats, int stats_rep, int* status,
+                              int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
+                              int in_t_stride, int out_t_stride, int nnz_cap, int dtype, int grid_cap,
+                              void* stream) {
+  if (!x || !A || !Wp || !y) return ISTGCN_EINVAL;
+  if (NM < 0 || Tlog < 0 || V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 8) return ISTGCN_EINVAL;
+  if (in_t_stride < 1 || out_t_stride < 1 || nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
+  if (Tlog > 0 && ((Tlog - 1) * in_t_stride >= Tin || (Tlog - 1) * out_t_stride >= Tout)) return ISTGCN_EINVAL;
+  if (stats && stats_rep < 1) return ISTGCN_EINVAL;
+  if (NM == 0 || Tlog == 0) return ISTGCN_OK;
+  GcnFwdParams P{};
+  P.x = x; P.A = A; P.Wp = Wp; P.bterm = bterm; P.addend = addend; P.y = y; P.stats = stats; P.status = status;
+  P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Tlog = Tlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K;
+  P.in_t_stride = in_t_stride; P.out_t_stride = out_t_stride; P.nnz_cap = nnz_cap;
+  P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
+  if (grid_cap < 1) grid_cap = 1024;
+  if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
+  if (dtype == 1) return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
+  return ISTGCN_EINVAL;
+}
+
+// Geometry query so the host can size / order the fragment-packed weights exactly as the kernel reads them.
+extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp,
+                                   int* MTtot, int* EPL) {
+  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  const int epl = dtype == 0 ? 4 : 8, cc = dtype == 0 ? 32 : 64, kgs = 2 * epl;
+  int cce = Cin >= cc ? cc : round_up(Cin, epl);
+  int MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : Cout <= 128 ? 4 : 8;
+  *CCeff = cce; *nch = ceil_div(Cin, cce); *KKp = round_up(K * cce, kgs);
+  *MTtot = ceil_div(Cout, MT * 32) * MT; *EPL = epl;
+  return ISTGCN_OK;
+}

@@ -1,0 +1,174 @@
+"""-m gpu: the graph-conv HIP kernel (through the C ABI) against the golden fixtures and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from gpu_util import dev, to_ntvc, to_nctv, diag, OUT
+from oracle import stgcn_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from istgcn_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_probe_mfma_lane_maps(ops, dt):
+    """A = exact small integers, asymmetric B: pins the A/B/D lane maps of common.hpp."""
+    import ctypes
+    kgs = 8 if dt == torch.float32 else 16
+    g = torch.Generator().manual_seed(5)
+    A = torch.randint(-4, 5, (32, kgs), generator=g).float()
+    Bt = torch.randint(-4, 5, (32, kgs), generator=g).float() + torch.arange(32).float()[:, None] * 0.0
+    Bt[:, 0] += torch.arange(32).float()        # asymmetric
+    D = torch.zeros(32, 32, device=dev())
+    a, b = A.to(dev(), dt).contiguous(), Bt.to(dev(), dt).contiguous()
+    ops._call('istgcn_probe_mfma', ops._ptr(a), ops._ptr(b), ops._ptr(D), ops.dtype_code(a), ops._stream(a))
+    torch.cuda.synchronize()
+    assert torch.equal(D.cpu(), A @ Bt.t())
+
+
+def test_probe_tr16(ops):
+    """ds_read_b64_tr_b16: record what each lane receives for the addressing the bf16 kernels use."""
+    R_, C_ = 16, 32
+    src = (torch.arange(R_)[:, None] * 256 + torch.arange(C_)[None, :]).to(torch.int16).contiguous()
+    lane = torch.arange(64)
+    grp, idx = lane // 16, lane % 16
+    q, p = idx // 4, idx % 4
+    # group g: block rows 4*(g>>1).. , columns 16*(g&1)..
+    row = 4 * (grp // 2) + q
+    col = 16 * (grp % 2) + 4 * p
+    off = ((row * C_ + col) * 2).to(torch.int32)
+    out = torch.zeros(64, 4, dtype=torch.int16, device=dev())
+    s, o = src.to(dev()), off.to(dev())
+    ops._call('istgcn_probe_tr16', ops._ptr(s), R_ * C_, ops._ptr(o), ops._ptr(out), ops._stream(s))
+    torch.cuda.synchronize()
+    got = out.cpu().to(torch.int32) & 0xFFFF
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'probe_tr16.txt'), 'w') as f:
+        for l in range(64):
+            f.write('lane %2d addr(row %2d col %2d) -> %s\n' % (l, row[l], col[l], ['r%dc%d' % (v >> 8, v & 255) for v in got[l].tolist()]))
+    # expectation (cdna guide T10): lane i of a 16-lane group receives column i of the 4 rows
+    exp = torch.stack([(4 * (grp // 2) + j) * 256 + 16 * (grp % 2) + idx for j in range(4)], 1)
+    assert torch.equal(got, exp.to(torch.int32))
+
+
+def _unit(golden, ci):
+    g = golden('units_g2.npz')
+    b = 'c%d.' % ci
+    return g, b, (lambda k: torch.from_numpy(g[b + k]))
+
+
+def _fold(unit, t):
+    A, A2, A3 = t('A'), t('A2'), t('A3')
+    i1, i2, i3 = t('imp1'), t('imp2'), t('imp3')
+    if unit == 'tgcn':
+        return A * i1
+    if unit == '3a':
+        return A * i1 + A ** 2 * i2 + A ** 3 * i3
+    if unit in ('inc', 'incnew'):
+        return A * i1 + A2 * i2 + A3 * i3
+    Ai = A * i1
+    return {'multi3': Ai + Ai ** 2 + Ai ** 3, 'multi3fix': (Ai + Ai ** 2 + Ai ** 3) / 3, 'only3': Ai ** 3}[unit]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ci', range(4))
+@pytest.mark.parametrize('unit', ['tgcn', '3a', 'inc', 'incnew', 'multi3', 'multi3fix', 'only3'])
+def test_gcn_unit_golden(ops, golden, unit, ci, dt):
+    """y and dx of every GCN-unit variant of the reference = ONE kernel with a folded adjacency."""
+    g, b, t = _unit(golden, ci)
+    x, r, W, bias = t('x'), t('r'), t('W'), t('b')
+    Aeff = _fold(unit, t)
+    K, V = Aeff.shape[0], Aeff.shape[1]
+    cout, cin = W.shape[0] // K, W.shape[1]
+    d = dev()
+    Wk = W.view(K, cout, cin)
+    wr = Wk.permute(1, 0, 2).contiguous().to(d)                     # Wr[c][k][i]
+    bterm = torch.einsum('kc,kw->wc', bias.view(K, cout), Aeff.sum(1)).contiguous().to(d)
+    xg = to_ntvc(x).to(d, dt)
+    y = ops.gcn_forward(xg, Aeff.to(d).contiguous(), ops.pack_gcn_weight(wr, dt), cout, bterm=bterm)
+    torch.cuda.synchronize()
+    name = 'gcn_%s_c%d_%s' % (unit, ci, str(dt)[6:])
+    assert diag(name + '_y', to_nctv(y.float()), g[b + unit + '.y'], TOL[dt]) < TOL[dt]
+    # data gradient: same kernel, A^T and Wr^T  (W'[i][k][c] = W[k*Cout+c][i])
+    wt = Wk.permute(2, 0, 1).contiguous().to(d)
+    dy = to_ntvc(r).to(d, dt)
+    dx = ops.gcn_forward(dy, Aeff.transpose(1, 2).contiguous().to(d), ops.pack_gcn_weight(wt, dt), cin)
+    torch.cuda.synchronize()
+    assert diag(name + '_dx', to_nctv(dx.float()), g[b + unit + '.dx'], TOL[dt]) < TOL[dt]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [
+    # NM, Cin, Cout, T, V, K, dense
+    (3, 64, 64, 23, 25, 3, False), (2, 64, 128, 11, 25, 3, False), (2, 128, 256, 9, 25, 3, False),
+    (2, 256, 256, 7, 18, 3, True), (1, 3, 64, 300, 25, 3, False), (2, 64, 64, 12, 25, 4, True),
+    (2, 40, 24, 5, 15, 2, True), (5, 96, 320, 6, 19, 1, True),
+])
+def test_gcn_fwd_random_vs_oracle(ops, shape, dt):
+    """ragged tiles, channel padding, K=1..4, dense adjacency, BatchNorm partial sums, addend."""
+    NM, cin, cout, T, V, K, dense = shape
+    g = torch.Generator().manual_seed(hash(shape) & 0xFFFF)
+    x = torch.randn(NM, cin, T, V, generator=g)
+    W = torch.randn(K * cout, cin, 1, 1, generator=g) * cin ** -0.5
+    bias = torch.randn(K * cout, generator=g) * 0.1
+    A = torch.rand(K, V, V, generator=g)
+    if not dense:
+        A = A * (torch.rand(K, V, V, generator=g) < 0.12)
+    add = torch.randn(NM, cout, T, V, generator=g)
+    if dt == torch.bfloat16:   # compare like with like: oracle sees the same rounded inputs
+        x, add = x.bfloat16().float(), add.bfloat16().float()
+    ref = R.graph_einsum(torch.nn.functional.conv2d(x, W, bias), A) + add
+    d = dev()
+    wr = W.view(K, cout, cin).permute(1, 0, 2).contiguous().to(d)
+    bterm = torch.einsum('kc,kw->wc', bias.view(K, cout), A.sum(1)).contiguous().to(d)
+    stats = torch.zeros(ops.STATS_REP, 2, cout, dtype=torch.float64, device=d)
+    y = ops.gcn_forward(to_ntvc(x).to(d, dt), A.to(d), ops.pack_gcn_weight(wr, dt), cout, bterm=bterm,
+                        addend=to_ntvc(add).to(d, dt), stats=stats, nnz_cap=int((A != 0).sum()))
+    torch.cuda.synchronize()
+    name = 'gcnrand_%s_%s' % ('x'.join(map(str, shape[:6])), str(dt)[6:])
+    assert diag(name, to_nctv(y.float()), ref, TOL[dt]) < TOL[dt]
+    yf = y.double().cpu()
+    s = stats.sum(0).cpu()
+    assert rel_err(s[0], yf.sum((0, 1, 2))) < 1e-5
+    assert rel_err(s[1], (yf * yf).sum((0, 1, 2))) < 1e-5
+
+
+def test_gcn_strided_and_accumulate(ops):
+    """K=1, A=I, in stride 2 = the residual Conv2d(1x1, stride (2,1)) of st_gcnold.py:186-191; its data
+    gradient scatters into every other frame of an existing tensor (accumulate + out stride)."""
+    g = torch.Generator().manual_seed(9)
+    NM, cin, cout, T, V = 2, 64, 128, 14, 25
+    x = torch.randn(NM, cin, T, V, generator=g)
+    W = torch.randn(cout, cin, 1, 1, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.conv2d(x, W, bias, stride=(2, 1))
+    d = dev()
+    eye = torch.eye(V).view(1, V, V).contiguous().to(d)
+    bterm = bias.view(1, cout).expand(V, cout).contiguous().to(d)
+    y = ops.gcn_forward(to_ntvc(x).to(d), eye, ops.pack_gcn_weight(W.view(cout, 1, cin).to(d), torch.float32), cout,
+                        bterm=bterm, in_t_stride=2, nnz_cap=V)
+    assert diag('gcn_strided', to_nctv(y), ref, 2e-5) < 2e-5
+    dy = torch.randn(NM, cout, T // 2, V, generator=g)
+    base = torch.randn(NM, cin, T, V, generator=g)
+    xx = x.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(xx, W, bias, stride=(2, 1)).backward(dy)
+    buf = to_ntvc(base).to(d)
+    wt = W.view(cout, cin).t().contiguous().view(cin, 1, cout).to(d)
+    ops.gcn_forward(to_ntvc(dy).to(d), eye, ops.pack_gcn_weight(wt, torch.float32), cin, addend=buf, out=buf,
+                    Tout=T, out_t_stride=2, nnz_cap=V)
+    assert diag('gcn_strided_bwd', to_nctv(buf), base + xx.grad, 2e-5) < 2e-5
+
+
+def test_requires_gpu_no_fallback(ops):
+    x = torch.zeros(1, 2, 25, 8)
+    with pytest.raises(RuntimeError):
+        ops.gcn_forward(x, torch.zeros(1, 25, 25), torch.zeros(8), 8)
