@@ -48,6 +48,40 @@ int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* b
                    int V, int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int nnz_cap,
                    int dtype, int grid_cap, void* stream);
 
+/* Temporal (k,1) convolution over the frame axis as an implicit GEMM (and its data gradient):
+ *   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) ),
+ *   m in [0, Mlog); input frames outside [0, Tin) contribute zero.
+ * = nn.Conv2d(C, C, (9,1), (stride,1), (4,0)) net/st_gcnold.py:167-173 with the preceding BatchNorm2d+ReLU
+ *   (:165-166) applied on the fly (`pre` = [2][Cin] scale, shift; pre_relu) and the following BatchNorm2d's
+ *   (:174) batch sums emitted (`stats`); the three-branch Inception-TCN of
+ *   net/st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215 / net/st_gcn_mstcn.py:189-209,242-245 is the same call with
+ *   15 host-pre-summed taps.  Forward: in_mul = stride, tap_off[j] = j - pad, out_mul = 1, out_off = 0.
+ *   Data gradient: per phase p of the output frames, taps with (p + pad - j) % stride == 0, tap_off = (p+pad-j)/stride,
+ *   in_mul = 1, out_mul = stride, out_off = p, Wf[j][i][o] = W[o][i][j].
+ * mode 0: epi = + bias[o];            stats += sum(out), sum(out^2)
+ * mode 1: epi = * [aux*maux[0]+maux[1] > 0] (ReLU mask of the producer BatchNorm, aux = its input, same shape as out);
+ *                                     stats += sum(out), sum(out * (aux - maux[2]) * maux[3])   (BatchNorm backward)
+ * Wp: fragment-ordered weights, element (((((ch*ntaps + j)*MTtot + mt)*NKG + kg)*2 + h)*32 + r)*EPL + e holds
+ *   Wf[j][32*mt + r][ch*CC + kg*2*EPL + h*EPL + e]; CC, nch, MTtot, EPL from istgcn_tconv_geometry, NKG = CC/(2*EPL). */
+int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int* CC,
+                          int* nch, int* MTtot, int* EPL);
+int istgcn_tconv(const void* in, const void* Wp, const float* bias, const float* pre, int pre_relu, const void* aux,
+                 const float* maux, void* out, double* stats, int stats_rep, int mode, int NM, int Tin, int Tout,
+                 int Mlog, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int out_mul,
+                 int out_off, int dtype, int grid_cap, void* stream);
+
+/* Weight / bias gradient of the temporal convolution (autograd of net/st_gcnold.py:167-173 and of the pre-summed
+ * Inception-TCN): dW[j][o][i] += sum_{n,m,v} dz[n,m,v,o] * pre(g[n, in_mul*m + tap_off[j], v, i]),  dbias[o] += sum dz.
+ *   dz [NM][Tz][V][Cout]   g [NM][Tin][V][Cin]   pre [2][Cin] scale, shift (+ReLU) or NULL
+ *   dW [ntaps][Cout][Cin] fp32 and dbias [Cout] fp32 (or NULL) are ACCUMULATED into: the caller zeroes them. */
+int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, float* dbias,
+                       int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
+                       int in_mul, int dtype, int grid_cap, void* stream);
+
+/* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
+int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);
+int istgcn_probe_tr16(const void* src, int nelem, const int* lane_byte_off, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,393 @@
+// Temporal convolution over the frame axis of an NTVC tensor as an implicit GEMM on the matrix cores:
+//
+//   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) )
+//
+// for m in [0, Mlog); frames outside [0, Tin) contribute zero (the Conv2d zero padding, applied AFTER `pre`).
+//   pre  = optional per-channel affine + ReLU  -> the BatchNorm2d+ReLU in front of the conv
+//          (net/st_gcnold.py:165-166 `tcn.0/tcn.1`, `tcn_start` of net/st_gcn_multi3_fix_3A_mstcn.py:159-162)
+//   sum  = the (k,1) Conv2d, stride (s,1): st_gcnold.py:167-173; the three-branch Inception-TCN
+//          x1*m0 + x2*m1 + x3*m2 of st_gcn_multi3_fix_3A_mstcn.py:212-215 (and the /3 of st_gcn_mstcn.py:245)
+//          is ONE 15-tap convolution whose taps the host pre-sums (linear in the weights).
+//   epi  = + bias, and per-channel sum / sum-of-squares for the train-mode BatchNorm2d that follows
+//          (st_gcnold.py:174), or -- for the data gradient -- the ReLU mask of the producer's BatchNorm+ReLU
+//          recomputed from `aux`, with the two BatchNorm-backward reductions.
+// Forward: in_mul = stride, tap_off[j] = j - pad, out_mul = 1.  Data gradient: one launch per output phase
+// (t mod stride) with the taps that hit that phase, in_mul = 1, out_mul = stride, out_off = phase.
+//
+// A workgroup (4 waves) owns TR = 128*NT output rows (whole frames of one sequence) x up to 128 output
+// channels; the input rows it needs (with the tap halo) are staged per channel chunk into LDS once and then
+// re-read at a row offset per tap, so the activation is fetched from HBM/L2 once per chunk, not once per tap.
+// Tiles of one sequence are kept on one XCD (grid-stride order below) so halo re-reads hit that XCD's L2.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int MAX_TAPS = 16;
+
+struct TconvParams {
+  const void* in;
+  const void* Wp;
+  const float* bias;     // [Cout] or null
+  const float* pre;      // [2][Cin] scale, shift or null
+  const void* aux;       // epilogue mode 1: [NM][Tout][V][Cout]
+  const float* maux;     // epilogue mode 1: [4][Cout] scale, shift, mean, rstd
+  void* out;
+  double* stats;         // [stats_rep][2][Cout] or null
+  int NM, Tin, Tout, Mlog, V, Cin, Cout, ntaps;
+  int in_mul, out_mul, out_off, pre_relu, mode, stats_rep;
+  int tap_off[MAX_TAPS];
+  // derived on the host
+  int F, tiles_per_seq, total_tiles, CC, nch, NKG, MTtot, min_off, Fin;
+  int us_stride, out_stride, off_stat, off_work;
+};
+
+template <typename T, int MT, int NT, bool VEC>
+__global__ __launch_bounds__(NTHREADS) void tconv_kernel(const TconvParams P) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  constexpr int KGS = E::KGS;
+  constexpr int TR = 128 * NT;
+  typedef typename E::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);          // [TR]
+  unsigned short* row_v = row_f + TR;                                        // [TR]
+  float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
+  T* us = reinterpret_cast<T*>(smem + P.off_work);                           // [Fin*V][us_stride]
+  T* outs = us;                                                              // [128][out_stride]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = P.V;
+  const int mt0 = blockIdx.y * MT;
+  const int cbase_blk = mt0 * 32;
+  const int Q = P.CC / EPL;
+
+  for (int r = tid; r < TR; r += NTHREADS) {
+    int f = r / V;
+    row_f[r] = (unsigned short)f;
+    row_v[r] = (unsigned short)(r - f * V);
+  }
+  for (int c = tid; c < 2 * MT * 32; c += NTHREADS) stat[c] = 0.f;
+  __syncthreads();
+
+  const T* ing = reinterpret_cast<const T*>(P.in);
+  const T* Wp = reinterpret_cast<const T*>(P.Wp);
+  const T* auxg = reinterpret_cast<const T*>(P.aux);
+  T* outg = reinterpret_cast<T*>(P.out);
+
+  // XCD-affine persistent order: XCD x (= blockIdx.x % 8 under round-robin dispatch; speed only) walks the
+  // contiguous tile range [x*chunk, (x+1)*chunk), its workgroups taking neighbouring tiles at each step.
+  const int G8 = gridDim.x >> 3;
+  const int chunk = (P.total_tiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+
+  for (int slot = blockIdx.x >> 3; slot < chunk; slot += G8) {
+    const int tile = xcd * chunk + slot;
+    if (tile >= P.total_tiles) break;
+    const int n = tile / P.tiles_per_seq;
+    const int m0 = (tile - n * P.tiles_per_seq) * P.F;
+    const int nf = min(P.F, P.Mlog - m0);
+    const int rows = nf * V;
+    const int fin0 = P.in_mul * m0 + P.min_off;          // first staged input frame (may be < 0)
+    const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    // per-lane LDS row of its output rows at tap offset 0 (pad rows clamp to row 0: computed, never stored)
+    int brow[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int p = wave * (32 * NT) + t * 32 + (lane & 31);
+      brow[t] = p < rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0;
+    }
+
+    for (int ch = 0; ch < P.nch; ++ch) {
+      const int cb = ch * P.CC;
+      // ---- stage the input rows of this chunk (BatchNorm affine + ReLU applied on the way in) ----
+      for (int it = tid; it < in_rows * Q; it += NTHREADS) {
+        const int r = it / Q, q = it - r * Q;
+        const int fl = r / V, v = r - fl * V;
+        const int fr = fin0 + fl;
+        const int c0 = cb + q * EPL;
+        frag_t val;
+        zero_frag<T>(val);
+        if (fr >= 0 && fr < P.Tin && c0 < P.Cin) {
+          const size_t g = ((size_t)(n * P.Tin + fr) * V + v) * P.Cin + c0;
+          if (VEC) {
+            val = *reinterpret_cast<const frag_t*>(ing + g);
+          } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) if (c0 + j < P.Cin) val[j] = ing[g + j];
+          }
+          if (P.pre) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+              if (VEC || c0 + j < P.Cin) {
+                float fv = E::to_f(val[j]) * P.pre[c0 + j] + P.pre[P.Cin + c0 + j];
+                if (P.pre_relu) fv = fmaxf(fv, 0.f);
+                val[j] = E::from_f(fv);
+              }
+            }
+          }
+        }
+        *reinterpret_cast<frag_t*>(us + r * P.us_stride + q * EPL) = val;
+      }
+      __syncthreads();
+      // ---- taps x k-groups on the matrix cores ----
+      for (int j = 0; j < P.ntaps; ++j) {
+        const int roff = (P.tap_off[j] - P.min_off) * V;
+        const T* wtap = Wp + ((size_t)((ch * P.ntaps + j) * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
+        for (int kg = 0; kg < P.NKG; ++kg) {
+          frag_t b[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            b[t] = *reinterpret_cast<const frag_t*>(us + (brow[t] + roff) * P.us_stride + kg * KGS + (lane >> 5) * EPL);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const frag_t a = *reinterpret_cast<const frag_t*>(wtap + ((size_t)m * P.NKG + kg) * 64 * EPL);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a, b[t]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: per (row slab t, 64-channel pass) through LDS, coalesced stores, BatchNorm sums ----
+    constexpr int NPASS = (MT + 1) / 2;
+    constexpr int VPR = 64 / EPL;
+    constexpr int RSTEP = NTHREADS / VPR;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        {
+          const int sr = wave * 32 + (lane & 31);       // staging row
+#pragma unroll
+          for (int ml = 0; ml < 2; ++ml) {
+            const int m = 2 * ps + ml;
+            if (m < MT) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
+                const int cg = cbase_blk + ps * 64 + cl;
+                float v4[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                  float bv = (P.bias && cg + jj < P.Cout) ? P.bias[cg + jj] : 0.f;
+                  v4[jj] = acc[m][t][4 * g + jj] + bv;
+                }
+                store4(outs + sr * P.out_stride + cl, v4);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        {
+          const int vq = tid % VPR;
+          const int cg = cbase_blk + ps * 64 + vq * EPL;
+          const bool col_live = (ps * 64 + vq * EPL) < MT * 32 && cg < P.Cout;
+          float s1[EPL], s2[EPL];
+#pragma unroll
+          for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; }
+          if (col_live) {
+            for (int sr = tid / VPR; sr < 128; sr += RSTEP) {
+              const int p = (sr >> 5) * (32 * NT) + t * 32 + (sr & 31);
+              if (p >= rows) continue;
+              const int f = row_f[p], v = row_v[p];
+              const size_t g = ((size_t)(n * P.Tout + (m0 + f) * P.out_mul + P.out_off) * V + v) * P.Cout + cg;
+              frag_t sv = *reinterpret_cast<const frag_t*>(outs + sr * P.out_stride + vq * EPL);
+              frag_t av;
+              if (P.mode == 1) {
+                if (VEC) av = *reinterpret_cast<const frag_t*>(auxg + g);
+                else {
+#pragma unroll
+                  for (int jj = 0; jj < EPL; ++jj) av[jj] = (cg + jj < P.Cout) ? auxg[g + jj] : E::from_f(0.f);
+                }
+              }
+#pragma unroll
+              for (int jj = 0; jj < EPL; ++jj) {
+                if (VEC || cg + jj < P.Cout) {
+                  float fv = E::to_f(sv[jj]);
+                  if (P.mode == 1) {
+                    const int c = cg + jj;
+                    const float xa = E::to_f(av[jj]);
+                    const bool on = xa * P.maux[c] + P.maux[P.Cout + c] > 0.f;
+                    fv = on ? fv : 0.f;
+                    const T o = E::from_f(fv);
+                    sv[jj] = o;
+                    fv = E::to_f(o);
+                    s1[jj] += fv;
+                    s2[jj] += fv * (xa - P.maux[2 * P.Cout + c]) * P.maux[3 * P.Cout + c];
+                  } else {
+                    s1[jj] += fv;
+                    s2[jj] += fv * fv;
+                  }
+                }
+              }
+              if (VEC) *reinterpret_cast<frag_t*>(outg + g) = sv;
+              else {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g + jj] = sv[jj];
+              }
+            }
+          }
+          if (P.stats) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+#pragma unroll
+              for (int msk = VPR; msk < 64; msk <<= 1) {
+                s1[jj] += __shfl_xor(s1[jj], msk);
+                s2[jj] += __shfl_xor(s2[jj], msk);
+              }
+            }
+            if (lane < VPR && col_live) {
+#pragma unroll
+              for (int jj = 0; jj < EPL; ++jj) {
+                const int cl = ps * 64 + vq * EPL + jj;
+                if (cbase_blk + cl < P.Cout) {
+                  atomicAdd(&stat[cl], s1[jj]);
+                  atomicAdd(&stat[MT * 32 + cl], s2[jj]);
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  if (P.stats) {
+    __syncthreads();
+    double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
+    for (int c = tid; c < MT * 32; c += NTHREADS) {
+      if (cbase_blk + c < P.Cout) {
+        atomic_add_f64(dst + cbase_blk + c, (double)stat[c]);
+        atomic_add_f64(dst + P.Cout + cbase_blk + c, (double)stat[MT * 32 + c]);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NT>
+int launch3(const TconvParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+  const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
+#define GO(VV)                                                                                              \
+  do {                                                                                                      \
+    auto kfn = tconv_kernel<T, MT, NT, VV>;                                                                 \
+    static bool attr_done = false;                                                                          \
+    if (!attr_done) {                                                                                       \
+      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
+          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      attr_done = true;                                                                                     \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+  } while (0)
+  if (vec) GO(true); else GO(false);
+#undef GO
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+// Tiling decision shared by the launcher and the geometry query (the host packs weights to match).
+struct TconvGeom { int CC, nch, NKG, MT, MTtot, gy, NT, F, Fin, min_off, lds, off_stat, off_work, us_stride, out_stride; };
+
+inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, TconvGeom* G) {
+  const int epl = dtype == 0 ? 4 : 8, kgs = 2 * epl, esz = dtype == 0 ? 4 : 2;
+  int mn = tap_off[0], mx = tap_off[0];
+  for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
+  G->min_off = mn;
+  G->MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
+  G->gy = ceil_div(Cout, G->MT * 32);
+  G->MTtot = G->gy * G->MT;
+  G->out_stride = 64 + epl;
+  const int budget = 78 * 1024;                       // two workgroups per CU
+  const int cc_max = dtype == 0 ? 32 : 64;
+  int best_nt = 0, best_cc = 0;
+  for (int nt = 2; nt >= 1 && !best_nt; --nt) {
+    if (nt * 128 / V < 1) continue;
+    for (int cc = cc_max; cc >= kgs; cc >>= 1) {
+      const int F = nt * 128 / V;
+      const int Fin = in_mul * (F - 1) + (mx - mn) + 1;
+      const long need = (long)Fin * V * (cc + epl) * esz;
+      if (need <= budget) { best_nt = nt; best_cc = cc; break; }
+    }
+  }
+  if (!best_nt) { best_nt = 1; best_cc = kgs; }
+  int cc = best_cc;
+  if (Cin < cc) cc = round_up(Cin, kgs);
+  G->NT = best_nt; G->CC = cc; G->nch = ceil_div(Cin, cc); G->NKG = cc / kgs;
+  G->F = best_nt * 128 / V;
+  G->Fin = in_mul * (G->F - 1) + (mx - mn) + 1;
+  G->us_stride = cc + epl;
+  size_t off = (size_t)2 * 128 * best_nt * sizeof(unsigned short);
+  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off; off += (size_t)2 * G->MT * 32 * 4;
+  off = (off + 15) & ~(size_t)15; G->off_work = (int)off;
+  size_t work = (size_t)G->Fin * V * G->us_stride * esz;
+  size_t ost = (size_t)128 * G->out_stride * esz;
+  off += work > ost ? work : ost;
+  G->lds = (int)off;
+  return off <= 160 * 1024 ? ISTGCN_OK : ISTGCN_EINVAL;
+}
+
+template <typename T>
+int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t stream) {
+  P.F = G.F; P.CC = G.CC; P.nch = G.nch; P.NKG = G.NKG; P.MTtot = G.MTtot; P.min_off = G.min_off; P.Fin = G.Fin;
+  P.us_stride = G.us_stride; P.out_stride = G.out_stride; P.off_stat = G.off_stat; P.off_work = G.off_work;
+  P.tiles_per_seq = ceil_div(P.Mlog, P.F);
+  P.total_tiles = P.NM * P.tiles_per_seq;
+  int gx = round_up(P.total_tiles < grid_cap ? P.total_tiles : grid_cap, 8);
+  dim3 grid(gx, G.gy);
+  const size_t lds = G.lds;
+#define CASE(MTv, NTv) if (G.MT == MTv && G.NT == NTv) return launch3<T, MTv, NTv>(P, grid, lds, stream)
+  CASE(1, 1); CASE(2, 1); CASE(4, 1); CASE(1, 2); CASE(2, 2); CASE(4, 2);
+#undef CASE
+  return ISTGCN_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype,
+                                     int* CC, int* nch, int* MTtot, int* EPL) {
+  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!tap_off || ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1) return ISTGCN_EINVAL;
+  TconvGeom G;
+  int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
+  if (rc) return rc;
+  *CC = G.CC; *nch = G.nch; *MTtot = G.MTtot; *EPL = dtype == 0 ? 4 : 8;
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, const float* pre, int pre_relu,
+                            const void* aux, const float* maux, void* out, double* stats, int stats_rep, int mode,
+                            int NM, int Tin, int Tout, int Mlog, int V, int Cin, int Cout, int ntaps,
+                            const int* tap_off, int in_mul, int out_mul, int out_off, int dtype, int grid_cap,
+                            void* stream) {
+  if (!in || !Wp || !out || !tap_off) return ISTGCN_EINVAL;
+  if (ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1 || out_mul < 1) return ISTGCN_EINVAL;
+  if (NM < 0 || Mlog < 0 || out_off < 0 || (mode != 0 && mode != 1)) return ISTGCN_EINVAL;
+  if (mode == 1 && (!aux || !maux)) return ISTGCN_EINVAL;
+  if (Mlog > 0 && (Mlog - 1) * out_mul + out_off >= Tout) return ISTGCN_EINVAL;
+  if (stats && stats_rep < 1) return ISTGCN_EINVAL;
+  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (NM == 0 || Mlog == 0) return ISTGCN_OK;
+  TconvParams P{};
+  P.in = in; P.Wp = Wp; P.bias = bias; P.pre = pre; P.aux = aux; P.maux = maux; P.out = out; P.stats = stats;
+  P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Mlog = Mlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
+  P.in_mul = in_mul; P.out_mul = out_mul; P.out_off = out_off; P.pre_relu = pre_relu; P.mode = mode;
+  P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
+  for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
+  TconvGeom G;
+  int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
+  if (rc) return rc;
+  if (grid_cap < 8) grid_cap = 1024;
+  if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
+  return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
+}

@@ -1,0 +1,134 @@
+"""-m gpu: temporal-convolution HIP kernel (forward, data gradient, fused BN/ReLU prologue, mask epilogue)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from gpu_util import dev, to_ntvc, to_nctv, diag
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 3e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from istgcn_amd import ops as o
+    return o
+
+
+CASES = [
+    # NM, Cin, Cout, T, V, k, stride
+    (2, 64, 64, 23, 25, 9, 1), (2, 64, 128, 20, 25, 9, 2), (1, 128, 128, 31, 25, 15, 1), (2, 256, 256, 12, 18, 9, 1),
+    (2, 16, 16, 16, 25, 3, 1), (2, 8, 8, 17, 25, 15, 2), (3, 11, 11, 9, 25, 9, 1), (1, 64, 64, 300, 25, 9, 1),
+    (2, 128, 256, 30, 25, 15, 2),
+]
+
+
+def _mk(case, dt, seed=0):
+    NM, cin, cout, T, V, k, s = case
+    g = torch.Generator().manual_seed(1000 + seed + hash(case) % 1000)
+    x = torch.randn(NM, cin, T, V, generator=g)
+    W = torch.randn(cout, cin, k, 1, generator=g) * (cin * k) ** -0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    sc = 0.5 + torch.rand(cin, generator=g)
+    sh = torch.randn(cin, generator=g) * 0.3
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    return x, W, b, sc, sh
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+def test_tconv_forward(ops, case, dt):
+    NM, cin, cout, T, V, k, s = case
+    x, W, b, sc, sh = _mk(case, dt)
+    u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if dt == torch.bfloat16:
+        u = u.bfloat16().float()
+    ref = F.conv2d(u, W, b, stride=(s, 1), padding=((k - 1) // 2, 0))
+    Tout = ref.shape[2]
+    d = dev()
+    taps, in_mul = ops.conv_taps_fwd(k, s)
+    wf = W[:, :, :, 0].permute(2, 0, 1).contiguous().to(d)          # [k][Cout][Cin]
+    wp = ops.pack_tconv_weight(wf, V, taps, in_mul, dt)
+    stats = torch.zeros(ops.STATS_REP, 2, cout, dtype=torch.float64, device=d)
+    y = ops.tconv(to_ntvc(x).to(d, dt), wp, cout, taps, bias=b.to(d), pre=torch.stack([sc, sh]).to(d), pre_relu=True,
+                  stats=stats, Tout=Tout, Mlog=Tout, in_mul=in_mul)
+    torch.cuda.synchronize()
+    name = 'tconv_fwd_%s_%s' % ('x'.join(map(str, case)), str(dt)[6:])
+    assert diag(name, to_nctv(y.float()), ref, TOL[dt]) < TOL[dt]
+    yf = y.double().cpu()
+    s_ = stats.sum(0).cpu()
+    assert rel_err(s_[0], yf.sum((0, 1, 2))) < 1e-5 and rel_err(s_[1], (yf * yf).sum((0, 1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+def test_tconv_data_gradient_with_mask(ops, case, dt):
+    """du = conv^T(dz) per output phase, then the ReLU mask of the producer BN recomputed from `aux` and the two
+    BatchNorm-backward reductions sum(d1), sum(d1 * xhat)."""
+    NM, cin, cout, T, V, k, s = case
+    x, W, b, sc, sh = _mk(case, dt, seed=1)
+    g = torch.Generator().manual_seed(77)
+    Tz = (T + 2 * ((k - 1) // 2) - k) // s + 1
+    dz = torch.randn(NM, cout, Tz, V, generator=g)
+    mean = torch.randn(cin, generator=g) * 0.2
+    rstd = 0.5 + torch.rand(cin, generator=g)
+    if dt == torch.bfloat16:
+        dz = dz.bfloat16().float()
+    u = x.clone().requires_grad_(True)
+    F.conv2d(u, W, None, stride=(s, 1), padding=((k - 1) // 2, 0)).backward(dz)
+    on = (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
+    ref = u.grad * on
+    d = dev()
+    out = torch.full((NM, T, V, cin), float('nan'), device=d, dtype=dt)
+    stats = torch.zeros(ops.STATS_REP, 2, cin, dtype=torch.float64, device=d)
+    maux = torch.stack([sc, sh, mean, rstd]).to(d)
+    xg = to_ntvc(x).to(d, dt)
+    for phase in range(s):
+        tl = ops.conv_taps_bwd(k, s, phase)
+        Mlog = (T - phase + s - 1) // s
+        if not tl:
+            continue
+        wt = torch.stack([W[:, :, j, 0].t() for j, _ in tl]).contiguous().to(d)      # [taps][Cin][Cout]
+        offs = [dj for _, dj in tl]
+        wp = ops.pack_tconv_weight(wt, V, offs, 1, dt)
+        ops.tconv(to_ntvc(dz).to(d, dt), wp, cin, offs, aux=xg, maux=maux, out=out, stats=stats, mode=1,
+                  Tout=T, Mlog=Mlog, in_mul=1, out_mul=s, out_off=phase)
+    torch.cuda.synchronize()
+    name = 'tconv_bwd_%s_%s' % ('x'.join(map(str, case)), str(dt)[6:])
+    assert diag(name, to_nctv(out.float()), ref, TOL[dt]) < TOL[dt]
+    of = out.double().cpu()
+    xhat = (to_ntvc(x).double() - mean.double()) * rstd.double()
+    s_ = stats.sum(0).cpu()
+    assert rel_err(s_[0], of.sum((0, 1, 2))) < 1e-5
+    assert rel_err(s_[1], (of * xhat).sum((0, 1, 2))) < 1e-4
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+def test_tconv_weight_gradient(ops, case, dt):
+    """dW[j][o][i] and dbias against autograd of relu(bn(x)) -> conv2d."""
+    NM, cin, cout, T, V, k, s = case
+    x, W, b, sc, sh = _mk(case, dt, seed=2)
+    g = torch.Generator().manual_seed(78)
+    u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    if dt == torch.bfloat16:
+        u = u.bfloat16().float()
+    Wp = W.clone().requires_grad_(True)
+    bp = b.clone().requires_grad_(True)
+    z = F.conv2d(u, Wp, bp, stride=(s, 1), padding=((k - 1) // 2, 0))
+    dz = torch.randn(z.shape, generator=g)
+    if dt == torch.bfloat16:
+        dz = dz.bfloat16().float()
+    z.backward(dz)
+    d = dev()
+    taps, in_mul = ops.conv_taps_fwd(k, s)
+    dW, db = ops.tconv_wgrad(to_ntvc(dz).to(d, dt), to_ntvc(x).to(d, dt), taps, in_mul=in_mul,
+                             pre=torch.stack([sc, sh]).to(d), pre_relu=True)
+    torch.cuda.synchronize()
+    ref = Wp.grad[:, :, :, 0].permute(2, 0, 1)
+    tol = 2e-5 if dt == torch.float32 else 5e-3
+    name = 'tconv_wgrad_%s_%s' % ('x'.join(map(str, case)), str(dt)[6:])
+    assert diag(name, dW, ref, tol) < tol
+    assert diag(name + '_db', db, bp.grad, tol) < tol
