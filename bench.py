@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Throughput of the IST-GCN hot path on MI355X: skeleton-clips/sec, forward + backward (+ SGD step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--model st_gcn_msgcn] [--batch 64]
+
+N=1 workload = BASELINE.json configs[1]: net/st_gcn_msgcn.py (Inception-GCN), NTU-RGB+D xsub shape
+(C=3, T=300, V=25, M=2, 60 classes), batch 64 clips per GPU, training step of processor/recognition.py:249-296
+(train mode, dropout 0.5, CrossEntropy, SGD-nesterov) on synthetic clips and random-init weights.
+N>1 (launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one process per GPU,
+the batch axis sharded (64 clips per GPU, weak scaling), one flat-bucket gradient all-reduce per step over RCCL.
+
+One JSON line on rank 0, with
+  roofline      the dominant kernel family of the step: algorithmic FLOPs (or bytes) of its launches / their summed
+                durations, HIP events on the launch stream inside the timed region (ops.PROFILE)
+  cpu_baseline  the oracle (CPU restatement of the reference, `oracle/stgcn_ref.py`) timed on this box's host cores on
+                a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {'mfma_f32': 157.3, 'mfma_bf16': 2500.0, 'hbm': 8000.0}       # TFLOP/s, TFLOP/s, GB/s  (MI355X_MICROARCH.md)
+MODELS = {
+    'st_gcnold': (dict(layout='ntu-rgb+d', strategy='spatial'), 60, 25),
+    'st_gcn_msgcn': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, 25),
+    'st_gcn_mstcn_1x1': (dict(layout='openpose', strategy='spatial'), 400, 18),
+    'st_gcn_multi3_fix_3A_mstcn': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60, 25),
+    'st_gcn_mstcn_1x1_deep': (dict(layout='ntu-rgb+d', strategy='spatial'), 60, 25),
+}
+FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit GEMM)',
+          'istgcn_tconv_wgrad': 'tconv_wgrad', 'istgcn_gcn_fwd': 'gcn_fwd (graph conv fwd + data-grad)',
+          'istgcn_gcn_wgrad': 'gcn_wgrad', 'istgcn_block_out_fwd': 'block_out_fwd', 'istgcn_block_out_bwd': 'block_out_bwd',
+          'istgcn_affine2': 'bn_bwd_apply'}
+
+
+def cpu_baseline(model_tag, T, seconds_budget=25.0):
+    """Oracle train step on the host cores: 1 warm-up + up to 3 timed steps of batch 8 (bounded sample)."""
+    from oracle import stgcn_ref as R
+    gargs, nc, V = MODELS[model_tag]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 8
+    m = R.RefModel(model_tag, 3, nc, gargs, True, dropout=0.5)
+    R.weights_init_(m, seed=0)
+    opt = R.make_optimizer(m)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 3, T, V, 2, generator=g)
+    y = torch.randint(0, nc, (B,), generator=g)
+    R.train_step(m, opt, x, y)                         # warm-up
+    t0, n = time.time(), 0
+    while n < 3 and (n == 0 or time.time() - t0 < seconds_budget):
+        R.train_step(m, opt, x, y)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': round(B / dt, 3), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed steps (1 warm-up) of batch %d, same model / clip shape (T=%d,V=%d,M=2), fp32, torch CPU, '
+                      'dropout 0.5, SGD step included' % (n, B, T, V)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default=os.environ.get('ISTGCN_BENCH_DTYPE', 'bf16'), choices=['bf16', 'f32'])
+    ap.add_argument('--model', default='st_gcn_msgcn', choices=sorted(MODELS))
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import importlib
+    import istgcn_amd  # noqa: F401
+    from istgcn_amd import ops, harness, dp
+    gargs, nc, V = MODELS[args.model]
+    T = args.frames or (600 if args.model.endswith('deep') else 300)
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    torch.manual_seed(0)
+    model = importlib.import_module('istgcn_amd.net.' + args.model).Model(3, nc, gargs, True, dropout=0.5,
+                                                                        compute_dtype=dt)
+    model.apply(harness.weights_init)
+    model.to(dev).train()
+    sync = dp.FlatGradSync(model) if world > 1 else None
+    opt = harness.make_optimizer(model)
+    g = torch.Generator().manual_seed(1234 + rank)
+    B = args.batch
+    x = torch.randn(B, 3, T, V, 2, generator=g).to(dev)
+    y = torch.randint(0, nc, (B,), generator=g).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        harness.train_step(model, opt, x, y, sync)
+    barrier()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = harness.train_step(model, opt, x, y, sync)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss_val = float(loss)
+
+    # ---- per-family totals from the HIP events of the timed region ----
+    fam = {}
+    for name, flops, nbytes, e0, e1 in prof:
+        rec = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
+        rec[0] += 1
+        rec[1] += e0.elapsed_time(e1) * 1e-3
+        rec[2] += flops
+        rec[3] += nbytes
+    dom = max(fam, key=lambda k: fam[k][1])
+    n, secs, flops, nbytes = fam[dom]
+    ridge = (PEAK['mfma_bf16'] if dt == torch.bfloat16 else PEAK['mfma_f32']) * 1e12 / (PEAK['hbm'] * 1e9)
+    if flops / max(nbytes, 1.0) >= ridge:
+        peak = PEAK['mfma_bf16'] if dt == torch.bfloat16 else PEAK['mfma_f32']
+        roof = {'bound': 'mfma', 'achieved': round(flops / secs / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s'}
+    else:
+        roof = {'bound': 'hbm', 'achieved': round(nbytes / secs / 1e9, 1), 'peak': PEAK['hbm'], 'unit': 'GB/s'}
+    roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+    roof['traffic'] = None
+    roof['kernel'] = FAMILY.get(dom, dom)
+    roof['launches'] = n
+    roof['avg_launch_ms'] = round(secs / n * 1e3, 4)
+    roof['share_of_gpu_time'] = round(secs / sum(v[1] for v in fam.values()), 3)
+    if args.breakdown and rank == 0:
+        tot = sum(v[1] for v in fam.values())
+        for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            sys.stderr.write('%-24s n=%5d  %8.2f ms/step  %5.1f%%  %8.1f TFLOP/s  %8.1f GB/s\n' % (
+                k, v[0], v[1] / args.steps * 1e3, 100 * v[1] / tot, v[2] / v[1] / 1e12, v[3] / v[1] / 1e9))
+        sys.stderr.write('kernels %.2f ms/step of %.2f ms/step wall\n' % (tot / args.steps * 1e3, elapsed / args.steps * 1e3))
+
+    if rank == 0:
+        line = {
+            'metric': 'skeleton-clips/sec fwd+bwd, NTU V=25 T=300',
+            'value': round(B * world * args.steps / elapsed, 2), 'unit': 'clips/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if dt == torch.bfloat16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'net/%s.py NTU xsub shape (N,3,%d,%d,2), %d clips/GPU, train step (fwd+bwd+SGD-nesterov), '
+                                   'dropout 0.5, random-init weights' % (args.model, T, V, B),
+                       'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
+                       'storage': 'bf16 activations, fp32 accumulate/params, fp64 BN sums' if dt == torch.bfloat16 else 'fp32'},
+            'roofline': roof, 'final_loss': round(loss_val, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.model, T)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -48,6 +48,17 @@ int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* b
                    int V, int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int nnz_cap,
                    int dtype, int grid_cap, void* stream);
 
+/* Parameter gradients of the graph-convolution unit (autograd of net/utils/tgcn.py:79-86 and the folded variants):
+ *   dW[k][c][i] += sum_{n,t,w} dy[n,t,w,c] * sum_v A[k][v][w] x[n,t,v,i]       (= Conv2d weight grad, [K*Cout][Cin])
+ *   dA[k][v][w] += sum_{n,t,i} x[n,t,v,i] * sum_c W[k][c][i] dy[n,t,w,c]       only where A[k][v][w] != 0
+ *   S[w][c]     += sum_{n,t} dy[n,t,w,c]                                        (bias-term gradient)
+ * dy [NM][T][V][Cout], x [NM][T][V][Cin], A [K][V][V] fp32, K <= 4.  dW / dA / S are fp32, ACCUMULATED (caller zeroes).
+ * dA, S may be NULL.  Wq (needed with dA): W^T fragments, element [ct][it][k][kg][h][r][e] =
+ * W[k][32*ct + kg*2*EPL + h*EPL + e][32*it + r], zero padded (EPL = 4 fp32 / 8 bf16). */
+int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, const void* Wq, float* dW, float* dA, float* S,
+                     int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap,
+                     void* stream);
+
 /* Temporal (k,1) convolution over the frame axis as an implicit GEMM (and its data gradient):
  *   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) ),
  *   m in [0, Mlog); input frames outside [0, Tin) contribute zero.
@@ -77,6 +88,36 @@ int istgcn_tconv(const void* in, const void* Wp, const float* bias, const float*
 int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, float* dbias,
                        int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
                        int in_mul, int dtype, int grid_cap, void* stream);
+
+/* BatchNorm2d bookkeeping (train-mode statistics are batch sums the MFMA kernels emit in their epilogues).
+ * istgcn_bn_finalize: stats [rep][2][C] fp64 (sum, sum of squares) over `count` elements per channel ->
+ *   coef [4][C] fp32 = scale (gamma*rstd), shift (beta - mean*scale), mean, rstd; training != 0 also updates
+ *   running_mean / running_var in place (momentum, unbiased variance) exactly as nn.BatchNorm2d does
+ *   (net/st_gcnold.py:165,174,192); training == 0 derives coef from the running statistics (eval mode).
+ * istgcn_bn_bwd_coef: stats [rep][2][C] = (sum d, sum d*xhat) -> abc [3][C] with dx = abc0*d + abc1*x + abc2,
+ *   dgamma = sum d*xhat, dbeta = sum d (autograd of BatchNorm2d); training == 0: dx = gamma*rstd*d. */
+int istgcn_bn_finalize(const double* stats, int stats_rep, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, int training,
+                       float* coef, int C, void* stream);
+int istgcn_bn_bwd_coef(const double* stats, int stats_rep, double count, const float* gamma, const float* coef,
+                       int training, float* abc, float* dgamma, float* dbeta, int C, void* stream);
+
+/* Tail of the st_gcn block, net/st_gcnold.py:174-175 + 201-203 (tcn.3 BatchNorm, tcn.4 Dropout, + residual, ReLU):
+ *   out = relu( dropout_p( z*coef2[0] + coef2[1] ) + res' ),  res' = res (identity) or res*coefr[0] + coefr[1]
+ *   (the BatchNorm of the strided 1x1 residual branch, :186-193) or 0 (res == NULL).  rows = NM*T*V, C channels.
+ * Dropout: counter-based Philox4x32-10 keyed by (seed, flat element index); the same (p, seed) in the backward
+ * calls regenerates the mask.  p = 0 disables it.
+ * istgcn_block_out_bwd: dres = dout * [out > 0] (the gradient of both the residual branch and, after dropout, of
+ *   tcn.3); stats2 += (sum dres*mask, sum dres*mask*zhat); statsr += (sum dres, sum dres*rhat) when the residual
+ *   branch has a BatchNorm (r = its input, coefr = its coef[4][C]); r == NULL otherwise.
+ * istgcn_affine2: out = abc[0]*d*mask + abc[1]*x + abc[2]  (elementwise part of BatchNorm backward; x may be NULL). */
+int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
+                         long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
+int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
+                         const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
+                         long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
+int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
+                   unsigned long long seed, int dtype, void* stream);
 
 /* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);

@@ -94,6 +94,10 @@ def load():
     global _lib, _err
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (SONAME libamdhip64.so.7).  It must be in the process BEFORE this library
+    # is dlopen'ed so that both share ONE runtime (device context, streams, allocations); loaded the other way round
+    # the system libamdhip64 would come in as a second, device-less runtime (hipErrorNoDevice at the first launch).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         _err = ('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
                 'There is no CPU fallback for the IST-GCN hot path.' % LIB_PATH)

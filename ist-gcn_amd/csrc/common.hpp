@@ -76,8 +76,16 @@ __device__ static inline void atomic_add_f64(double* p, double v) { unsafeAtomic
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// hipGetLastError() is per-thread and sticky across *any* HIP call of the host process (PyTorch's allocator polls
+// events and leaves hipErrorNotReady behind): clear it before our launch so the check below sees only our own.
+#define ISTGCN_LAUNCH(...)            \
+  do {                                \
+    (void)hipGetLastError();          \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 #define ISTGCN_CHECK_LAUNCH()                         \
   do {                                                \
     hipError_t e_ = hipGetLastError();                \
-    if (e_ != hipSuccess) return ISTGCN_ELAUNCH;      \
+    if (e_ != hipSuccess) return 1000 + (int)e_;      \
   } while (0)

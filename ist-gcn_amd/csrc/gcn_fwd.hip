@@ -308,11 +308,11 @@ int launch_mt(const GcnFwdParams& P, dim3 grid, size_t lds, hipStream_t stream) 
     auto kfn = gcn_fwd_kernel<T, MT, VI, VO>;                                                               \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
-      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
-          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
   } while (0)
   if (vin && vout) GO(true, true);
   else if (vin) GO(true, false);

@@ -334,11 +334,11 @@ int launch_T(GwgParams& P, int grid_cap, hipStream_t stream) {
     auto kfn = gcn_wgrad_kernel<T, KTv>;                                                                    \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
-      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
-          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), off, stream, P);                                          \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), off, stream, P);                                          \
   } while (0)
   if (P.K == 1) GO(1);
   else if (P.K <= 3) GO(3);

@@ -1,0 +1,366 @@
+// HBM-bound glue of the st_gcn block around the two MFMA kernels (all on [rows = NM*T*V][C] NTVC views):
+//   bn_finalize     batch sums -> BatchNorm2d affine (train: batch stats + running-stat update; eval: running stats)
+//   block_out_fwd   out = relu( dropout( z*s2 + b2 ) + residual )                 net/st_gcnold.py:174-175,201-203
+//   block_out_bwd   d = dout * [out > 0]  (residual gradient), BatchNorm-backward sums of d*mask for tcn.3 and of d
+//                   for the residual BatchNorm                                   (autograd of the same lines)
+//   bn_bwd_coef     sums -> per-channel (a, b, c) with  dx = a*d*mask + b*x + c,  and dgamma, dbeta
+//   affine2         out = a[c]*d*mask + b[c]*x + c[c]                             (BatchNorm backward, elementwise part)
+// Dropout uses a counter-based Philox4x32-10 stream keyed by (seed, element index): the backward pass regenerates
+// the forward mask instead of storing it.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+  uint32_t c[4] = {c0, c1, 0x9E3779B9u, 0xBB67AE85u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// keep-mask scale factors (0 or 1/(1-p)) for VW consecutive elements starting at flat element index e0 (e0 % 4 == 0)
+template <int VW>
+__device__ static inline void drop_scales(float (&m)[VW], size_t e0, uint32_t thr, float inv_keep, uint32_t s0, uint32_t s1) {
+#pragma unroll
+  for (int b = 0; b < (VW + 3) / 4; ++b) {
+    uint32_t rnd[4];
+    const size_t blk = e0 / 4 + b;
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s0, s1, rnd);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * b + j < VW) m[4 * b + j] = rnd[j] >= thr ? inv_keep : 0.f;
+  }
+}
+__device__ static inline float drop_scale1(size_t e, uint32_t thr, float inv_keep, uint32_t s0, uint32_t s1) {
+  uint32_t rnd[4];
+  const size_t blk = e / 4;
+  philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s0, s1, rnd);
+  return rnd[e & 3] >= thr ? inv_keep : 0.f;
+}
+
+template <typename T, int VW>
+__device__ static inline void load_vec(const T* p, float (&f)[VW]) {
+  if constexpr (VW == Elem<T>::EPL) {
+    typename Elem<T>::frag r = *reinterpret_cast<const typename Elem<T>::frag*>(p);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) f[j] = Elem<T>::to_f(r[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) f[j] = Elem<T>::to_f(p[j]);
+  }
+}
+template <typename T, int VW>
+__device__ static inline void store_vec(T* p, float (&f)[VW]) {
+  if constexpr (VW == Elem<T>::EPL) {
+    typename Elem<T>::frag r;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) r[j] = Elem<T>::from_f(f[j]);
+    *reinterpret_cast<typename Elem<T>::frag*>(p) = r;
+  } else {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) p[j] = Elem<T>::from_f(f[j]);
+  }
+}
+
+struct DropCfg { uint32_t thr; float inv_keep; uint32_t s0, s1; int on; };
+
+static inline DropCfg make_drop(float p, unsigned long long seed) {
+  DropCfg d{};
+  d.on = p > 0.f;
+  if (d.on) {
+    double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    d.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
+  }
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, int rep, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, float momentum, float eps, int training, float* coef,
+                                   int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, rstd;
+  if (training) {
+    double s = 0, ss = 0;
+    for (int r = 0; r < rep; ++r) { s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c]; }
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = rmean[c];
+    rstd = 1.f / sqrtf(rvar[c] + eps);
+  }
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  coef[c] = g * rstd;
+  coef[C + c] = b - mean * g * rstd;
+  coef[2 * C + c] = mean;
+  coef[3 * C + c] = rstd;
+}
+
+// dx = a*d + b*x + c ; a = g*rstd, b = -g*rstd^2*m2, c = -g*rstd*m1 + g*rstd^2*m2*mean   (m1 = sum d / M, m2 = sum d*xhat / M)
+__global__ void bn_bwd_coef_kernel(const double* stats, int rep, double count, const float* gamma, const float* coef,
+                                   int training, float* abc, float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, sx = 0;
+  for (int r = 0; r < rep; ++r) { s += stats[(size_t)r * 2 * C + c]; sx += stats[(size_t)r * 2 * C + C + c]; }
+  const float g = gamma ? gamma[c] : 1.f, mean = coef[2 * C + c], rstd = coef[3 * C + c];
+  if (dgamma) dgamma[c] = (float)sx;
+  if (dbeta) dbeta[c] = (float)s;
+  if (training) {
+    const double m1 = s / count, m2 = sx / count;
+    abc[c] = g * rstd;
+    abc[C + c] = (float)(-(double)g * rstd * rstd * m2);
+    abc[2 * C + c] = (float)(-(double)g * rstd * m1 + (double)g * rstd * rstd * m2 * mean);
+  } else {
+    abc[c] = g * rstd; abc[C + c] = 0.f; abc[2 * C + c] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int VW>
+__global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const float* coef2, const T* res, const float* coefr,
+                                                          T* out, size_t rows, int C, DropCfg D) {
+  const int QC = C / VW;
+  const size_t total = rows * QC;
+  for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+    const int q = (int)(idx % QC);
+    const int c0 = q * VW;
+    const size_t e0 = idx * VW;
+    float zv[VW], rv[VW], m[VW];
+    load_vec<T, VW>(z + e0, zv);
+    if (res) load_vec<T, VW>(res + e0, rv);
+    if (D.on) {
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float y = zv[j] * coef2[c0 + j] + coef2[C + c0 + j];
+      if (D.on) y *= m[j];
+      if (res) y += coefr ? rv[j] * coefr[c0 + j] + coefr[C + c0 + j] : rv[j];
+      zv[j] = fmaxf(y, 0.f);
+    }
+    store_vec<T, VW>(out + e0, zv);
+  }
+}
+
+// d = dout*[out>0] -> dres ; stats2 += (sum d*mask, sum d*mask*zhat) ; statsr += (sum d, sum d*rhat)
+template <typename T, int VW>
+__global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const T* z, const float* coef2,
+                                                          const T* r, const float* coefr, T* dres, double* stats2,
+                                                          double* statsr, int rep, size_t rows, int C, DropCfg D) {
+  __shared__ float red[4][NT];
+  const int QC = C / VW;                 // vectors per row; NT % QC == 0 is guaranteed by the launcher
+  const int q = threadIdx.x % QC;
+  const int c0 = q * VW;
+  const size_t rstep = (size_t)gridDim.x * (NT / QC);
+  float a1[VW], a2[VW], b1[VW], b2[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) { a1[j] = a2[j] = b1[j] = b2[j] = 0.f; }
+  for (size_t row = (size_t)blockIdx.x * (NT / QC) + threadIdx.x / QC; row < rows; row += rstep) {
+    const size_t e0 = row * C + c0;
+    float dv[VW], ov[VW], zv[VW], rv[VW], m[VW];
+    load_vec<T, VW>(dout + e0, dv);
+    load_vec<T, VW>(out + e0, ov);
+    load_vec<T, VW>(z + e0, zv);
+    if (r) load_vec<T, VW>(r + e0, rv);
+    if (D.on) {
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const float d = ov[j] > 0.f ? dv[j] : 0.f;
+      dv[j] = d;
+      const float dm = D.on ? d * m[j] : d;
+      a1[j] += dm;
+      a2[j] += dm * (zv[j] - coef2[2 * C + c0 + j]) * coef2[3 * C + c0 + j];
+      if (r) {
+        b1[j] += d;
+        b2[j] += d * (rv[j] - coefr[2 * C + c0 + j]) * coefr[3 * C + c0 + j];
+      }
+    }
+    store_vec<T, VW>(dres + e0, dv);
+  }
+  // block reduction over the NT/QC threads that share a channel vector
+#pragma unroll
+  for (int j = 0; j < VW; ++j) {
+    red[0][threadIdx.x] = a1[j]; red[1][threadIdx.x] = a2[j]; red[2][threadIdx.x] = b1[j]; red[3][threadIdx.x] = b2[j];
+    __syncthreads();
+    if (threadIdx.x < QC) {
+      float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      for (int t = threadIdx.x; t < NT; t += QC) { s0 += red[0][t]; s1 += red[1][t]; s2 += red[2][t]; s3 += red[3][t]; }
+      const int c = c0 + j;
+      double* d2 = stats2 + (size_t)(blockIdx.x % rep) * 2 * C;
+      atomic_add_f64(d2 + c, (double)s0);
+      atomic_add_f64(d2 + C + c, (double)s1);
+      if (r) {
+        double* dr = statsr + (size_t)(blockIdx.x % rep) * 2 * C;
+        atomic_add_f64(dr + c, (double)s2);
+        atomic_add_f64(dr + C + c, (double)s3);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int VW>
+__global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, const float* abc, T* out, size_t rows, int C,
+                                                    DropCfg D) {
+  const int QC = C / VW;
+  const size_t total = rows * QC;
+  for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+    const int c0 = (int)(idx % QC) * VW;
+    const size_t e0 = idx * VW;
+    float dv[VW], xv[VW], m[VW];
+    load_vec<T, VW>(d + e0, dv);
+    if (x) load_vec<T, VW>(x + e0, xv);
+    if (D.on) {
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      else {
+#pragma unroll
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float v = dv[j];
+      if (D.on) v *= m[j];
+      v = v * abc[c0 + j];
+      if (x) v += xv[j] * abc[C + c0 + j] + abc[2 * C + c0 + j];
+      dv[j] = v;
+    }
+    store_vec<T, VW>(out + e0, dv);
+  }
+}
+
+static inline int ew_grid(size_t items) {
+  size_t g = (items + NT - 1) / NT;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// vector width: the 16-byte fragment when the channel count allows it and the per-channel thread map divides the block
+template <typename T> static inline int pick_vw(int C, bool need_div) {
+  const int epl = Elem<T>::EPL;
+  if (C % epl == 0 && (!need_div || (NT % (C / epl) == 0 && C / epl <= NT))) return epl;
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int istgcn_bn_finalize(const double* stats, int stats_rep, double count, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  int training, float* coef, int C, void* stream) {
+  if (!coef || C < 1) return ISTGCN_EINVAL;
+  if (training && (!stats || stats_rep < 1 || count <= 0)) return ISTGCN_EINVAL;
+  if (!training && (!running_mean || !running_var)) return ISTGCN_EINVAL;
+  ISTGCN_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, count,
+                     gamma, beta, running_mean, running_var, momentum, eps, training, coef, C);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_bn_bwd_coef(const double* stats, int stats_rep, double count, const float* gamma, const float* coef,
+                                  int training, float* abc, float* dgamma, float* dbeta, int C, void* stream) {
+  if (!stats || !coef || !abc || C < 1 || stats_rep < 1 || count <= 0) return ISTGCN_EINVAL;
+  ISTGCN_LAUNCH(bn_bwd_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, count,
+                     gamma, coef, training, abc, dgamma, dbeta, C);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+#define DISPATCH_VW(KERNEL, TYPE, VWBIG, grid, ...)                                                                   \
+  do {                                                                                                            \
+    if (vw == VWBIG) ISTGCN_LAUNCH((KERNEL<TYPE, VWBIG>), grid, dim3(NT), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else ISTGCN_LAUNCH((KERNEL<TYPE, 1>), grid, dim3(NT), 0, (hipStream_t)stream, __VA_ARGS__);              \
+  } while (0)
+
+extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
+                                    long long rows, int C, float p_drop, unsigned long long seed, int dtype,
+                                    void* stream) {
+  if (!z || !coef2 || !out || rows < 0 || C < 1 || (dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f)
+    return ISTGCN_EINVAL;
+  if (rows == 0) return ISTGCN_OK;
+  const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
+  const DropCfg D = make_drop(p_drop, seed);
+  const dim3 grid(ew_grid((size_t)rows * (C / vw)));
+  if (dtype == 0) {
+    const float *zz = (const float*)z, *rr = (const float*)res; float* oo = (float*)out;
+    DISPATCH_VW(block_out_fwd_kernel, float, 4, grid, zz, coef2, rr, coefr, oo, (size_t)rows, C, D);
+  } else {
+    const __bf16 *zz = (const __bf16*)z, *rr = (const __bf16*)res; __bf16* oo = (__bf16*)out;
+    DISPATCH_VW(block_out_fwd_kernel, __bf16, 8, grid, zz, coef2, rr, coefr, oo, (size_t)rows, C, D);
+  }
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
+                                    const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
+                                    long long rows, int C, float p_drop, unsigned long long seed, int dtype,
+                                    void* stream) {
+  if (!dout || !out || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
+  if ((r != nullptr) != (coefr != nullptr) || (r && !statsr)) return ISTGCN_EINVAL;
+  if ((dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
+  if (rows == 0) return ISTGCN_OK;
+  int vw = dtype == 0 ? pick_vw<float>(C, true) : pick_vw<__bf16>(C, true);
+  if (vw == 1 && (C > NT || NT % C != 0)) return ISTGCN_EINVAL;   // scalar map needs C | 256
+  const DropCfg D = make_drop(p_drop, seed);
+  const int rpb = NT / (C / vw);
+  size_t g = ((size_t)rows + rpb - 1) / rpb;
+  if (g > 1024) g = 1024;
+  const dim3 grid((int)g);
+  if (dtype == 0) {
+    DISPATCH_VW(block_out_bwd_kernel, float, 4, grid, (const float*)dout, (const float*)out, (const float*)z, coef2,
+                  (const float*)r, coefr, (float*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D);
+  } else {
+    DISPATCH_VW(block_out_bwd_kernel, __bf16, 8, grid, (const __bf16*)dout, (const __bf16*)out, (const __bf16*)z, coef2,
+                  (const __bf16*)r, coefr, (__bf16*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D);
+  }
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C,
+                              float p_drop, unsigned long long seed, int dtype, void* stream) {
+  if (!d || !abc || !out || rows < 0 || C < 1 || (dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f)
+    return ISTGCN_EINVAL;
+  if (rows == 0) return ISTGCN_OK;
+  const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
+  const DropCfg D = make_drop(p_drop, seed);
+  const dim3 grid(ew_grid((size_t)rows * (C / vw)));
+  if (dtype == 0) {
+    DISPATCH_VW(affine2_kernel, float, 4, grid, (const float*)d, (const float*)x, abc, (float*)out, (size_t)rows, C, D);
+  } else {
+    DISPATCH_VW(affine2_kernel, __bf16, 8, grid, (const __bf16*)d, (const __bf16*)x, abc, (__bf16*)out, (size_t)rows, C, D);
+  }
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}

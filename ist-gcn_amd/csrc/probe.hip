@@ -36,10 +36,10 @@ __global__ void probe_tr16_kernel(const unsigned short* src, int nelem, const in
 extern "C" int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream) {
   if (!A || !Bt || !D) return ISTGCN_EINVAL;
   if (dtype == 0)
-    hipLaunchKernelGGL(probe_mfma_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)A,
+    ISTGCN_LAUNCH(probe_mfma_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)A,
                        (const float*)Bt, D);
   else if (dtype == 1)
-    hipLaunchKernelGGL(probe_mfma_kernel<__bf16>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const __bf16*)A,
+    ISTGCN_LAUNCH(probe_mfma_kernel<__bf16>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const __bf16*)A,
                        (const __bf16*)Bt, D);
   else
     return ISTGCN_EINVAL;
@@ -49,7 +49,7 @@ extern "C" int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dt
 
 extern "C" int istgcn_probe_tr16(const void* src, int nelem, const int* lane_byte_off, void* out, void* stream) {
   if (!src || !lane_byte_off || !out || nelem < 1 || nelem > 16384) return ISTGCN_EINVAL;
-  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), nelem * 2, (hipStream_t)stream,
+  ISTGCN_LAUNCH(probe_tr16_kernel, dim3(1), dim3(64), nelem * 2, (hipStream_t)stream,
                      (const unsigned short*)src, nelem, lane_byte_off, (unsigned short*)out);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;

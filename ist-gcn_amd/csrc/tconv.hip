@@ -284,11 +284,11 @@ int launch3(const TconvParams& P, dim3 grid, size_t lds, hipStream_t stream) {
     auto kfn = tconv_kernel<T, MT, NT, VV>;                                                                 \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
-      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
-          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
   } while (0)
   if (vec) GO(true); else GO(false);
 #undef GO

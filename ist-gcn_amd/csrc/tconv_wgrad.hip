@@ -229,11 +229,11 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
     auto kfn = tconv_wgrad_kernel<T, JTv>;                                                                  \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
-      if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=  \
-          hipSuccess) return ISTGCN_ELAUNCH;                                                                \
+      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL(kfn, grid, dim3(NTHREADS), off, stream, P);                                          \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), off, stream, P);                                          \
   } while (0)
   if (P.ntaps <= 1) GO(1);
   else if (P.ntaps <= 3) GO(3);

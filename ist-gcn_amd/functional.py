@@ -1,0 +1,241 @@
+"""Autograd wiring of the HIP kernels: one `torch.autograd.Function` per fused stage.
+
+* `GraphConvFn`  -- the GCN unit alone (net/utils/tgcn.py:76-89 and variants), used by the unit-level
+                   drop-in modules in `net/utils/`.
+* `STGCNBlockFn` -- a whole st_gcn block (net/st_gcnold.py:197-203 and variants): GCN unit -> BN -> ReLU ->
+                   temporal conv (1 branch, 3 pre-summed branches, or the sqrt(C) bottleneck) -> BN -> Dropout
+                   -> + residual -> ReLU, forward and hand-written backward, all through `libistgcn_hip.so`.
+
+Everything *tiny* that depends on learnable parameters (folding importances into one adjacency, pushing the
+Conv2d bias through the einsum, pre-summing the Inception-TCN taps) is expressed with ordinary differentiable
+torch ops on (K,V,V)/(C,C,k)-sized tensors in `fold_*` below, so the kernels only ever see folded operands and
+return gradients w.r.t. those; autograd maps them back to the reference's parameters.
+Activations are NTVC ([N*M, T, V, C], see csrc/common.hpp); parameters and all statistics are fp32/fp64.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+# --------------------------------------------------------------------------------------------------
+# differentiable host-side folds (tiny tensors)
+# --------------------------------------------------------------------------------------------------
+def fold_adjacency(kind, A, imps, A2=None, A3=None):
+    """One effective adjacency for every GCN-unit variant (the einsum is linear in A):
+    plain  A*imp                                   st_gcnold.py:86
+    incep  A*imp + A2*imp2 + A3*imp3               st_gcn_msgcn.py:116-117 + inceptionv2_gcn.py:69-80
+    3a     A*imp + A**2*imp2 + A**3*imp3           tgcn_multi3_fix_3A.py:86-89 (elementwise powers)"""
+    if kind == 'plain':
+        return A * imps[0]
+    if kind == 'incep':
+        return A * imps[0] + A2 * imps[1] + A3 * imps[2]
+    if kind == '3a':
+        return A * imps[0] + (A * A) * imps[1] + (A * A * A) * imps[2]
+    raise KeyError(kind)
+
+
+def fold_bias_term(bias, A_eff, cout):
+    """Conv2d bias pushed through the einsum: bterm[w][c] = sum_k b[k*C+c] * sum_v A_eff[k][v][w]."""
+    K = A_eff.shape[0]
+    return torch.einsum('kc,kw->wc', bias.view(K, cout), A_eff.sum(1)).contiguous()
+
+
+def fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
+    """x1*m0 + x2*m1 + x3*m2 (st_gcn_multi3_fix_3A_mstcn.py:212-215; /3 in st_gcn_mstcn.py:245) with kernel sizes
+    3/9/15 and paddings 1/4/7 is ONE 15-tap convolution: taps [15][Cout][Cin] and one bias."""
+    t3 = w3[:, :, :, 0].permute(2, 0, 1) * mst[2]
+    t2 = F.pad(w2[:, :, :, 0].permute(2, 0, 1) * mst[1], (0, 0, 0, 0, 3, 3))
+    t1 = F.pad(w1[:, :, :, 0].permute(2, 0, 1) * mst[0], (0, 0, 0, 0, 6, 6))
+    taps = (t1 + t2 + t3) * scale
+    bias = (b1 * mst[0] + b2 * mst[1] + b3 * mst[2]) * scale
+    return taps.contiguous(), bias.contiguous()
+
+
+def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None):
+    """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase."""
+    NM, Tz = dz.shape[0], dz.shape[1]
+    out = torch.empty((NM, T_in, V, cin), dtype=dz.dtype, device=dz.device)
+    filled = False
+    for phase in range(stride):
+        tl = ops.conv_taps_bwd(k, stride, phase)
+        Mlog = (T_in - phase + stride - 1) // stride
+        if Mlog <= 0:
+            continue
+        if not tl:
+            if not filled:
+                out.zero_()
+                filled = True
+            continue
+        wt = torch.stack([w_taps[j].t() for j, _ in tl]).contiguous()          # [taps][Cin][Cout]
+        offs = [dj for _, dj in tl]
+        wp = ops.pack_tconv_weight(wt, V, offs, 1, dz.dtype)
+        ops.tconv(dz, wp, cin, offs, aux=aux, maux=maux, out=out, stats=stats, mode=0 if aux is None else 1,
+                  Tout=T_in, Mlog=Mlog, in_mul=1, out_mul=stride, out_off=phase)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# GCN unit
+# --------------------------------------------------------------------------------------------------
+class GraphConvFn(torch.autograd.Function):
+    """y = einsum('nkctv,kvw->nctw', conv1x1(x; W, b), A_eff) on NTVC tensors.
+    inputs: x [NM,T,V,Cin], A_eff [K,V,V], bterm [V,Cout] (or None), W3 [K,Cout,Cin]; nnz_cap int."""
+
+    @staticmethod
+    def forward(ctx, x, A_eff, bterm, W3, nnz_cap):
+        K, cout, cin = W3.shape
+        A_eff = A_eff.contiguous()
+        wp = ops.pack_gcn_weight(W3.permute(1, 0, 2), x.dtype)
+        y = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, nnz_cap=nnz_cap)
+        ctx.save_for_backward(x, A_eff, W3)
+        ctx.nnz_cap = nnz_cap
+        ctx.has_b = bterm is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, A_eff, W3 = ctx.saved_tensors
+        K, cout, cin = W3.shape
+        dy = dy.contiguous()
+        need_A = ctx.needs_input_grad[1]
+        dW, dA, S = ops.gcn_wgrad(dy, x, A_eff, W3 if need_A else None, want_dA=need_A, want_S=ctx.has_b,
+                                  nnz_cap=ctx.nnz_cap)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ops.pack_gcn_weight(W3.permute(2, 0, 1), dy.dtype)          # W'[i][k][c]
+            dx = ops.gcn_forward(dy, A_eff.transpose(1, 2).contiguous(), wt, cin, nnz_cap=ctx.nnz_cap)
+        return dx, dA, (S if ctx.has_b else None), dW, None
+
+
+# --------------------------------------------------------------------------------------------------
+# whole st_gcn block
+# --------------------------------------------------------------------------------------------------
+class BlockCfg:
+    """Static description of one block (shapes, variant, BatchNorm hyper-parameters)."""
+
+    def __init__(self, cin, cout, K, V, stride, residual, tcn, ksize, p_drop, nnz_cap, width=None,
+                 momentum=0.1, eps=1e-5):
+        self.cin, self.cout, self.K, self.V, self.stride = cin, cout, K, V, stride
+        self.residual = residual          # 'none' | 'id' | 'conv'
+        self.tcn = tcn                    # 'conv' (single or pre-summed multi-branch) | 'bneck'
+        self.ksize = ksize                # temporal taps of the (folded) conv: 9 or 15
+        self.p_drop, self.nnz_cap = p_drop, nnz_cap
+        self.width = width                # bottleneck width int(sqrt(C))
+        self.momentum, self.eps = momentum, eps
+
+
+class STGCNBlockFn(torch.autograd.Function):
+    """forward(cfg, training, seed, bn_buffers, x, A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2,
+               Wr, br, gr, betar, Ws, bs, We, be)
+    Wt/bt: temporal taps [k][Cw][Cw] + bias (Cw = cout, or the bottleneck width); Ws/bs, We/be: the bottleneck's
+    1x1 in/out projections (None otherwise); Wr/br/gr/betar: the strided 1x1 residual conv + its BatchNorm.
+    bn_buffers: dict name -> (running_mean, running_var) updated in place when training."""
+
+    @staticmethod
+    def forward(ctx, cfg, training, seed, bufs, x, A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2,
+                Wr, br, gr, betar, Ws, bs, We, be):
+        dt = x.dtype
+        NM, T, V, cin = x.shape
+        cout, s = cfg.cout, cfg.stride
+        Tz = (T - 1) // s + 1
+        dev = x.device
+        A_eff = A_eff.contiguous()
+        # 1. graph conv (+ BN1 batch sums)
+        st1 = ops.new_stats(cout, dev) if training else None
+        wp = ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt)
+        g = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, stats=st1, nnz_cap=cfg.nnz_cap)
+        coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training)
+        # 2. temporal conv (BN1+ReLU fused into the staging; BN2 batch sums from the epilogue)
+        st2 = ops.new_stats(cout, dev) if training else None
+        taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
+        q = yb = None
+        if cfg.tcn == 'conv':
+            wt = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
+            z = ops.tconv(g, wt, cout, taps, bias=bt, pre=coef1[:2].contiguous(), pre_relu=True, stats=st2,
+                          Tout=Tz, Mlog=Tz, in_mul=in_mul)
+        else:
+            w = cfg.width
+            ws = ops.pack_tconv_weight(Ws.view(1, w, cout), V, [0], 1, dt)
+            q = ops.tconv(g, ws, w, [0], bias=bs, pre=coef1[:2].contiguous(), pre_relu=True, Tout=T, Mlog=T)
+            wt = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
+            yb = ops.tconv(q, wt, w, taps, bias=bt, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+            we = ops.pack_tconv_weight(We.view(1, cout, w), V, [0], 1, dt)
+            z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
+        coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training)
+        # 3. residual branch
+        r = coefr = None
+        if cfg.residual == 'id':
+            res, cr = x, None
+        elif cfg.residual == 'conv':
+            strs = ops.new_stats(cout, dev) if training else None
+            wr = ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
+            r = ops.tconv(x, wr, cout, [0], bias=br, stats=strs, Tout=Tz, Mlog=Tz, in_mul=s)
+            coefr = ops.bn_finalize(strs, NM * Tz * V, gr, betar, bufs['bnr'][0], bufs['bnr'][1], cfg.momentum,
+                                    cfg.eps, training)
+            res, cr = r, coefr[:2].contiguous()
+        else:
+            res, cr = None, None
+        # 4. BN2 + dropout + residual + ReLU
+        p = cfg.p_drop if training else 0.0
+        out = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed)
+        ctx.cfg, ctx.training, ctx.seed, ctx.p = cfg, training, seed, p
+        ctx.save_for_backward(x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb)
+        ctx.has_b = bterm is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg, training, seed, p = ctx.cfg, ctx.training, ctx.seed, ctx.p
+        (x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb) = ctx.saved_tensors
+        dt = x.dtype
+        NM, T, V, cin = x.shape
+        cout, s, k = cfg.cout, cfg.stride, cfg.ksize
+        Tz = z.shape[1]
+        dout = dout.contiguous()
+        if dout.dtype != dt:
+            dout = dout.to(dt)
+        # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
+        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed)
+        abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training)
+        dz = ops.affine2(dres, z, abc2, p, seed)
+        # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
+        taps, in_mul = ops.conv_taps_fwd(k, s)
+        pre1 = coef1[:2].contiguous()
+        st1b = ops.new_stats(cout, x.device)
+        dWs = dbs = dWe = dbe = None
+        if cfg.tcn == 'conv':
+            dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True)
+            d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b)
+        else:
+            w = cfg.width
+            dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
+            dWe = dWe3.view(cout, w)
+            dyb = _conv_bwd_data(dz, We.view(1, cout, w), 1, 1, Tz, w, V)
+            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul)
+            dq = _conv_bwd_data(dyb, Wt, k, s, T, w, V)
+            dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
+            dWs = dWs3.view(w, cout)
+            d1 = _conv_bwd_data(dq, Ws.view(1, w, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
+        abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training)
+        dg = ops.affine2(d1, g, abc1)
+        # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in
+        need_A = ctx.needs_input_grad[5]
+        dWg, dA, S = ops.gcn_wgrad(dg, x, A_eff, Wg3 if need_A else None, want_dA=need_A, want_S=ctx.has_b,
+                                   nnz_cap=cfg.nnz_cap)
+        dWr = dbr = dgr = dbetar = None
+        dx = None
+        if ctx.needs_input_grad[4] or cfg.residual == 'conv':
+            wt = ops.pack_gcn_weight(Wg3.permute(2, 0, 1), dt)
+            addend = dres if cfg.residual == 'id' else None
+            dx = ops.gcn_forward(dg, A_eff.transpose(1, 2).contiguous(), wt, cin, addend=addend, nnz_cap=cfg.nnz_cap)
+        if cfg.residual == 'conv':
+            abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training)
+            dr = ops.affine2(dres, r, abcr)
+            dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s)
+            dWr = dWr3.view(cout, cin)
+            eye = torch.eye(V, device=x.device, dtype=torch.float32).view(1, V, V)
+            wrt = ops.pack_gcn_weight(Wr.t().contiguous().view(cin, 1, cout), dt)
+            ops.gcn_forward(dr, eye, wrt, cin, addend=dx, out=dx, Tout=T, out_t_stride=s, nnz_cap=V)
+        return (None, None, None, None, dx, dA, (S if ctx.has_b else None), dWg, dg1, db1, dWt, dbt, dg2, db2,
+                dWr, dbr, dgr, dbetar, dWs, dbs, dWe, dbe)

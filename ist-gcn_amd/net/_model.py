@@ -1,0 +1,283 @@
+"""Table-driven implementation behind the drop-in `net.*` modules.
+
+The reference's 21 model files are copy-paste variants of one structure; here one `STGCNBlock`
+and one `STGCNModel` are specialised per variant by `make(kind)`, which returns classes named like the reference's
+(`Model`, `st_gcn`) with the reference's constructor signatures, forward signatures, attribute names and therefore
+`state_dict()` keys/shapes (incl. the dead parameters `linear.*`, `gcn.branch.bn.*`).  Parameters live in real
+`nn.Conv2d` / `nn.BatchNorm2d` sub-modules so `model.apply(weights_init)` (processor/recognition.py:31-44,149),
+`load_weights`, `DataParallel` and SGD over `model.parameters()` behave as upstream; `forward` never calls those
+sub-modules -- it hands their tensors to the HIP kernels through `functional.STGCNBlockFn`.
+
+There is no CPU path: tensors must be on an MI355X, otherwise RuntimeError.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as Fn
+from .utils.graph import Graph
+
+PLAN10 = ((64, 1), (64, 1), (64, 1), (64, 1), (128, 2), (128, 1), (128, 1), (256, 2), (256, 1), (256, 1))
+PLAN7 = ((64, 1), (64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1))
+PLAN13 = ((64, 1), (64, 1), (64, 1), (64, 1), (64, 1), (128, 2), (128, 1), (128, 1), (128, 1), (256, 2), (256, 1),
+          (256, 1), (256, 1))
+
+# kind -> gcn unit, tcn unit, block plan, dead Linear(3,C) present (st_gcnold.py:178)
+VARIANTS = {
+    'st_gcnold': dict(gcn='plain', tcn='single', plan=PLAN10, dead_linear=True),
+    'st_gcn': dict(gcn='plain', tcn='single', plan=PLAN10, dead_linear=True),      # name the shipped YAMLs use
+    'st_gcn_tanh': dict(gcn='plain', tcn='single', plan=PLAN10, dead_linear=True),
+    'st_gcn_msgcn': dict(gcn='incep', tcn='single', plan=PLAN10, dead_linear=False),
+    'st_gcn_msgcn_new': dict(gcn='incep', tcn='single', plan=PLAN7, dead_linear=False),
+    'st_gcn_deep_msgcn': dict(gcn='incep', tcn='single', plan=PLAN13, dead_linear=False),
+    'st_gcn_mstcn': dict(gcn='plain', tcn='multi3', plan=PLAN7, dead_linear=False),
+    'st_gcn_mstcn_1x1': dict(gcn='plain', tcn='bneck', plan=PLAN10, dead_linear=False),
+    'st_gcn_mstcn_1x1_deep': dict(gcn='plain', tcn='bneck', plan=PLAN13, dead_linear=False),
+    'st_gcn_multi3_fix_3A_mstcn': dict(gcn='3a', tcn='multi', plan=PLAN10, dead_linear=False),
+}
+
+_DTYPES = {'float32': torch.float32, 'fp32': torch.float32, 'bfloat16': torch.bfloat16, 'bf16': torch.bfloat16,
+           torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
+
+
+class _ConvHolder(nn.Module):
+    """`gcn.branch`: conv + a BatchNorm that upstream declares and never applies (inceptionv2_gcn.py:30,34)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size=(1, 1))
+        self.bn = nn.BatchNorm2d(cout)
+
+
+class _GCNParams(nn.Module):
+    """Parameter container of the block's GCN unit with the reference's attribute names."""
+
+    def __init__(self, unit, cin, cout, K):
+        super().__init__()
+        self.kernel_size = K
+        if unit == 'incep':
+            self.branch = _ConvHolder(cin, cout * K)
+        else:
+            self.conv = nn.Conv2d(cin, cout * K, kernel_size=(1, 1))
+
+    def the_conv(self):
+        return self.branch.conv if hasattr(self, 'branch') else self.conv
+
+
+def _to_ntvc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _to_nctv(x):
+    return x.permute(0, 3, 1, 2)          # logical (N,C,T,V), channels_last strides: no copy
+
+
+class STGCNBlock(nn.Module):
+    KIND = None
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, dropout=0, residual=True):
+        super().__init__()
+        var = VARIANTS[self.KIND]
+        assert len(kernel_size) == 2
+        assert kernel_size[0] % 2 == 1
+        self.gcn_kind, self.tcn_kind = var['gcn'], var['tcn']
+        self.cin, self.cout, self.stride, self.p_drop = in_channels, out_channels, stride, float(dropout)
+        K = kernel_size[1]
+        self.K, self.tk = K, kernel_size[0]
+        self.gcn = _GCNParams(self.gcn_kind, in_channels, out_channels, K)
+        c = out_channels
+        if self.tcn_kind == 'single':
+            pad = ((kernel_size[0] - 1) // 2, 0)
+            self.tcn = nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True),
+                                     nn.Conv2d(c, c, (kernel_size[0], 1), (stride, 1), pad),
+                                     nn.BatchNorm2d(c), nn.Dropout(dropout, inplace=True))
+        else:
+            w = int(c ** 0.5) if self.tcn_kind == 'bneck' else c
+            self.width = w
+            self.tcn_start = nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+            if self.tcn_kind == 'bneck':
+                self.conv_1x1_start = nn.Conv2d(c, w, (1, 1), (1, 1), (0, 0))
+            self.tcn_1 = nn.Conv2d(w, w, (3, 1), (stride, 1), (1, 0))
+            self.tcn_2 = nn.Conv2d(w, w, (9, 1), (stride, 1), (4, 0))
+            self.tcn_3 = nn.Conv2d(w, w, (15, 1), (stride, 1), (7, 0))
+            if self.tcn_kind == 'bneck':
+                self.conv_1x1_end = nn.Conv2d(w, c, (1, 1), (1, 1), (0, 0))
+            self.tcn_end = nn.Sequential(nn.BatchNorm2d(c), nn.Dropout(dropout, inplace=True))
+        if var['dead_linear']:
+            self.linear = nn.Linear(3, c)
+        if not residual:
+            self.res_mode = 'none'
+        elif in_channels == out_channels and stride == 1:
+            self.res_mode = 'id'
+        else:
+            self.res_mode = 'conv'
+            self.residual = nn.Sequential(nn.Conv2d(in_channels, c, kernel_size=1, stride=(stride, 1)),
+                                          nn.BatchNorm2d(c))
+        self.relu = nn.ReLU(inplace=True)
+        self._calls = 0
+
+    # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
+    def run(self, x, A_eff, mst=None, nnz_cap=None):
+        if not x.is_cuda:
+            raise RuntimeError('istgcn_amd: the st_gcn block runs on MI355X only (tensor on %s); no CPU fallback'
+                               % x.device)
+        c, V = self.cout, x.shape[2]
+        conv = self.gcn.the_conv()
+        Wg3 = conv.weight.view(self.K, c, self.cin)
+        bterm = Fn.fold_bias_term(conv.bias, A_eff, c) if conv.bias is not None else None
+        if self.tcn_kind == 'single':
+            bn1, tconv, bn2 = self.tcn[0], self.tcn[2], self.tcn[3]
+            Wt, bt, ks = tconv.weight[:, :, :, 0].permute(2, 0, 1).contiguous(), tconv.bias, self.tk
+            Ws = bs = We = be = None
+            mode = 'conv'
+        else:
+            bn1, bn2 = self.tcn_start[0], self.tcn_end[0]
+            if mst is None:
+                raise TypeError('this st_gcn variant needs mstcn_importance')
+            Wt, bt = Fn.fold_tcn_taps(self.tcn_1.weight, self.tcn_2.weight, self.tcn_3.weight, self.tcn_1.bias,
+                                      self.tcn_2.bias, self.tcn_3.bias, mst,
+                                      scale=(1.0 / 3.0) if self.tcn_kind == 'multi3' else 1.0)
+            ks = 15
+            if self.tcn_kind == 'bneck':
+                Ws, bs = self.conv_1x1_start.weight.view(self.width, c), self.conv_1x1_start.bias
+                We, be = self.conv_1x1_end.weight.view(c, self.width), self.conv_1x1_end.bias
+                mode = 'bneck'
+            else:
+                Ws = bs = We = be = None
+                mode = 'conv'
+        bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
+        Wr = br = gr = betar = None
+        mom, eps = bn1.momentum, bn1.eps
+        if self.res_mode == 'conv':
+            rc, rbn = self.residual[0], self.residual[1]
+            Wr, br, gr, betar = rc.weight.view(c, self.cin), rc.bias, rbn.weight, rbn.bias
+            bufs['bnr'] = (rbn.running_mean, rbn.running_var)
+        if nnz_cap is None:
+            nnz_cap = self.K * V * V
+        cfg = Fn.BlockCfg(self.cin, c, self.K, V, self.stride, self.res_mode, mode, ks, self.p_drop, int(nnz_cap),
+                          width=getattr(self, 'width', None), momentum=mom if mom is not None else 0.1, eps=eps)
+        training = self.training
+        if training:
+            for bn in (bn1, bn2) + ((self.residual[1],) if self.res_mode == 'conv' else ()):
+                bn.num_batches_tracked.add_(1)
+        self._calls += 1
+        seed = (torch.initial_seed() * 1000003 + id(self) % 65521 * 7919 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        return Fn.STGCNBlockFn.apply(cfg, training, seed, bufs, x, A_eff, bterm, Wg3, bn1.weight, bn1.bias, Wt, bt,
+                                     bn2.weight, bn2.bias, Wr, br, gr, betar, Ws, bs, We, be)
+
+    # ---- reference-signature forward on (N,C,T,V) tensors ------------------------------------------
+    def forward(self, x, A, *rest):
+        gk, multi = self.gcn_kind, self.tcn_kind != 'single'
+        mst = None
+        if gk == 'plain':
+            assert A.size(0) == self.K
+            if multi:
+                (mst,) = rest
+            A_eff, ret = A, (A,)
+        elif gk == 'incep':
+            A2, A3 = rest[0], rest[1]
+            assert A.size(0) == self.K
+            A_eff, ret = A + A2 + A3, (A, A2, A3)
+        else:
+            i1, i2, i3 = rest[0], rest[1], rest[2]
+            assert A.size(0) == self.K
+            if multi:
+                mst = rest[3]
+            A_eff, ret = Fn.fold_adjacency('3a', A, (i1, i2, i3)), (A,)
+        y = self.run(_to_ntvc(x), A_eff, mst)
+        return (_to_nctv(y),) + ret
+
+
+class STGCNModel(nn.Module):
+    KIND = None
+    BLOCK = None
+
+    def __init__(self, in_channels, num_class, graph_args, edge_importance_weighting, **kwargs):
+        super().__init__()
+        var = VARIANTS[self.KIND]
+        self.gcn_kind, self.tcn_kind = var['gcn'], var['tcn']
+        self.act_dtype = _DTYPES[kwargs.pop('compute_dtype', 'float32')]
+        self.graph = Graph(**graph_args)
+        if self.gcn_kind == 'incep':                                    # st_gcn_msgcn.py:36-39
+            self.register_buffer('A2', torch.tensor(self.graph.A2, dtype=torch.float32, requires_grad=False))
+            self.register_buffer('A3', torch.tensor(self.graph.A3, dtype=torch.float32, requires_grad=False))
+        A = torch.tensor(self.graph.A, dtype=torch.float32, requires_grad=False)
+        self.register_buffer('A', A)
+        K, V = A.size(0), A.size(1)
+        kernel_size = (9, K)
+        self.data_bn = nn.BatchNorm1d(in_channels * V)
+        kwargs0 = {k: v for k, v in kwargs.items() if k != 'dropout'}
+        blocks, cin = [], in_channels
+        for idx, (cout, stride) in enumerate(var['plan']):
+            if idx == 0:
+                blocks.append(self.BLOCK(cin, cout, kernel_size, 1, residual=False, **kwargs0))
+            else:
+                blocks.append(self.BLOCK(cin, cout, kernel_size, stride, **kwargs))
+            cin = cout
+        self.st_gcn_networks = nn.ModuleList(blocks)
+        n_imp = 3 if self.gcn_kind in ('incep', '3a') else 1
+        shapes = [self.A.size(), self.A2.size() if self.gcn_kind == 'incep' else self.A.size(),
+                  self.A3.size() if self.gcn_kind == 'incep' else self.A.size()]
+        for j, name in enumerate(('edge_importance', 'edge_importance2', 'edge_importance3')[:n_imp]):
+            if edge_importance_weighting:
+                setattr(self, name, nn.ParameterList([nn.Parameter(torch.ones(shapes[j])) for _ in blocks]))
+            else:
+                setattr(self, name, [1] * len(blocks))
+        if self.tcn_kind != 'single':
+            self.mstcn_importance = nn.ParameterList([nn.Parameter(torch.ones(3)) for _ in blocks])
+        self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
+        self._nnz_cap = None
+        self.register_load_state_dict_post_hook(lambda m, keys: setattr(m, '_nnz_cap', None))
+
+    # the sparsity pattern bounds the kernels' in-LDS adjacency lists; recomputed if buffers are reloaded
+    def _cap(self):
+        if self._nnz_cap is None:
+            pat = self.A != 0
+            if self.gcn_kind == 'incep':
+                pat = pat | (self.A2 != 0) | (self.A3 != 0)
+            self._nnz_cap = max(1, int(pat.sum().item()))
+        return self._nnz_cap
+
+    def _a_eff(self, i):
+        imps = [self.edge_importance[i]]
+        if self.gcn_kind in ('incep', '3a'):
+            imps += [self.edge_importance2[i], self.edge_importance3[i]]
+        return Fn.fold_adjacency(self.gcn_kind, self.A, imps, getattr(self, 'A2', None), getattr(self, 'A3', None))
+
+    def _trunk(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('istgcn_amd.net: Model.forward needs the input on an MI355X (got %s); the HIP path has '
+                               'no CPU fallback' % x.device)
+        N, C, T, V, M = x.size()
+        # data_bn (st_gcnold.py:74-80): (N,C,T,V,M) -> BatchNorm1d over V*C channels -> NTVC
+        x = x.permute(0, 4, 3, 1, 2).contiguous().view(N * M, V * C, T)
+        x = self.data_bn(x)
+        x = x.view(N * M, V, C, T).permute(0, 3, 1, 2).contiguous().to(self.act_dtype)
+        cap = self._cap()
+        for i, blk in enumerate(self.st_gcn_networks):
+            mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
+            x = blk.run(x, self._a_eff(i), mst, nnz_cap=cap)
+        return x
+
+    def forward(self, x):
+        N, M = x.size(0), x.size(4)
+        y = self._trunk(x)                                           # (NM, T', V, 256)
+        feat = y.float().mean(dim=(1, 2)).view(N, M, -1).mean(dim=1)   # global pooling, then persons
+        out = F.conv2d(feat.view(N, -1, 1, 1), self.fcn.weight, self.fcn.bias)
+        return out.view(N, -1)
+
+    def extract_feature(self, x):
+        N, M = x.size(0), x.size(4)
+        y = self._trunk(x).float()
+        _, t, v, c = y.size()
+        feature = y.view(N, M, t, v, c).permute(0, 4, 2, 3, 1)
+        o = F.conv2d(y.permute(0, 3, 1, 2), self.fcn.weight, self.fcn.bias)      # (NM, nc, t, v)
+        output = o.view(N, M, -1, t, v).permute(0, 2, 3, 4, 1)
+        return output, feature
+
+
+def make(kind):
+    """-> (Model, st_gcn) classes of one reference model file."""
+    blk = type('st_gcn', (STGCNBlock,), {'KIND': kind, '__doc__': 'st_gcn block of net/%s.py' % kind})
+    mdl = type('Model', (STGCNModel,), {'KIND': kind, 'BLOCK': blk, '__doc__': 'Model of net/%s.py' % kind})
+    return mdl, blk

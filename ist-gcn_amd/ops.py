@@ -47,11 +47,31 @@ def _check_dev(*ts):
     return dev
 
 
-def _call(fn_name, *args):
+# Optional per-launch timing used by bench.py for the roofline line: when PROFILE is a list, every kernel launch
+# appends (entry point, algorithmic flops, algorithmic bytes, start event, end event), the events recorded on the
+# stream the kernel was launched on.  None (default) = no events, no overhead.
+PROFILE = None
+
+
+def _call(fn_name, *args, work=None):
     lib = _lib.load()
-    rc = getattr(lib, fn_name)(*args)
+    if PROFILE is not None and work is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, fn_name)(*args)
+        e1.record()
+        PROFILE.append((fn_name, work[0], work[1], e0, e1))
+    else:
+        rc = getattr(lib, fn_name)(*args)
     if rc != 0:
-        raise RuntimeError('%s failed with code %d (%s)' % (fn_name, rc, {1: 'invalid argument', 2: 'launch failure'}.get(rc, '?')))
+        why = {1: 'invalid argument', 2: 'launch failure'}.get(rc)
+        if why is None:
+            why = 'hipError %d %s' % (rc % 1000, 'from the launch' if rc < 2000 else 'from hipFuncSetAttribute')
+        raise RuntimeError('%s failed with code %d (%s)' % (fn_name, rc, why))
+
+
+def _esz(t):
+    return t.element_size()
 
 
 def gcn_geometry(cin, cout, K, dt):
@@ -96,7 +116,9 @@ def gcn_forward(x, A, wp, cout, bterm=None, addend=None, out=None, stats=None, T
     _check_dev(x, A, wp, bterm, addend, out, stats)
     _call('istgcn_gcn_fwd', _ptr(x), _ptr(A), _ptr(wp), _ptr(bterm), _ptr(addend), _ptr(out), _ptr(stats),
           0 if stats is None else stats.shape[0], None, NM, Tin, Tout, Tlog, V, Cin, cout, K,
-          in_t_stride, out_t_stride, int(nnz_cap), dtype_code(x), grid_cap, _stream(x))
+          in_t_stride, out_t_stride, int(nnz_cap), dtype_code(x), grid_cap, _stream(x),
+          work=(2.0 * NM * Tlog * V * cout * K * Cin + 2.0 * NM * Tlog * V * V * K * cout,      # 1x1 conv + dense einsum
+                float(NM * Tlog * V) * (Cin + cout * (2 if addend is not None else 1)) * _esz(x)))
     return out
 
 
@@ -144,7 +166,9 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
     _check_dev(x, wp, bias, pre, aux, maux, out, stats)
     _call('istgcn_tconv', _ptr(x), _ptr(wp), _ptr(bias), _ptr(pre), int(bool(pre_relu)), _ptr(aux), _ptr(maux),
           _ptr(out), _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, Cin, cout,
-          len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), grid_cap, _stream(x))
+          len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), grid_cap, _stream(x),
+          work=(2.0 * NM * Mlog * V * cout * Cin * len(tap_off),
+                float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if mode == 1 else 1)) * _esz(x)))
     return out
 
 
@@ -171,5 +195,113 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
     db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
     _check_dev(dz, g, pre, dW, db)
     _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
-          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap, _stream(dz))
+          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap, _stream(dz),
+          work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)))
     return dW, db
+
+
+# ----------------------------------------------------------------------------------------------
+# graph-conv parameter gradients (istgcn_gcn_wgrad)
+# ----------------------------------------------------------------------------------------------
+def pack_gcn_wq(w3, dtype):
+    """w3: [K][Cout][Cin] fp32 (the raw Conv2d weight viewed per partition) -> fragments of W^T for the dxa product:
+    element [ct][it][k][kg][h][r][e] = w3[k][32*ct + kg*2*EPL + h*EPL + e][32*it + r]."""
+    K, cout, cin = w3.shape
+    epl = 4 if dtype == torch.float32 else 8
+    nct, nit = (cout + 31) // 32, (cin + 31) // 32
+    w = F.pad(w3, (0, nit * 32 - cin, 0, nct * 32 - cout))
+    w = w.reshape(K, nct, 32 // (2 * epl), 2, epl, nit, 32).permute(1, 5, 0, 2, 3, 6, 4)
+    return w.to(dtype).contiguous()
+
+
+def gcn_wgrad(dy, x, A, w3=None, want_dA=True, want_S=True, nnz_cap=None, grid_cap=0):
+    """istgcn_gcn_wgrad -> (dW [K][Cout][Cin], dA [K][V][V] or None, S [V][Cout] or None), all fp32."""
+    NM, T, V, Cout = dy.shape
+    Cin = x.shape[3]
+    K = A.shape[0]
+    assert x.shape[:3] == dy.shape[:3] and x.dtype == dy.dtype and A.shape == (K, V, V)
+    dev = dy.device
+    dW = torch.zeros((K, Cout, Cin), dtype=torch.float32, device=dev)
+    dA = torch.zeros((K, V, V), dtype=torch.float32, device=dev) if want_dA else None
+    S = torch.zeros((V, Cout), dtype=torch.float32, device=dev) if want_S else None
+    wq = None
+    if want_dA:
+        assert w3 is not None and w3.shape == (K, Cout, Cin)
+        wq = pack_gcn_wq(w3, dy.dtype)
+    if nnz_cap is None:
+        nnz_cap = K * V * V
+    _check_dev(dy, x, A, wq, dW, dA, S)
+    _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(wq), _ptr(dW), _ptr(dA), _ptr(S), NM, T, V, Cin, Cout,
+          K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
+          work=((2.0 if want_dA else 1.0) * 2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)))
+    return dW, dA, S
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm bookkeeping + the block's HBM-bound glue (pointwise.hip)
+# ----------------------------------------------------------------------------------------------
+def new_stats(C, device):
+    return torch.zeros((STATS_REP, 2, C), dtype=torch.float64, device=device)
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training):
+    """-> coef [4][C] fp32: scale, shift, mean, rstd.  Training also updates the running statistics in place."""
+    C = gamma.shape[0]
+    coef = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    _check_dev(stats, gamma, beta, running_mean, running_var, coef)
+    _call('istgcn_bn_finalize', _ptr(stats), 0 if stats is None else stats.shape[0], ctypes.c_double(float(count)),
+          _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum),
+          ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma))
+    return coef
+
+
+def bn_bwd_coef(stats, count, gamma, coef, training):
+    """-> (abc [3][C], dgamma [C], dbeta [C]) from the two BatchNorm-backward sums."""
+    C = gamma.shape[0]
+    abc = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
+    dg = torch.empty((C,), dtype=torch.float32, device=gamma.device)
+    db = torch.empty((C,), dtype=torch.float32, device=gamma.device)
+    _check_dev(stats, gamma, coef, abc, dg, db)
+    _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], ctypes.c_double(float(count)), _ptr(gamma), _ptr(coef),
+          int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma))
+    return abc, dg, db
+
+
+def _rows(t):
+    return t.numel() // t.shape[-1]
+
+
+def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0):
+    out = torch.empty_like(z)
+    _check_dev(z, coef2, res, coefr, out)
+    if res is not None:
+        assert res.shape == z.shape and res.dtype == z.dtype
+    _call('istgcn_block_out_fwd', _ptr(z), _ptr(coef2), _ptr(res), _ptr(coefr), _ptr(out), ctypes.c_longlong(_rows(z)),
+          z.shape[-1], ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
+          work=(3.0 * z.numel(), float(z.numel()) * (3 if res is not None else 2) * _esz(z)))
+    return out
+
+
+def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0):
+    """-> (dres = dout*[out>0], stats2, statsr or None)"""
+    C = z.shape[-1]
+    dres = torch.empty_like(z)
+    st2 = new_stats(C, z.device)
+    str_ = new_stats(C, z.device) if r is not None else None
+    assert dout.shape == z.shape == out.shape and dout.dtype == z.dtype
+    _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
+    _call('istgcn_block_out_bwd', _ptr(dout), _ptr(out), _ptr(z), _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres),
+          _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C, ctypes.c_float(p_drop),
+          ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
+          work=(6.0 * z.numel(), float(z.numel()) * (5 if r is not None else 4) * _esz(z)))
+    return dres, st2, str_
+
+
+def affine2(d, x, abc, p_drop=0.0, seed=0):
+    """out = abc[0]*d*dropmask + abc[1]*x + abc[2]  (BatchNorm backward, elementwise part)."""
+    out = torch.empty_like(d)
+    _check_dev(d, x, abc, out)
+    _call('istgcn_affine2', _ptr(d), _ptr(x), _ptr(abc), _ptr(out), ctypes.c_longlong(_rows(d)), d.shape[-1],
+          ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(d), _stream(d),
+          work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)))
+    return out

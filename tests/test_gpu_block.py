@@ -1,0 +1,253 @@
+"""-m gpu: st_gcn blocks and whole Models of the HIP product (through the drop-in nn.Module API) against the golden
+fixtures generated from the reference, in fp32 (tight) and bf16 storage (loose, stated)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from detinit import det_fill_, det_tensor, det_labels
+from gpu_util import dev, diag, close, l2rel
+
+pytestmark = pytest.mark.gpu
+SD = json.load(open(os.path.join(GOLDEN, 'state_dict_g5.json')))
+MODEL_CFG = {
+    'st_gcnold': (dict(layout='ntu-rgb+d', strategy='spatial'), 60),
+    'st_gcn_msgcn': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60),
+    'st_gcn_mstcn_1x1': (dict(layout='openpose', strategy='spatial'), 400),
+    'st_gcn_multi3_fix_3A_mstcn': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60),
+    'st_gcn_mstcn_1x1_deep': (dict(layout='ntu-rgb+d', strategy='spatial'), 60),
+    'st_gcn_mstcn': (dict(layout='ntu-rgb+d', strategy='spatial'), 60),
+    'st_gcn_msgcn_new': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60),
+    'st_gcn_deep_msgcn': (dict(layout='ntu-rgb+d', strategy='spatial_3'), 60),
+}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from istgcn_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------ pointwise
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_bn_finalize_and_block_out(ops, dt):
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    rows, C = 1000, 64
+    z = torch.randn(rows, C, generator=g) * 2 + 0.5
+    res = torch.randn(rows, C, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    if dt == torch.bfloat16:
+        z, res = z.bfloat16().float(), res.bfloat16().float()
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ref = F.batch_norm(z, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    st = ops.new_stats(C, d)
+    st[0, 0] = z.double().sum(0).to(d)
+    st[3, 1] = (z.double() ** 2).sum(0).to(d)
+    rmd, rvd = torch.zeros(C, device=d), torch.ones(C, device=d)
+    coef = ops.bn_finalize(st, rows, gamma.to(d), beta.to(d), rmd, rvd, 0.1, 1e-5, True)
+    assert rel_err(rmd, rm) < 1e-6 and rel_err(rvd, rv) < 1e-5
+    zd = z.to(d, dt).view(10, 4, 25, C)
+    out = ops.block_out_fwd(zd, coef[:2].contiguous(), res.to(d, dt).view_as(zd), None, 0.0, 0)
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert diag('block_out_fwd_%s' % str(dt)[6:], out.float().view(rows, C), F.relu(ref + res), tol) < tol
+    # eval mode: running statistics
+    coef_e = ops.bn_finalize(None, 0, gamma.to(d), beta.to(d), rmd, rvd, 0.1, 1e-5, False)
+    ref_e = F.batch_norm(z, rmd.cpu(), rvd.cpu(), gamma, beta, training=False, eps=1e-5)
+    out_e = ops.block_out_fwd(zd, coef_e[:2].contiguous(), None, None, 0.0, 0)
+    assert diag('block_out_eval_%s' % str(dt)[6:], out_e.float().view(rows, C), F.relu(ref_e), tol) < tol
+
+
+def test_dropout_mask_is_regenerated_in_backward(ops):
+    d = dev()
+    rows, C, p, seed = 4096, 64, 0.5, 1234567
+    z = torch.randn(1, rows // 25 + 1, 25, C, device=d).abs() + 0.1
+    coef = torch.stack([torch.ones(C), torch.zeros(C), torch.zeros(C), torch.ones(C)]).to(d)
+    out = ops.block_out_fwd(z, coef[:2].contiguous(), None, None, p, seed)
+    keep = out > 0
+    frac = float(keep.float().mean())
+    assert 0.47 < frac < 0.53
+    assert rel_err(out[keep], (z * 2)[keep]) < 1e-6                     # 1/(1-p) scaling
+    out2 = ops.block_out_fwd(z, coef[:2].contiguous(), None, None, p, seed)
+    assert torch.equal(out, out2)
+    out3 = ops.block_out_fwd(z, coef[:2].contiguous(), None, None, p, seed + 1)
+    assert not torch.equal(out, out3)
+    # backward path: affine2 with the same (p, seed) applies the same mask
+    ones = torch.ones_like(z)
+    abc = torch.stack([torch.ones(C), torch.zeros(C), torch.zeros(C)]).to(d)
+    dz = ops.affine2(ones, None, abc, p, seed)
+    assert torch.equal(dz > 0, keep)
+    dres, st2, _ = ops.block_out_bwd(ones, out, z, coef, None, None, p, seed)
+    assert torch.equal(dres > 0, keep)
+    assert rel_err(st2.sum(0)[0], (dres * dz).double().sum((0, 1, 2))) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ blocks (G3)
+def _block_args(kind, A, A2, A3, imps, mst):
+    if kind in ('st_gcnold',):
+        return (A * imps[0],)
+    if kind == 'st_gcn_msgcn':
+        return (A * imps[0], A2 * imps[1], A3 * imps[2])
+    if kind in ('st_gcn_mstcn', 'st_gcn_mstcn_1x1'):
+        return (A * imps[0], mst)
+    return (A, imps[0], imps[1], imps[2], mst)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kind', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn'])
+def test_blocks_golden(golden, kind, dt):
+    g = golden('block_g3_%s.npz' % kind)
+    mod = importlib.import_module('istgcn_amd.net.' + kind)
+    d = dev()
+    bases = sorted({'.'.join(k.split('.')[:2]) + '.' for k in g.files})
+    tol_f, tol_g = (3e-5, 2e-4) if dt == torch.float32 else (2e-2, 0.15)   # bf16: relative L2 (ReLU-mask flips on 576-position fixtures)
+    for b in bases:
+        t = lambda k: torch.from_numpy(g[b + k])  # noqa: E731
+        sd = {k[len(b) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(b + 'sd.')}
+        A, A2, A3, x, r = t('A').to(d), t('A2').to(d), t('A3').to(d), t('x'), t('r')
+        wkey = 'gcn.conv.weight' if 'gcn.conv.weight' in sd else 'gcn.branch.conv.weight'
+        K = A.shape[0]
+        cout, cin = sd[wkey].shape[0] // K, sd[wkey].shape[1]
+        stride = x.shape[2] // r.shape[2]
+        blk = mod.st_gcn(cin, cout, (9, K), stride, dropout=0, residual=(b.split('.')[1] != 's0'))
+        blk.load_state_dict(sd, strict=True)
+        blk.to(d)
+        imps = [t('imp%d' % j).to(d).requires_grad_(True) for j in (1, 2, 3)]
+        mst = t('mst').to(d).requires_grad_(True)
+        xin = x.to(d, dt) if dt == torch.bfloat16 else x.to(d)
+        name = 'blk_%s_%s_%s' % (kind, b.strip('.').replace('.', '_'), str(dt)[6:])
+        blk.eval()
+        with torch.no_grad():
+            y = blk(xin, *_block_args(kind, A, A2, A3, imps, mst))[0]
+        assert close(name + '_yeval', y.float(), g[b + 'y_eval'], tol_f, dt)
+        blk.train()
+        xx = xin.clone().requires_grad_(True)
+        y = blk(xx, *_block_args(kind, A, A2, A3, imps, mst))[0]
+        assert close(name + '_ytrain', y.float(), g[b + 'y_train'], tol_f, dt)
+        (y.float() * r.to(d)).sum().backward()
+        assert close(name + '_dx', xx.grad.float(), g[b + 'dx'], tol_g, dt)
+        n_grad = 0
+        for k, p in blk.named_parameters():
+            if b + 'grad.' + k in g.files:
+                assert p.grad is not None, k
+                assert close(name + '_grad_' + k, p.grad, g[b + 'grad.' + k], tol_g, dt), k
+                n_grad += 1
+            else:
+                assert p.grad is None, k
+        assert n_grad > 0
+        for j in (1, 2, 3):
+            if b + 'dimp%d' % j in g.files:
+                assert close(name + '_dimp%d' % j, imps[j - 1].grad, g[b + 'dimp%d' % j], tol_g, dt)
+        if b + 'dmst' in g.files:
+            assert close(name + '_dmst', mst.grad, g[b + 'dmst'], tol_g, dt)
+        for k, v in blk.state_dict().items():
+            if 'running' in k:
+                assert close(name + '_' + k, v, g[b + 'after.' + k], tol_f, dt), k
+
+
+# ------------------------------------------------------------------------------------------------ models (G4/G5)
+def _model(tag, dt, dropout=0):
+    gargs, nc = MODEL_CFG[tag]
+    mod = importlib.import_module('istgcn_amd.net.' + tag)
+    m = mod.Model(3, nc, gargs, True, dropout=dropout, compute_dtype=dt)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert got == SD[tag]
+    m.load_state_dict(det_fill_(m.state_dict()))
+    return m.to(dev()), nc
+
+
+@pytest.mark.parametrize('tag', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1_deep'])
+def test_model_eval_logits_full_clip(golden, tag):
+    """BASELINE.json:north_star parity bar: logits within 1e-3 (fp32) of the reference forward on identical
+    (N,C,T,V,M) inputs, at the full clip shape of each config (N=2)."""
+    g = golden('model_g4_%s.npz' % tag)
+    m, nc = _model(tag, torch.float32)
+    m.eval()
+    x = det_tensor('g4.x.' + tag, tuple(int(s) for s in g['eval_shape'])).to(dev())
+    with torch.no_grad():
+        y = m(x)
+    assert diag('model_eval_' + tag, y, g['eval_logits'], 1e-3) < 1e-3
+
+
+@pytest.mark.parametrize('tag', sorted(MODEL_CFG))
+def test_model_train_step_fp32(golden, tag):
+    """one SGD-nesterov step = processor/recognition.py:249-296: logits, loss, every gradient norm, every updated
+    parameter norm and a few updated tensors against the reference."""
+    from istgcn_amd import harness
+    g = golden('model_g4_%s.npz' % tag)
+    m, nc = _model(tag, torch.float32)
+    shp = tuple(int(s) for s in g['train_shape'])
+    x = det_tensor('g4.xt.' + tag, shp).to(dev())
+    lab = det_labels('g4.lab.' + tag, shp[0], nc).to(dev())
+    opt = harness.make_optimizer(m)
+    m.train()
+    logits = m(x)
+    loss = F.cross_entropy(logits, lab)
+    opt.zero_grad()
+    loss.backward()
+    assert diag('model_train_logits_' + tag, logits, g['train_logits'], 1e-3) < 1e-3
+    assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-3
+    params = list(m.parameters())
+    none = np.asarray([p.grad is None for p in params])
+    assert np.array_equal(none, g['grad_none'])                     # dead params stay grad-less
+    gn = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) for p in params])
+    bad = np.abs(gn - g['grad_norms']) > 2e-3 * np.maximum(1.0, g['grad_norms'])
+    assert not bad.any(), [(SD[tag + '#param_names'][i], gn[i], g['grad_norms'][i]) for i in np.flatnonzero(bad)[:8]]
+    opt.step()
+    sd = m.state_dict()
+    after = np.asarray([float(sd[k].double().norm()) for k in SD[tag + '#param_names']])
+    assert np.allclose(after, g['param_norms_after'], rtol=1e-3, atol=1e-5)
+    bufn = np.asarray([float(v.double().norm()) for k, v in sd.items() if 'running' in k])
+    assert np.allclose(bufn, g['buffer_norms_after'], rtol=1e-3, atol=1e-5)
+    for k in g.files:
+        if k.startswith('after.'):
+            assert diag('model_after_%s_%s' % (tag, k), sd[k[6:]], g[k], 1e-3) < 1e-3, k
+
+
+@pytest.mark.parametrize('tag', ['st_gcn_msgcn', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1'])
+def test_model_bf16_storage_close_to_fp32(golden, tag):
+    """bf16 activations with fp32 accumulation / fp64 statistics against (a) the reference's fp32 logits and (b) the
+    fp32 HIP path's gradients (itself pinned to the reference above): logits within 3e-2 relative L2, the full
+    gradient within 0.25 relative L2, every sizeable parameter gradient with cosine > 0.8 (the deterministic test init
+    is deliberately ill-conditioned -- eval logits up to 98 -- so bf16 ReLU-mask flips show; fp32 is the parity gate)."""
+    g = golden('model_g4_%s.npz' % tag)
+    shp = tuple(int(s) for s in g['train_shape'])
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m, nc = _model(tag, dt)
+        x = det_tensor('g4.xt.' + tag, shp).to(dev())
+        lab = det_labels('g4.lab.' + tag, shp[0], nc).to(dev())
+        m.train()
+        logits = m(x)
+        loss = F.cross_entropy(logits, lab)
+        loss.backward()
+        grads[dt] = ([None if p.grad is None else p.grad.double().flatten() for p in m.parameters()], logits.detach(), float(loss))
+    g32, g16 = grads[torch.float32], grads[torch.bfloat16]
+    assert l2rel(g16[1], g['train_logits']) < 3e-2
+    assert abs(g16[2] - float(g['train_loss'])) < 5e-2
+    a = torch.cat([t for t in g32[0] if t is not None])
+    b = torch.cat([t for t in g16[0] if t is not None])
+    assert torch.isfinite(b).all()
+    assert float((a - b).norm() / a.norm()) < 0.25
+    top = max(float(t.norm()) for t in g32[0] if t is not None)
+    for ta, tb in zip(g32[0], g16[0]):
+        if ta is not None and float(ta.norm()) > 1e-2 * top:
+            cos = float((ta * tb).sum() / (ta.norm() * tb.norm()))
+            assert cos > 0.8, cos
+
+
+def test_extract_feature_shapes():
+    m, nc = _model('st_gcnold', torch.float32)
+    m.eval()
+    x = torch.randn(2, 3, 32, 25, 2, device=dev())
+    with torch.no_grad():
+        out, feat = m.extract_feature(x)
+        y = m(x)
+    assert out.shape == (2, nc, 8, 25, 2) and feat.shape == (2, 256, 8, 25, 2)
+    # pooling the per-position scores reproduces forward (fcn is linear)
+    assert rel_err(out.mean(dim=(2, 3, 4)), y) < 1e-4

@@ -172,3 +172,75 @@ def test_requires_gpu_no_fallback(ops):
     x = torch.zeros(1, 2, 25, 8)
     with pytest.raises(RuntimeError):
         ops.gcn_forward(x, torch.zeros(1, 25, 25), torch.zeros(8), 8)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ci', range(4))
+@pytest.mark.parametrize('unit', ['tgcn', '3a', 'inc'])
+def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
+    """dW, db and the importance gradients of the reference units from ONE wgrad kernel: the kernel returns dW, the
+    adjacency gradient on the pattern and S = sum dy; the fold A_eff(importances) and the bias term are differentiated
+    by the same tiny host expressions the Model uses."""
+    g, b, t = _unit(golden, ci)
+    x, r, W, bias = t('x'), t('r'), t('W'), t('b')
+    A, A2, A3 = t('A'), t('A2'), t('A3')
+    imps = [t('imp%d' % j).clone().requires_grad_(True) for j in (1, 2, 3)]
+    if unit == 'tgcn':
+        Aeff = A * imps[0]
+    elif unit == '3a':
+        Aeff = A * imps[0] + A ** 2 * imps[1] + A ** 3 * imps[2]
+    else:
+        Aeff = A * imps[0] + A2 * imps[1] + A3 * imps[2]
+    K, V = A.shape[0], A.shape[1]
+    cout, cin = W.shape[0] // K, W.shape[1]
+    d = dev()
+    xin, rin = x, r
+    if dt == torch.bfloat16:
+        xin, rin = x.bfloat16().float(), r.bfloat16().float()
+    w3 = W.view(K, cout, cin).contiguous().to(d)
+    dW, dA, S = ops.gcn_wgrad(to_ntvc(rin).to(d, dt), to_ntvc(xin).to(d, dt), Aeff.detach().to(d).contiguous(), w3,
+                              nnz_cap=int((Aeff != 0).sum()))
+    torch.cuda.synchronize()
+    dW, dA, S = dW.cpu(), dA.cpu(), S.cpu()
+    tol = 3e-5 if dt == torch.float32 else 1e-2
+    name = 'gcnwg_%s_c%d_%s' % (unit, ci, str(dt)[6:])
+    assert diag(name + '_dW', dW.view(K * cout, cin, 1, 1), g[b + unit + '.dW'], tol) < tol
+    # db[k*C+c] = sum_w colsum_k(A)[w] * S[w][c]
+    db = torch.einsum('kw,wc->kc', Aeff.detach().sum(1), S).reshape(-1)
+    assert diag(name + '_db', db, g[b + unit + '.db'], tol) < tol
+    # adjacency gradient: kernel part (through W x) + bias part (every v of column w gets sum_c b[k,c] S[w][c])
+    dA_full = dA + torch.einsum('kc,wc->kw', bias.view(K, cout), S)[:, None, :] * (Aeff.detach() != 0)
+    Aeff.backward(dA_full)
+    for j in (1, 2, 3):
+        key = b + unit + '.dimp%d' % j
+        if key in g.files:
+            assert diag(name + '_dimp%d' % j, imps[j - 1].grad, g[key], tol) < tol
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 64, 64, 23, 25, 3, False), (2, 64, 128, 11, 25, 3, False), (2, 128, 256, 9, 25, 3, False),
+                                   (2, 256, 256, 7, 18, 3, True), (1, 3, 64, 300, 25, 3, False), (2, 64, 64, 12, 25, 4, True),
+                                   (2, 40, 24, 5, 15, 2, True)])
+def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
+    NM, cin, cout, T, V, K, dense = shape
+    gen = torch.Generator().manual_seed(hash(shape) & 0xFFFF)
+    x = torch.randn(NM, cin, T, V, generator=gen)
+    dy = torch.randn(NM, cout, T, V, generator=gen)
+    if dt == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    W = (torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5).requires_grad_(True)
+    A = torch.rand(K, V, V, generator=gen)
+    if not dense:
+        A = A * (torch.rand(K, V, V, generator=gen) < 0.12)
+    A = A.requires_grad_(True)
+    y = R.graph_einsum(torch.nn.functional.conv2d(x, W), A)
+    y.backward(dy)
+    d = dev()
+    dW, dA, S = ops.gcn_wgrad(to_ntvc(dy).to(d, dt), to_ntvc(x).to(d, dt), A.detach().to(d), W.detach().view(K, cout, cin).to(d),
+                              nnz_cap=int((A != 0).sum()))
+    torch.cuda.synchronize()
+    tol = 3e-5 if dt == torch.float32 else 1e-2
+    name = 'gcnwgrand_%s_%s' % ('x'.join(map(str, shape[:6])), str(dt)[6:])
+    assert diag(name + '_dW', dW.cpu().view_as(W), W.grad, tol) < tol
+    assert diag(name + '_dA', dA.cpu(), A.grad * (A.detach() != 0), tol) < tol
+    assert diag(name + '_S', S.cpu(), to_ntvc(dy).sum((0, 1)), tol) < tol
