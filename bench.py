@@ -44,7 +44,9 @@ def cpu_baseline(model_tag, T, seconds_budget=25.0):
     """Oracle train step on the host cores: 1 warm-up + up to 3 timed steps of batch 8 (bounded sample)."""
     from oracle import stgcn_ref as R
     gargs, nc, V = MODELS[model_tag]
-    cores = os.cpu_count() or 1
+    # 16 threads: fastest of {8,16,32,64} on the MI355X box's 256-core host for this model (tools/cpu_thread_sweep.py:
+    # 1.48 / 1.91 / 1.82 / 0.93 clips/s); torch's default of one thread per core (256) is 20x slower than that.
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     B = 8
     m = R.RefModel(model_tag, 3, nc, gargs, True, dropout=0.5)
