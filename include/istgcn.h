@@ -72,7 +72,7 @@ int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, const void* 
  * mode 0: epi = + bias[o];            stats += sum(out), sum(out^2)
  * mode 1: epi = * [aux*maux[0]+maux[1] > 0] (ReLU mask of the producer BatchNorm, aux = its input, same shape as out);
  *                                     stats += sum(out), sum(out * (aux - maux[2]) * maux[3])   (BatchNorm backward)
- * Wp: fragment-ordered weights, element (((((ch*ntaps + j)*MTtot + mt)*NKG + kg)*2 + h)*32 + r)*EPL + e holds
+ * Wp: fragment-ordered weights, element (((((ch*ntaps + j)*NKG + kg)*MTtot + mt)*2 + h)*32 + r)*EPL + e holds
  *   Wf[j][32*mt + r][ch*CC + kg*2*EPL + h*EPL + e]; CC, nch, MTtot, EPL from istgcn_tconv_geometry, NKG = CC/(2*EPL). */
 int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int* CC,
                           int* nch, int* MTtot, int* EPL);

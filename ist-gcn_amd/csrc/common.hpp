@@ -71,6 +71,65 @@ __device__ static inline void store4(__bf16* dst, const float (&v)[4]) {
   *reinterpret_cast<bf16x4*>(dst) = o;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Tile staging HBM/L2 -> LDS.  Copies an [R rows] x [Q 16-byte vectors] block whose global rows are `gstride`
+// elements apart into LDS rows `lstride` elements apart.  All U loads of a batch are issued before the first one
+// is consumed, so a 256-thread workgroup keeps U*4 KiB in flight (the serial load->use loop this replaces kept 4 KiB
+// and was pure memory latency).  Rows outside [r_lo, r_hi) and channels >= c_lim are written as zeros; an optional
+// per-channel affine (+ReLU) -- the BatchNorm in front of the consumer -- is applied on the way in.
+// VEC = rows are 16-byte aligned and whole vectors are either inside or outside c_lim.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int U, bool VEC>
+__device__ static inline void stage_block(const T* __restrict__ g, size_t gstride, int c_lim, T* lds, int lstride,
+                                          int R, int r_lo, int r_hi, int Q, const float* __restrict__ sc,
+                                          const float* __restrict__ sh, int relu, int tid, int nthreads) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  typedef typename E::frag frag_t;
+  const int tot = R * Q;
+  const bool pow2 = (Q & (Q - 1)) == 0;
+  const int lq = 31 - __builtin_clz(Q);
+  for (int base = tid; base < tot; base += nthreads * U) {
+    frag_t v[U];
+    int rr[U], qq[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * nthreads;
+      int r, q;
+      if (pow2) { r = it >> lq; q = it & (Q - 1); } else { r = it / Q; q = it - r * Q; }
+      rr[u] = r; qq[u] = q;
+      live[u] = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
+      zero_frag<T>(v[u]);
+      if (live[u]) {
+        const T* src = g + (size_t)r * gstride + q * EPL;
+        if (VEC) v[u] = *reinterpret_cast<const frag_t*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * nthreads;
+      if (it < tot) {
+        if (sc && live[u]) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            if (VEC || qq[u] * EPL + e < c_lim) {
+              float fv = E::to_f(v[u][e]) * sc[qq[u] * EPL + e] + sh[qq[u] * EPL + e];
+              if (relu) fv = fmaxf(fv, 0.f);
+              v[u][e] = E::from_f(fv);
+            }
+          }
+        }
+        *reinterpret_cast<frag_t*>(lds + rr[u] * lstride + qq[u] * EPL) = v[u];
+      }
+    }
+  }
+}
+
 __device__ static inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

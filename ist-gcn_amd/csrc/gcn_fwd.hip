@@ -134,7 +134,10 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
     for (int ch = 0; ch < P.nch; ++ch) {
       const int cb = ch * P.CCeff;
       // ---- stage x chunk: rows x CCeff channels -> xs (zero beyond Cin) ----
-      {
+      if (P.in_t_stride == 1) {
+        stage_block<T, 8, VEC_IN>(xg + ((size_t)(n * P.Tin + t0) * V) * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, xs,
+                                  P.xs_stride, rows, 0, rows, Q, nullptr, nullptr, 0, tid, NTHREADS);
+      } else {
         const int tot = rows * Q;
         for (int it = tid; it < tot; it += NTHREADS) {
           int r = it / Q, q = it - r * Q;
@@ -178,17 +181,31 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
         }
       }
       __syncthreads();
-      // ---- channel contraction on the matrix cores ----
+      // ---- channel contraction on the matrix cores (weight fragments of k-group kg+1 in flight during kg) ----
       {
         const T* brow = xa + (wave * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
         const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-        for (int kg = 0; kg < P.NKG; ++kg) {
-          const frag_t b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
+        frag_t a0[MT], a1[MT], b0, b1;
+        auto load_step = [&](int kg, frag_t (&a)[MT], frag_t& b) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const frag_t a = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
-            mma_kgroup(acc[m], a, b);
+          for (int m = 0; m < MT; ++m)
+            a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
+          b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
+        };
+        load_step(0, a0, b0);
+        for (int kg = 0; kg < P.NKG; kg += 2) {
+          load_step(min(kg + 1, P.NKG - 1), a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a0[m], b0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(min(kg + 2, P.NKG - 1), a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kg + 1 < P.NKG) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a1[m], b1);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();   // xa / xs free again (next chunk or the epilogue's staging buffer)

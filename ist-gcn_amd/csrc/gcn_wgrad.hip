@@ -112,31 +112,19 @@ __global__ __launch_bounds__(NTHREADS) void gcn_wgrad_kernel(const GwgParams P) 
     const int rows = nf * V;
 
     // ---- stage dy (c-tile) and x (i-tile), zero padded ----
-    for (int idx = tid; idx < TR * QV; idx += NTHREADS) {
-      const int r = idx / QV, q = idx - r * QV;
-      frag_t dv, xv;
-      zero_frag<T>(dv);
-      zero_frag<T>(xv);
-      if (r < rows) {
-        const size_t pos = (size_t)(n * P.T + t0 + row_f[r]) * V + row_w[r];
-        const int cc = c0 + q * EPL, ii = i0 + q * EPL;
-        if (cc < P.Cout) {
-          if (vec) dv = *reinterpret_cast<const frag_t*>(dyg + pos * P.Cout + cc);
-          else {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) if (cc + e < P.Cout) dv[e] = dyg[pos * P.Cout + cc + e];
-          }
-        }
-        if (ii < P.Cin) {
-          if (vec) xv = *reinterpret_cast<const frag_t*>(xg + pos * P.Cin + ii);
-          else {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) if (ii + e < P.Cin) xv[e] = xg[pos * P.Cin + ii + e];
-          }
-        }
+    {
+      const size_t pos0 = (size_t)(n * P.T + t0) * V;
+      if (vec) {
+        stage_block<T, 4, true>(dyg + pos0 * P.Cout + c0, (size_t)P.Cout, P.Cout - c0, dys, DS, TR, 0, rows, QV, nullptr,
+                                nullptr, 0, tid, NTHREADS);
+        stage_block<T, 4, true>(xg + pos0 * P.Cin + i0, (size_t)P.Cin, P.Cin - i0, xs, CB, TR, 0, rows, QV, nullptr,
+                                nullptr, 0, tid, NTHREADS);
+      } else {
+        stage_block<T, 4, false>(dyg + pos0 * P.Cout + c0, (size_t)P.Cout, P.Cout - c0, dys, DS, TR, 0, rows, QV, nullptr,
+                                 nullptr, 0, tid, NTHREADS);
+        stage_block<T, 4, false>(xg + pos0 * P.Cin + i0, (size_t)P.Cin, P.Cin - i0, xs, CB, TR, 0, rows, QV, nullptr,
+                                 nullptr, 0, tid, NTHREADS);
       }
-      *reinterpret_cast<frag_t*>(dys + r * DS + q * EPL) = dv;
-      *reinterpret_cast<frag_t*>(xs + r * CB + q * EPL) = xv;
     }
     __syncthreads();
     // ---- K aggregated images xa_k[p][i] ----

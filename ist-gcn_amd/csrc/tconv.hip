@@ -43,7 +43,7 @@ struct TconvParams {
 };
 
 template <typename T, int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NTHREADS) void tconv_kernel(const TconvParams P) {
+__global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int KGS = E::KGS;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_kernel(const TconvParams P) {
   unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);          // [TR]
   unsigned short* row_v = row_f + TR;                                        // [TR]
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
+  int* tap_roff = reinterpret_cast<int*>(stat + 2 * MT * 32);                 // [MAX_TAPS] LDS row offset per tap
   T* us = reinterpret_cast<T*>(smem + P.off_work);                           // [Fin*V][us_stride]
   T* outs = us;                                                              // [128][out_stride]
 
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_kernel(const TconvParams P) {
     row_v[r] = (unsigned short)(r - f * V);
   }
   for (int c = tid; c < 2 * MT * 32; c += NTHREADS) stat[c] = 0.f;
+  if (tid < P.ntaps) tap_roff[tid] = (P.tap_off[tid] - P.min_off) * V;
   __syncthreads();
 
   const T* ing = reinterpret_cast<const T*>(P.in);
@@ -110,50 +112,51 @@ __global__ __launch_bounds__(NTHREADS) void tconv_kernel(const TconvParams P) {
     for (int ch = 0; ch < P.nch; ++ch) {
       const int cb = ch * P.CC;
       // ---- stage the input rows of this chunk (BatchNorm affine + ReLU applied on the way in) ----
-      for (int it = tid; it < in_rows * Q; it += NTHREADS) {
-        const int r = it / Q, q = it - r * Q;
-        const int fl = r / V, v = r - fl * V;
-        const int fr = fin0 + fl;
-        const int c0 = cb + q * EPL;
-        frag_t val;
-        zero_frag<T>(val);
-        if (fr >= 0 && fr < P.Tin && c0 < P.Cin) {
-          const size_t g = ((size_t)(n * P.Tin + fr) * V + v) * P.Cin + c0;
-          if (VEC) {
-            val = *reinterpret_cast<const frag_t*>(ing + g);
-          } else {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) if (c0 + j < P.Cin) val[j] = ing[g + j];
-          }
-          if (P.pre) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-              if (VEC || c0 + j < P.Cin) {
-                float fv = E::to_f(val[j]) * P.pre[c0 + j] + P.pre[P.Cin + c0 + j];
-                if (P.pre_relu) fv = fmaxf(fv, 0.f);
-                val[j] = E::from_f(fv);
-              }
-            }
-          }
-        }
-        *reinterpret_cast<frag_t*>(us + r * P.us_stride + q * EPL) = val;
+      {
+        const long long row0 = (long long)(n * P.Tin + fin0) * V;
+        const int r_lo = fin0 < 0 ? -fin0 * V : 0;
+        const int r_hi = min(in_rows, (P.Tin - fin0) * V);
+        stage_block<T, 8, VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
+                               Q, P.pre ? P.pre + cb : nullptr, P.pre ? P.pre + P.Cin + cb : nullptr, P.pre_relu, tid,
+                               NTHREADS);
       }
       __syncthreads();
-      // ---- taps x k-groups on the matrix cores ----
-      for (int j = 0; j < P.ntaps; ++j) {
-        const int roff = (P.tap_off[j] - P.min_off) * V;
-        const T* wtap = Wp + ((size_t)((ch * P.ntaps + j) * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-        for (int kg = 0; kg < P.NKG; ++kg) {
-          frag_t b[NT];
+      // ---- taps x k-groups on the matrix cores, software pipelined: the weight fragments (L2) and the shifted
+      //      activation fragments (LDS) of step it+1 are in flight while the MFMAs of step it issue ----
+      {
+        const int nit = P.ntaps * P.NKG;                       // NKG is a power of two
+        const int lkg = 31 - __builtin_clz(P.NKG);
+        const T* wbase = Wp + (((size_t)ch * nit) * P.MTtot + mt0) * 64 * EPL + lane * EPL;
+        const int hoff = (lane >> 5) * EPL;
+        frag_t a0[MT], a1[MT], b0[NT], b1[NT];
+        auto load_step = [&](int it, frag_t (&a)[MT], frag_t (&b)[NT]) {
+          const int j = it >> lkg, kg = it & (P.NKG - 1);
+          const int roff = tap_roff[j];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            a[m] = *reinterpret_cast<const frag_t*>(wbase + ((size_t)it * P.MTtot + m) * 64 * EPL);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            b[t] = *reinterpret_cast<const frag_t*>(us + (brow[t] + roff) * P.us_stride + kg * KGS + (lane >> 5) * EPL);
+            b[t] = *reinterpret_cast<const frag_t*>(us + (brow[t] + roff) * P.us_stride + kg * KGS + hoff);
+        };
+        auto mma_step = [&](const frag_t (&a)[MT], const frag_t (&b)[NT]) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const frag_t a = *reinterpret_cast<const frag_t*>(wtap + ((size_t)m * P.NKG + kg) * 64 * EPL);
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a, b[t]);
-          }
+            for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
+        };
+        // steps beyond the last one re-load the last step (never consumed): no data-dependent control flow around the
+        // loads, so the compiler's vmcnt bookkeeping is exact and the MFMAs of step `it` wait only for step `it`.
+        load_step(0, a0, b0);
+        for (int it = 0; it < nit; it += 2) {
+          load_step(min(it + 1, nit - 1), a1, b1);
+          __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it hides behind
+          mma_step(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_step(min(it + 2, nit - 1), a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (it + 1 < nit) mma_step(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __syncthreads();
@@ -328,7 +331,7 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
   G->Fin = in_mul * (G->F - 1) + (mx - mn) + 1;
   G->us_stride = cc + epl;
   size_t off = (size_t)2 * 128 * best_nt * sizeof(unsigned short);
-  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off; off += (size_t)2 * G->MT * 32 * 4;
+  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off; off += (size_t)2 * G->MT * 32 * 4 + MAX_TAPS * 4;
   off = (off + 15) & ~(size_t)15; G->off_work = (int)off;
   size_t work = (size_t)G->Fin * V * G->us_stride * esz;
   size_t ost = (size_t)128 * G->out_stride * esz;

@@ -3,13 +3,15 @@
 // are zero), and the conv-bias gradient dbias[o] += sum dz.  Autograd of net/st_gcnold.py:167-173 (and of the
 // pre-summed 15-tap Inception-TCN, st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215).
 //
-// This is a GEMM whose contraction runs over every position of the batch (millions) and whose output is tiny,
-// so: a workgroup owns ONE 32x32 (o-tile, i-tile) block for ALL taps and keeps the ntaps accumulator tiles in
-// registers while it walks position tiles in a grid-stride loop; each of its 4 waves contracts its own quarter
-// of the tile's positions (no intra-tile reduction), and the per-wave partial tiles are flushed ONCE at the end
-// with fp32 atomics shaped as two 128-byte row segments per instruction.  dz fragments are reused across taps;
-// the shifted u fragments come from one staged halo tile.  bf16 operands are row-major [position][channel] in LDS
-// and reach the MFMA k axis through ds_read_b64_tr_b16.
+// This is a GEMM whose contraction runs over every position of the batch (millions) and whose output is tiny, so
+// the output stays in registers: a workgroup owns an (OT*32) x (IT*32) channel block for ALL taps, each of its 4
+// waves keeps the ntaps 32x32 accumulator tiles of one (o-tile, i-tile) pair -- or of one PS-th of the tile's
+// positions -- while the workgroup walks position tiles in a grid-stride loop, and everything is flushed ONCE at
+// the end with fp32 atomics shaped as two 128-byte row segments per instruction.  A dz fragment is reused across
+// all taps; the tap-shifted u fragments come from one staged halo tile.  Operands live in LDS as 32-channel
+// sub-tiles [row][32] (64-byte rows for bf16: conflict-free for ds_read_b64_tr_b16, which feeds the MFMA k axis =
+// position axis straight from the row-major image); fp32 operand registers are double buffered so LDS latency
+// hides behind the MFMAs of the previous k-step.
 #include "common.hpp"
 
 namespace {
@@ -17,6 +19,7 @@ namespace {
 constexpr int NTHREADS = 256;
 constexpr int TR = 128;
 constexpr int MAX_TAPS = 16;
+constexpr int CB = 32;
 
 struct TwgParams {
   const void* dz;        // [NM][Tz][V][Cout]
@@ -26,29 +29,95 @@ struct TwgParams {
   float* dbias;          // [Cout] or null
   int NM, Tin, Tz, V, Cin, Cout, ntaps, in_mul, pre_relu;
   int tap_off[MAX_TAPS];
-  int F, tiles_per_seq, total_tiles, min_off, Fin, n_itile;
+  int F, tiles_per_seq, total_tiles, min_off, Fin, n_iblk, urows;
   int off_urow, off_dz, off_u;   // LDS byte offsets
 };
 
-template <typename T, int JT>
-__global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P) {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ static inline bf16x8 tr_pair(const __bf16* lo_addr, const __bf16* hi_addr) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_addr);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_addr);
+  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  bf16x8 o;
+  o[0] = l4[0]; o[1] = l4[1]; o[2] = l4[2]; o[3] = l4[3];
+  o[4] = h4[0]; o[5] = h4[1]; o[6] = h4[2]; o[7] = h4[3];
+  return o;
+}
+
+// sub-tiled staging: vector q of a row goes to sub-tile q / QV
+template <typename T, int U, bool VEC>
+__device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gstride, int c_lim, T* lds, int sub_elems,
+                                             int R, int r_lo, int r_hi, int nsub, const float* __restrict__ sc,
+                                             const float* __restrict__ sh, int relu, int tid) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
+  constexpr int QV = CB / EPL;
   typedef typename E::frag frag_t;
-  constexpr int CB = 32;                         // channels per operand tile
-  constexpr int QV = CB / EPL;                   // 16-byte vectors per staged row
+  const int Q = nsub * QV;                 // power of two
+  const int lq = 31 - __builtin_clz(Q);
+  const int tot = R * Q;
+  for (int base = tid; base < tot; base += NTHREADS * U) {
+    frag_t v[U];
+    int rr[U], qq[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * NTHREADS;
+      const int r = it >> lq, q = it & (Q - 1);
+      rr[u] = r; qq[u] = q;
+      live[u] = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
+      zero_frag<T>(v[u]);
+      if (live[u]) {
+        const T* src = g + (size_t)r * gstride + q * EPL;
+        if (VEC) v[u] = *reinterpret_cast<const frag_t*>(src);
+        else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * NTHREADS;
+      if (it < tot) {
+        if (sc && live[u]) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            if (VEC || qq[u] * EPL + e < c_lim) {
+              float fv = E::to_f(v[u][e]) * sc[qq[u] * EPL + e] + sh[qq[u] * EPL + e];
+              if (relu) fv = fmaxf(fv, 0.f);
+              v[u][e] = E::from_f(fv);
+            }
+          }
+        }
+        const int sub = qq[u] / QV, ql = qq[u] - sub * QV;
+        *reinterpret_cast<frag_t*>(lds + sub * sub_elems + rr[u] * CB + ql * EPL) = v[u];
+      }
+    }
+  }
+}
+
+template <typename T, int JT, int OT, int IT, int PS>
+__global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P) {
+  static_assert(OT * IT * PS == 4, "one (o-tile, i-tile, position-slice) per wave");
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  constexpr int NPOS = TR / PS;                  // positions contracted by one wave per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);      // [TR]
-  unsigned short* row_v = row_f + TR;                                    // [TR]
-  unsigned short* urow = reinterpret_cast<unsigned short*>(smem + P.off_urow);  // [TR] u-tile row at tap offset 0
-  T* dzs = reinterpret_cast<T*>(smem + P.off_dz);                        // [TR][CB]
-  T* us = reinterpret_cast<T*>(smem + P.off_u);                          // [Fin*V][CB]
+  unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);               // [TR]
+  unsigned short* row_v = row_f + TR;                                             // [TR]
+  unsigned short* urow = reinterpret_cast<unsigned short*>(smem + P.off_urow);    // [TR] u-tile row at tap offset 0
+  T* dzs = reinterpret_cast<T*>(smem + P.off_dz);                                 // [OT][TR][CB]
+  T* us = reinterpret_cast<T*>(smem + P.off_u);                                   // [IT][urows][CB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V;
-  const int ot = blockIdx.y / P.n_itile, it = blockIdx.y - ot * P.n_itile;
-  const int o0 = ot * CB, i0 = it * CB;
+  const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
+  const int ot = wave % OT, it = (wave / OT) % IT, ps = wave / (OT * IT);
+  const int o0 = oblk * (OT * CB), i0 = iblk * (IT * CB);
   const bool vec = (P.Cin % EPL == 0) && (P.Cout % EPL == 0);
+  const int u_sub = P.urows * CB;
 
   for (int r = tid; r < TR; r += NTHREADS) {
     int f = r / V;
@@ -62,10 +131,17 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   for (int j = 0; j < JT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float bsum = 0.f;   // dbias partial: thread (c = tid & 31, rows tid>>5 step 8)
+  float bsum = 0.f;
+
+  // per-tap element offset into a u sub-tile (taps beyond ntaps alias tap 0: computed, never flushed)
+  int toff[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) toff[j] = (P.tap_off[j] - P.min_off) * V * CB;
 
   const T* dzg = reinterpret_cast<const T*>(P.dz);
   const T* gg = reinterpret_cast<const T*>(P.g);
+  const T* dz_w = dzs + ot * (TR * CB);
+  const T* us_w = us + it * u_sub;
 
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int n = tile / P.tiles_per_seq;
@@ -75,110 +151,77 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     const int fin0 = P.in_mul * m0 + P.min_off;
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;
 
-    // ---- stage dz tile (zero pad rows) ----
-    for (int idx = tid; idx < TR * QV; idx += NTHREADS) {
-      const int r = idx / QV, q = idx - r * QV;
-      const int c0 = o0 + q * EPL;
-      frag_t val;
-      zero_frag<T>(val);
-      if (r < rows && c0 < P.Cout) {
-        const size_t a = ((size_t)(n * P.Tz + m0 + row_f[r]) * V + row_v[r]) * P.Cout + c0;
-        if (vec) val = *reinterpret_cast<const frag_t*>(dzg + a);
-        else {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) if (c0 + e < P.Cout) val[e] = dzg[a + e];
-        }
-      }
-      *reinterpret_cast<frag_t*>(dzs + r * CB + q * EPL) = val;
+    // ---- stage dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
+    {
+      const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
+      if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+      else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
     }
     for (int r = tid; r < TR; r += NTHREADS)
       urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
-    // ---- stage u tile with halo: pre(g), zero outside the sequence ----
-    for (int idx = tid; idx < in_rows * QV; idx += NTHREADS) {
-      const int r = idx / QV, q = idx - r * QV;
-      const int fl = r / V, v = r - fl * V;
-      const int fr = fin0 + fl;
-      const int c0 = i0 + q * EPL;
-      frag_t val;
-      zero_frag<T>(val);
-      if (fr >= 0 && fr < P.Tin && c0 < P.Cin) {
-        const size_t a = ((size_t)(n * P.Tin + fr) * V + v) * P.Cin + c0;
-        if (vec) val = *reinterpret_cast<const frag_t*>(gg + a);
-        else {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) if (c0 + e < P.Cin) val[e] = gg[a + e];
-        }
-        if (P.pre) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            if (c0 + e < P.Cin) {
-              float fv = E::to_f(val[e]) * P.pre[c0 + e] + P.pre[P.Cin + c0 + e];
-              if (P.pre_relu) fv = fmaxf(fv, 0.f);
-              val[e] = E::from_f(fv);
-            }
-          }
-        }
-      }
-      *reinterpret_cast<frag_t*>(us + r * CB + q * EPL) = val;
+    {
+      const long long row0 = (long long)(n * P.Tin + fin0) * V;
+      const int r_lo = fin0 < 0 ? -fin0 * V : 0;
+      const int r_hi = min(in_rows, (P.Tin - fin0) * V);
+      const float* sc = P.pre ? P.pre + i0 : nullptr;
+      const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
+      const T* src = gg + row0 * P.Cin + i0;
+      if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
+      else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
     }
     __syncthreads();
 
-    if (P.dbias && it == 0) {
-      const int c = tid & 31;
-      for (int r = tid >> 5; r < rows; r += 8) bsum += E::to_f(dzs[r * CB + c]);
+    if (P.dbias && iblk == 0) {
+      constexpr int NC = OT * CB;
+      const int c = tid % NC;
+      const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
+      for (int r = tid / NC; r < rows; r += NTHREADS / NC) bsum += E::to_f(col[r * CB]);
     }
 
-    // ---- this wave's 32 positions: D_j[o][i] += dz[p][o] * u[row(p) + tap_j][i] ----
+    // ---- D_j[o][i] += dz[p][o] * u[row(p) + tap_j][i] over this wave's positions ----
+    const int pbase = ps * NPOS;
     if constexpr (sizeof(T) == 4) {
+      constexpr int NK = NPOS / 2;
       const int r = lane & 31, h = lane >> 5;
-#pragma unroll 4
-      for (int kk = 0; kk < 16; ++kk) {
-        const int p = wave * 32 + 2 * kk + h;
-        const float a = dzs[p * CB + r];
-        const int ub = urow[p];
+      float a0, a1, b0[JT], b1[JT];
+      auto load_k = [&](int kk, float& a, float (&b)[JT]) {
+        const int p = pbase + 2 * kk + h;
+        a = dz_w[p * CB + r];
+        const T* ub = us_w + urow[p] * CB + r;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-          if (j < P.ntaps) {
-            const float b = us[(ub + (P.tap_off[j] - P.min_off) * V) * CB + r];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
-          }
-        }
+        for (int j = 0; j < JT; ++j) b[j] = ub[toff[j]];
+      };
+      auto mma_k = [&](float a, const float (&b)[JT]) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+      };
+      load_k(0, a0, b0);
+      for (int kk = 0; kk < NK; kk += 2) {
+        load_k(kk + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_k(min(kk + 2, NK - 1), a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      constexpr int NK = NPOS / 16;
       const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
       const int q = (lane & 15) >> 2, pp = lane & 3;
+      const int coff = cblk + 4 * pp;
+      bf16x8 a, b[JT];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int pb = wave * 32 + 16 * kk + 8 * h;       // this lane-half's 8 positions: pb .. pb+7
-        // A = dz^T: rows pb+4s+q of dzs, columns cblk + 4*pp
-        bf16x8 a;
-        {
-          typedef short s16x4 __attribute__((ext_vector_type(4)));
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(dzs + (pb + q) * CB + cblk + 4 * pp));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(dzs + (pb + 4 + q) * CB + cblk + 4 * pp));
-          bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-          a[0] = l4[0]; a[1] = l4[1]; a[2] = l4[2]; a[3] = l4[3];
-          a[4] = h4[0]; a[5] = h4[1]; a[6] = h4[2]; a[7] = h4[3];
-        }
-        const int ub0 = urow[pb + q], ub1 = urow[pb + 4 + q];
+      for (int kk = 0; kk < NK; ++kk) {
+        const int pb = pbase + 16 * kk + 8 * h + q;          // this lane addresses rows pb and pb+4 of its 8 positions
+        a = tr_pair(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
+        const T* u0 = us_w + urow[pb] * CB + coff;
+        const T* u1 = us_w + urow[pb + 4] * CB + coff;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
-          if (j < P.ntaps) {
-            const int ro = (P.tap_off[j] - P.min_off) * V;
-            typedef short s16x4 __attribute__((ext_vector_type(4)));
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(us + (ub0 + ro) * CB + cblk + 4 * pp));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(us + (ub1 + ro) * CB + cblk + 4 * pp));
-            bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-            bf16x8 b;
-            b[0] = l4[0]; b[1] = l4[1]; b[2] = l4[2]; b[3] = l4[3];
-            b[4] = h4[0]; b[5] = h4[1]; b[6] = h4[2]; b[7] = h4[3];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
-          }
-        }
+        for (int j = 0; j < JT; ++j) b[j] = tr_pair(u0 + toff[j], u1 + toff[j]);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -190,21 +233,60 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     if (j < P.ntaps) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = o0 + mfma_row(r, lane), i = i0 + (lane & 31);
+        const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
         if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[j][r]);
       }
     }
   }
-  if (P.dbias && it == 0) {
-    // reduce the 8 row-groups that share a channel: lanes l and l+32 within a wave, then across waves via atomics
-    bsum += __shfl_xor(bsum, 32);
-    if (lane < 32 && o0 + lane < P.Cout) atomicAdd(P.dbias + o0 + lane, bsum);
+  if (P.dbias && iblk == 0) {
+    constexpr int NC = OT * CB;
+    if (NC == 32) bsum += __shfl_xor(bsum, 32);
+    const int c = tid % NC;
+    if ((NC == 64 || lane < 32) && o0 + c < P.Cout) atomicAdd(P.dbias + o0 + c, bsum);
   }
+}
+
+template <typename T, int JT, int OT, int IT, int PS>
+int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
+  const int esz = sizeof(T);
+  P.n_iblk = ceil_div(P.Cin, IT * CB);
+  const int n_oblk = ceil_div(P.Cout, OT * CB);
+  P.urows = P.Fin * P.V;
+  size_t off = (size_t)2 * TR * 2;
+  off = (off + 15) & ~(size_t)15; P.off_urow = (int)off; off += (size_t)TR * 2;
+  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)OT * TR * CB * esz;
+  off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)IT * P.urows * CB * esz;
+  if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
+  const int blocks = n_oblk * P.n_iblk;
+  int gx = grid_cap / blocks;
+  if (gx < 1) gx = 1;
+  if (gx > P.total_tiles) gx = P.total_tiles;
+  dim3 grid(gx, blocks);
+  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (ea_ != hipSuccess) return 2000 + (int)ea_;
+    attr_done = true;
+  }
+  ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), off, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+template <typename T, int JT>
+int launch_JT(TwgParams& P, int grid_cap, hipStream_t stream) {
+  // channel block per workgroup: as wide as the layer and LDS allow (fewer redundant reads of dz / g, more MFMA work
+  // per staged byte); narrow layers fall back to one 32x32 pair split four ways over positions.
+  if constexpr (sizeof(T) == 2) {
+    if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 1>(P, grid_cap, stream);
+  }
+  if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 2>(P, grid_cap, stream);
+  return launch_cfg<T, JT, 1, 1, 4>(P, grid_cap, stream);
 }
 
 template <typename T>
 int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
-  const int esz = sizeof(T);
   int mn = P.tap_off[0], mx = P.tap_off[0];
   for (int j = 1; j < P.ntaps; ++j) { mn = P.tap_off[j] < mn ? P.tap_off[j] : mn; mx = P.tap_off[j] > mx ? P.tap_off[j] : mx; }
   P.min_off = mn;
@@ -212,36 +294,10 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.Fin = P.in_mul * (P.F - 1) + (mx - mn) + 1;
   P.tiles_per_seq = ceil_div(P.Tz, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  P.n_itile = ceil_div(P.Cin, 32);
-  const int n_otile = ceil_div(P.Cout, 32);
-  size_t off = (size_t)2 * TR * 2;
-  off = (off + 15) & ~(size_t)15; P.off_urow = (int)off; off += (size_t)TR * 2;
-  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)TR * 32 * esz;
-  off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)P.Fin * P.V * 32 * esz;
-  if (off > 160 * 1024 || P.Fin * P.V > 65535) return ISTGCN_EINVAL;
-  const int pairs = n_otile * P.n_itile;
-  int gx = grid_cap / pairs;
-  if (gx < 1) gx = 1;
-  if (gx > P.total_tiles) gx = P.total_tiles;
-  dim3 grid(gx, pairs);
-#define GO(JTv)                                                                                             \
-  do {                                                                                                      \
-    auto kfn = tconv_wgrad_kernel<T, JTv>;                                                                  \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done) {                                                                                       \
-      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
-      attr_done = true;                                                                                     \
-    }                                                                                                       \
-    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), off, stream, P);                                          \
-  } while (0)
-  if (P.ntaps <= 1) GO(1);
-  else if (P.ntaps <= 3) GO(3);
-  else if (P.ntaps <= 9) GO(9);
-  else GO(15);
-#undef GO
-  ISTGCN_CHECK_LAUNCH();
-  return ISTGCN_OK;
+  if (P.ntaps <= 1) return launch_JT<T, 1>(P, grid_cap, stream);
+  if (P.ntaps <= 3) return launch_JT<T, 3>(P, grid_cap, stream);
+  if (P.ntaps <= 9) return launch_JT<T, 9>(P, grid_cap, stream);
+  return launch_JT<T, 15>(P, grid_cap, stream);
 }
 
 }  // namespace
@@ -259,6 +315,7 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps; P.in_mul = in_mul;
   P.pre_relu = pre_relu;
   for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
+  for (int j = ntaps; j < MAX_TAPS; ++j) P.tap_off[j] = tap_off[0];    // padding taps: valid addresses, never flushed
   if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);

@@ -137,12 +137,12 @@ def tconv_geometry(V, cin, cout, tap_off, in_mul, dt):
 
 
 def pack_tconv_weight(wf, V, tap_off, in_mul, dtype):
-    """wf: [ntaps][Cout][Cin] fp32 -> [nch][ntaps][MTtot][NKG][2][32][EPL] fragments (see istgcn.h)."""
+    """wf: [ntaps][Cout][Cin] fp32 -> [nch][ntaps][NKG][MTtot][2][32][EPL] fragments (see istgcn.h)."""
     ntaps, cout, cin = wf.shape
     cc, nch, mttot, epl = tconv_geometry(V, cin, cout, tap_off, in_mul, _DT[dtype])
     nkg = cc // (2 * epl)
     w = F.pad(wf, (0, nch * cc - cin, 0, mttot * 32 - cout))
-    w = w.reshape(ntaps, mttot, 32, nch, nkg, 2, epl).permute(3, 0, 1, 4, 5, 2, 6)
+    w = w.reshape(ntaps, mttot, 32, nch, nkg, 2, epl).permute(3, 0, 4, 1, 5, 2, 6)
     return w.to(dtype).contiguous()
 
 

@@ -59,8 +59,8 @@ def test_geometry_and_packing_agree():
     cc, nch, mttot, epl = ops.tconv_geometry(25, 64, 128, taps, 1, 0)
     wf = torch.randn(9, 128, 64)
     wp = ops.pack_tconv_weight(wf, 25, taps, 1, torch.float32)
-    assert wp.shape == (nch, 9, mttot, cc // (2 * epl), 2, 32, epl)
-    assert float(wp[1, 3, 2, 1, 1, 5, 2]) == float(wf[3, 2 * 32 + 5, 1 * cc + 1 * 2 * epl + 1 * epl + 2])
+    assert wp.shape == (nch, 9, cc // (2 * epl), mttot, 2, 32, epl)
+    assert float(wp[1, 3, 1, 2, 1, 5, 2]) == float(wf[3, 2 * 32 + 5, 1 * cc + 1 * 2 * epl + 1 * epl + 2])
 
 
 def test_invalid_arguments_are_rejected_before_launch(lib):
