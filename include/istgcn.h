@@ -48,16 +48,25 @@ int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* b
                    int V, int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int nnz_cap,
                    int dtype, int grid_cap, void* stream);
 
-/* Parameter gradients of the graph-convolution unit (autograd of net/utils/tgcn.py:79-86 and the folded variants):
- *   dW[k][c][i] += sum_{n,t,w} dy[n,t,w,c] * sum_v A[k][v][w] x[n,t,v,i]       (= Conv2d weight grad, [K*Cout][Cin])
- *   dA[k][v][w] += sum_{n,t,i} x[n,t,v,i] * sum_c W[k][c][i] dy[n,t,w,c]       only where A[k][v][w] != 0
- *   S[w][c]     += sum_{n,t} dy[n,t,w,c]                                        (bias-term gradient)
- * dy [NM][T][V][Cout], x [NM][T][V][Cin], A [K][V][V] fp32, K <= 4.  dW / dA / S are fp32, ACCUMULATED (caller zeroes).
- * dA, S may be NULL.  Wq (needed with dA): W^T fragments, element [ct][it][k][kg][h][r][e] =
- * W[k][32*ct + kg*2*EPL + h*EPL + e][32*it + r], zero padded (EPL = 4 fp32 / 8 bf16). */
-int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, const void* Wq, float* dW, float* dA, float* S,
-                     int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap,
-                     void* stream);
+/* Backward of the graph-convolution unit (autograd of net/utils/tgcn.py:79-86 and the folded variants), two launches.
+ *
+ * istgcn_gcn_bwd_data: dx[n,t,v,i] = sum_k sum_w A[k][v][w] * dxa_k[n,t,w,i] (+ addend),  dxa_k = sum_c W[k][c][i] dy[..,c]
+ *                      dA[k][v][w] += sum_{n,t,i} x[n,t,v,i] * dxa_k[n,t,w,i]   only where A[k][v][w] != 0 (the only
+ *                      entries an importance gradient A (.) dA can see); dA may be NULL (then x may be NULL too).
+ *   dy [NM][T][V][Cout], x / addend / dx [NM][T][V][Cin] (addend NULL or the identity-residual gradient, may alias dx),
+ *   Wb: fragments of W for the dxa product, element [ich][cch][kg][mt][h][r][e] =
+ *       W[k][cch*CCc + kg*2*EPL + h*EPL + e][ich*CCi + il]  with  k*CCi + il = 32*mt + r  (zero padded);
+ *       CCi, nchi, CCc, nchc, KKp (rows, = 32*MTK), EPL from istgcn_gcn_bwd_geometry.
+ * istgcn_gcn_wgrad:    dW[k][c][i] += sum_{n,t,w} dy[n,t,w,c] * sum_v A[k][v][w] x[n,t,v,i]   (= Conv2d weight grad)
+ *                      S[w][c]     += sum_{n,t} dy[n,t,w,c]        (gradient of the bias term; S may be NULL)
+ * A [K][V][V] fp32, K <= 4.  dW / dA / S are fp32 and ACCUMULATED (the caller zeroes them). */
+int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc, int* KKp,
+                            int* EPL);
+int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const void* Wb, const void* addend, void* dx,
+                        float* dA, int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap, int dtype,
+                        int grid_cap, void* stream);
+int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V, int Cin,
+                     int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream);
 
 /* Temporal (k,1) convolution over the frame axis as an implicit GEMM (and its data gradient):
  *   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) ),

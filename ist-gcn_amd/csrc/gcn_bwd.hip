@@ -1,0 +1,340 @@
+// Data gradient and adjacency gradient of the graph-convolution unit in ONE pass (autograd of net/utils/tgcn.py:79-86
+// and the folded variants):
+//     dxa_k[(t,w)][i] = sum_c W[k][c][i] * dy[(t,w)][c]                       MFMA 32x32, contraction over Cout
+//     dx[(t,v)][i]    = sum_k sum_w A[k][v][w] * dxa_k[(t,w)][i]  (+ addend)  sparse LDS pass (rows of A)
+//     dA[k][v][w]    += sum_{t,i} x[(t,v)][i] * dxa_k[(t,w)][i]               only where A[k][v][w] != 0
+// This is the forward kernel run "GEMM-first": the K*Cin-wide intermediate dxa never leaves LDS, and because it is the
+// very tile the adjacency gradient needs, dA costs a handful of LDS dot products instead of a second GEMM (every
+// importance gradient upstream is A (.) dA: st_gcnold.py:86, tgcn_multi3_fix_3A.py:86-88, st_gcn_msgcn.py:116-117).
+// `addend` carries the identity-residual gradient of the st_gcn block (st_gcnold.py:181-182,201), so the block's input
+// gradient is written once.
+//
+// One workgroup (4 waves) owns 128 rows (whole frames) of one sequence; wave w owns rows [32w, 32w+32) as MFMA columns,
+// the (k,i) outputs of the current input-channel chunk are the MFMA rows.  Weight fragments stream from L2 one k-group
+// ahead of the MFMAs that consume them.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int TR = 128;
+
+struct GbdParams {
+  const void* dy;        // [NM][T][V][Cout]
+  const void* x;         // [NM][T][V][Cin] or null
+  const float* A;        // [K][V][V]
+  const void* Wb;        // fragments, see istgcn.h
+  const void* addend;    // [NM][T][V][Cin] or null (may alias dx)
+  void* dx;              // [NM][T][V][Cin]
+  float* dA;             // [K][V][V] accumulated, or null
+  int NM, T, V, Cin, Cout, K, nnz_cap;
+  int F, tiles_per_seq, total_tiles, CCi, nchi, CCc, nchc, NKGc, ds_stride;
+  int off_rv, off_rkw, off_ra, off_dacc, off_rows, off_dys, off_dxa;
+};
+
+template <typename T, int MTK, bool VEC>
+__global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  constexpr int KGS = E::KGS;
+  typedef typename E::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* r_off = reinterpret_cast<int*>(smem);                                         // [V+1] row lists of A
+  unsigned char* r_v = smem + P.off_rv;                                              // [cap] v of entry
+  unsigned short* r_kw = reinterpret_cast<unsigned short*>(smem + P.off_rkw);        // [cap] k*V + w
+  float* r_a = reinterpret_cast<float*>(smem + P.off_ra);                            // [cap]
+  float* dacc = reinterpret_cast<float*>(smem + P.off_dacc);                         // [cap]
+  unsigned char* row_f = smem + P.off_rows;                                          // [TR]
+  unsigned char* row_v = row_f + TR;                                                 // [TR]
+  T* dys = reinterpret_cast<T*>(smem + P.off_dys);                                   // [TR][ds_stride]  (later: x chunk)
+  T* dxa = reinterpret_cast<T*>(smem + P.off_dxa);                                   // [K][TR][CCi]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = P.V, K = P.K, CCi = P.CCi, DS = P.ds_stride;
+  const int Qi = CCi / EPL;
+
+  // ---- adjacency -> LDS (coalesced), then per-ROW compressed lists: row v -> entries (k, w, a) ----
+  {
+    float* A_l = reinterpret_cast<float*>(dxa);
+    for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = P.A[i];
+    for (int c = tid; c < P.nnz_cap; c += NTHREADS) dacc[c] = 0.f;
+    for (int r = tid; r < TR; r += NTHREADS) {
+      int f = r / V;
+      row_f[r] = (unsigned char)f;
+      row_v[r] = (unsigned char)(r - f * V);
+    }
+    __syncthreads();
+    if (tid < V) {
+      int cnt = 0;
+      for (int k = 0; k < K; ++k)
+        for (int w = 0; w < V; ++w) cnt += (A_l[(k * V + tid) * V + w] != 0.f);
+      r_off[tid + 1] = cnt;
+    }
+    if (tid == 0) r_off[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int v = 0; v < V; ++v) { int nn = r_off[v + 1]; r_off[v] = run; run += nn; }
+      r_off[V] = run;
+    }
+    __syncthreads();
+    if (tid < V) {
+      int e = r_off[tid];
+      for (int k = 0; k < K; ++k)
+        for (int w = 0; w < V; ++w) {
+          const float a = A_l[(k * V + tid) * V + w];
+          if (a != 0.f) {
+            if (e < P.nnz_cap) { r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = a; }
+            ++e;
+          }
+        }
+    }
+    __syncthreads();
+  }
+  const int nnz = min(r_off[V], P.nnz_cap);
+
+  const T* dyg = reinterpret_cast<const T*>(P.dy);
+  const T* xg = reinterpret_cast<const T*>(P.x);
+  const T* Wb = reinterpret_cast<const T*>(P.Wb);
+  const T* addg = reinterpret_cast<const T*>(P.addend);
+  T* dxg = reinterpret_cast<T*>(P.dx);
+
+  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    const int n = tile / P.tiles_per_seq;
+    const int t0 = (tile - n * P.tiles_per_seq) * P.F;
+    const int nf = min(P.F, P.T - t0);
+    const int rows = nf * V;
+    const size_t pos0 = (size_t)(n * P.T + t0) * V;
+
+    for (int ich = 0; ich < P.nchi; ++ich) {
+      const int ib = ich * CCi;
+      f32x16 acc[MTK];
+#pragma unroll
+      for (int m = 0; m < MTK; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+      for (int cch = 0; cch < P.nchc; ++cch) {
+        const int cb = cch * P.CCc;
+        stage_block<T, 8, VEC>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
+                               nullptr, nullptr, 0, tid, NTHREADS);
+        __syncthreads();
+        {
+          const T* brow = dys + (wave * 32 + (lane & 31)) * DS + (lane >> 5) * EPL;
+          const T* wfrag = Wb + ((size_t)(ich * P.nchc + cch) * P.NKGc * MTK * 64 + lane) * EPL;
+          frag_t a0[MTK], a1[MTK], b0, b1;
+          auto load_step = [&](int kg, frag_t (&a)[MTK], frag_t& b) {
+#pragma unroll
+            for (int m = 0; m < MTK; ++m)
+              a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)kg * MTK + m) * 64 * EPL);
+            b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
+          };
+          load_step(0, a0, b0);
+          for (int kg = 0; kg < P.NKGc; kg += 2) {
+            load_step(min(kg + 1, P.NKGc - 1), a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MTK; ++m) mma_kgroup(acc[m], a0[m], b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(min(kg + 2, P.NKGc - 1), a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg + 1 < P.NKGc) {
+#pragma unroll
+              for (int m = 0; m < MTK; ++m) mma_kgroup(acc[m], a1[m], b1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();
+      }
+
+      // ---- dxa chunk -> LDS [k][p][il]; x chunk -> the (now free) dy buffer for the adjacency gradient ----
+      {
+        const int p = wave * 32 + (lane & 31);
+#pragma unroll
+        for (int m = 0; m < MTK; ++m) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int kk = m * 32 + 8 * g + 4 * (lane >> 5);
+            if (kk < K * CCi) {
+              const int k = kk / CCi, il = kk - k * CCi;
+              float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+              store4(dxa + (k * TR + p) * CCi + il, v4);
+            }
+          }
+        }
+      }
+      if (P.dA)
+        stage_block<T, 4, VEC>(xg + pos0 * P.Cin + ib, (size_t)P.Cin, P.Cin - ib, dys, DS, TR, 0, rows, Qi, nullptr,
+                               nullptr, 0, tid, NTHREADS);
+      __syncthreads();
+
+      // ---- dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM ----
+      for (int idx = tid; idx < rows * Qi; idx += NTHREADS) {
+        const int r = idx / Qi, q = idx - r * Qi;
+        const int i0 = ib + q * EPL;
+        if (i0 >= P.Cin) continue;
+        const int f = row_f[r], v = row_v[r];
+        float sum[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
+        const int e1 = min(r_off[v + 1], P.nnz_cap);
+        for (int en = r_off[v]; en < e1; ++en) {
+          const int kw = r_kw[en];
+          const int k = kw / V, w = kw - k * V;
+          const float a = r_a[en];
+          const frag_t dv = *reinterpret_cast<const frag_t*>(dxa + (k * TR + f * V + w) * CCi + q * EPL);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(dv[e]);
+        }
+        const size_t g = (pos0 + r) * P.Cin + i0;
+        if (VEC) {
+          frag_t o;
+          if (addg) {
+            const frag_t av = *reinterpret_cast<const frag_t*>(addg + g);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sum[e] += E::to_f(av[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
+          *reinterpret_cast<frag_t*>(dxg + g) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            if (i0 + e < P.Cin) {
+              float fv = sum[e];
+              if (addg) fv += E::to_f(addg[g + e]);
+              dxg[g + e] = E::from_f(fv);
+            }
+          }
+        }
+      }
+      // ---- adjacency gradient on the pattern ----
+      if (P.dA) {
+        for (int idx = tid; idx < nnz * nf; idx += NTHREADS) {
+          const int en = idx / nf, f = idx - en * nf;
+          const int kw = r_kw[en];
+          const int k = kw / V, w = kw - k * V;
+          const T* xr = dys + (f * V + r_v[en]) * DS;
+          const T* dr = dxa + (k * TR + f * V + w) * CCi;
+          float s = 0.f;
+          for (int q = 0; q < Qi; ++q) {
+            const frag_t a = *reinterpret_cast<const frag_t*>(xr + q * EPL);
+            const frag_t b = *reinterpret_cast<const frag_t*>(dr + q * EPL);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+          }
+          atomicAdd(&dacc[en], s);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  if (P.dA) {
+    __syncthreads();
+    for (int en = tid; en < nnz; en += NTHREADS) {
+      const int kw = r_kw[en];
+      const int k = kw / V, w = kw - k * V;
+      atomicAdd(P.dA + (k * V + r_v[en]) * V + w, dacc[en]);
+    }
+  }
+}
+
+struct GbdGeom { int CCi, nchi, CCc, nchc, NKGc, KKp, MTK; };
+
+inline void gbd_geom(int Cin, int Cout, int K, int dtype, GbdGeom* G) {
+  const int epl = dtype == 0 ? 4 : 8, cc = dtype == 0 ? 32 : 64, kgs = 2 * epl;
+  G->CCi = Cin >= cc ? cc : round_up(Cin, epl);
+  G->nchi = ceil_div(Cin, G->CCi);
+  G->CCc = Cout >= cc ? cc : round_up(Cout, kgs);
+  G->nchc = ceil_div(Cout, G->CCc);
+  G->NKGc = G->CCc / kgs;
+  G->KKp = round_up(K * G->CCi, 32);
+  G->MTK = G->KKp / 32;
+}
+
+template <typename T, int MTK>
+int launch_mtk(GbdParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+  const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
+#define GO(VV)                                                                                              \
+  do {                                                                                                      \
+    auto kfn = gcn_bwd_kernel<T, MTK, VV>;                                                                  \
+    static bool attr_done = false;                                                                          \
+    if (!attr_done) {                                                                                       \
+      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ea_ != hipSuccess) return 2000 + (int)ea_;                                                        \
+      attr_done = true;                                                                                     \
+    }                                                                                                       \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                               \
+  } while (0)
+  if (vec) GO(true); else GO(false);
+#undef GO
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+template <typename T>
+int launch_T(GbdParams& P, const GbdGeom& G, int grid_cap, hipStream_t stream) {
+  const int esz = sizeof(T), epl = Elem<T>::EPL;
+  P.CCi = G.CCi; P.nchi = G.nchi; P.CCc = G.CCc; P.nchc = G.nchc; P.NKGc = G.NKGc;
+  P.F = TR / P.V;
+  P.tiles_per_seq = ceil_div(P.T, P.F);
+  P.total_tiles = P.NM * P.tiles_per_seq;
+  const int wide = P.CCc > P.CCi ? P.CCc : P.CCi;
+  P.ds_stride = wide + epl;
+  size_t off = (size_t)(P.V + 1) * 4;
+  off = (off + 15) & ~(size_t)15; P.off_rv = (int)off; off += P.nnz_cap;
+  off = (off + 15) & ~(size_t)15; P.off_rkw = (int)off; off += (size_t)P.nnz_cap * 2;
+  off = (off + 15) & ~(size_t)15; P.off_ra = (int)off; off += (size_t)P.nnz_cap * 4;
+  off = (off + 15) & ~(size_t)15; P.off_dacc = (int)off; off += (size_t)P.nnz_cap * 4;
+  off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TR;
+  off = (off + 15) & ~(size_t)15; P.off_dys = (int)off; off += (size_t)TR * P.ds_stride * esz;
+  off = (off + 15) & ~(size_t)15; P.off_dxa = (int)off;
+  size_t dxa = (size_t)P.K * TR * P.CCi * esz, al = (size_t)P.K * P.V * P.V * 4;
+  off += dxa > al ? dxa : al;
+  if (off > 160 * 1024) return ISTGCN_EINVAL;
+  int gx = P.total_tiles < grid_cap ? P.total_tiles : grid_cap;
+  dim3 grid(gx);
+  switch (G.MTK) {
+    case 1: return launch_mtk<T, 1>(P, grid, off, stream);
+    case 2: return launch_mtk<T, 2>(P, grid, off, stream);
+    case 3: return launch_mtk<T, 3>(P, grid, off, stream);
+    case 4: return launch_mtk<T, 4>(P, grid, off, stream);
+    case 5: return launch_mtk<T, 5>(P, grid, off, stream);
+    case 6: return launch_mtk<T, 6>(P, grid, off, stream);
+    case 7: return launch_mtk<T, 7>(P, grid, off, stream);
+    case 8: return launch_mtk<T, 8>(P, grid, off, stream);
+    default: return ISTGCN_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc,
+                                       int* KKp, int* EPL) {
+  if ((dtype != 0 && dtype != 1) || Cin < 1 || Cout < 1 || K < 1 || K > 4) return ISTGCN_EINVAL;
+  GbdGeom G;
+  gbd_geom(Cin, Cout, K, dtype, &G);
+  *CCi = G.CCi; *nchi = G.nchi; *CCc = G.CCc; *nchc = G.nchc; *KKp = G.KKp; *EPL = dtype == 0 ? 4 : 8;
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const void* Wb, const void* addend,
+                                   void* dx, float* dA, int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap,
+                                   int dtype, int grid_cap, void* stream) {
+  if (!dy || !A || !Wb || !dx) return ISTGCN_EINVAL;
+  if (dA && !x) return ISTGCN_EINVAL;
+  if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
+  if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
+  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (NM == 0 || T == 0) return ISTGCN_OK;
+  GbdParams P{};
+  P.dy = dy; P.x = x; P.A = A; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
+  P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;
+  GbdGeom G;
+  gbd_geom(Cin, Cout, K, dtype, &G);
+  if (grid_cap < 1) grid_cap = 1024;
+  if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
+  return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
+}

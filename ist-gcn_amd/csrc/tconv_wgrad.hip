@@ -27,6 +27,10 @@ struct TwgParams {
   const float* pre;      // [2][Cin] or null
   float* dW;             // [ntaps][Cout][Cin] fp32, caller-zeroed
   float* dbias;          // [Cout] or null
+  // graph-conv mode (AGG): the "taps" are the K adjacency partitions, u_k = sum_v A[k][v][w] x[(t,v)][:]
+  const float* A;        // [K][V][V]
+  float* S;              // [V][Cout] or null: sum_{n,t} dz[n,t,w,c]
+  int nnz_cap, off_csr_v, off_csr_a, off_S;
   int NM, Tin, Tz, V, Cin, Cout, ntaps, in_mul, pre_relu;
   int tap_off[MAX_TAPS];
   int F, tiles_per_seq, total_tiles, min_off, Fin, n_iblk, urows;
@@ -98,7 +102,7 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
   }
 }
 
-template <typename T, int JT, int OT, int IT, int PS>
+template <typename T, int JT, int OT, int IT, int PS, bool AGG>
 __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P) {
   static_assert(OT * IT * PS == 4, "one (o-tile, i-tile, position-slice) per wave");
   using E = Elem<T>;
@@ -110,6 +114,11 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   unsigned short* urow = reinterpret_cast<unsigned short*>(smem + P.off_urow);    // [TR] u-tile row at tap offset 0
   T* dzs = reinterpret_cast<T*>(smem + P.off_dz);                                 // [OT][TR][CB]
   T* us = reinterpret_cast<T*>(smem + P.off_u);                                   // [IT][urows][CB]
+  // AGG only: adjacency column lists (column = k*V + w -> entries (v, a)), S accumulators; x is staged in the dz region
+  int* csr_off = reinterpret_cast<int*>(smem + P.off_urow);                       // [K*V+1] (aliases urow: unused in AGG)
+  unsigned char* csr_v = smem + P.off_csr_v;
+  float* csr_a = reinterpret_cast<float*>(smem + P.off_csr_a);
+  float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][OT*CB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V;
@@ -124,6 +133,37 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     row_f[r] = (unsigned short)f;
     row_v[r] = (unsigned short)(r - f * V);
   }
+  if constexpr (AGG) {
+    // adjacency -> LDS (coalesced), then per-column compressed lists
+    const int K = P.ntaps, KV = K * V;
+    float* A_l = reinterpret_cast<float*>(us);
+    for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = P.A[i];
+    for (int c = tid; c <= KV; c += NTHREADS) csr_off[c] = 0;
+    for (int c = tid; c < V * OT * CB; c += NTHREADS) S_l[c] = 0.f;
+    __syncthreads();
+    for (int col = tid; col < KV; col += NTHREADS) {
+      int k = col / V, w = col - k * V, cnt = 0;
+      for (int v = 0; v < V; ++v) cnt += (A_l[(k * V + v) * V + w] != 0.f);
+      csr_off[col + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int c = 0; c < KV; ++c) { int nn = csr_off[c + 1]; csr_off[c] = run; run += nn; }
+      csr_off[KV] = run;
+    }
+    __syncthreads();
+    for (int col = tid; col < KV; col += NTHREADS) {
+      int k = col / V, w = col - k * V, e = csr_off[col];
+      for (int v = 0; v < V; ++v) {
+        float a = A_l[(k * V + v) * V + w];
+        if (a != 0.f) {
+          if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
+          ++e;
+        }
+      }
+    }
+  }
   __syncthreads();
 
   f32x16 acc[JT];
@@ -136,12 +176,14 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   // per-tap element offset into a u sub-tile (taps beyond ntaps alias tap 0: computed, never flushed)
   int toff[JT];
 #pragma unroll
-  for (int j = 0; j < JT; ++j) toff[j] = (P.tap_off[j] - P.min_off) * V * CB;
+  for (int j = 0; j < JT; ++j) toff[j] = AGG ? (j < P.ntaps ? j : 0) * TR * CB : (P.tap_off[j] - P.min_off) * V * CB;
 
   const T* dzg = reinterpret_cast<const T*>(P.dz);
   const T* gg = reinterpret_cast<const T*>(P.g);
   const T* dz_w = dzs + ot * (TR * CB);
   const T* us_w = us + it * u_sub;
+  typedef typename E::frag frag_t;
+  constexpr int QV = CB / EPL;
 
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int n = tile / P.tiles_per_seq;
@@ -151,27 +193,80 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     const int fin0 = P.in_mul * m0 + P.min_off;
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;
 
+    if constexpr (AGG) {
+      // ---- x tile -> dz region, K aggregated images -> us, then the dz tile over the x tile ----
+      const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
+      {
+        const T* src = gg + pos0 * P.Cin + i0;
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid);
+      }
+      __syncthreads();
+      const int K = P.ntaps;
+      for (int idx = tid; idx < IT * K * TR * QV; idx += NTHREADS) {
+        const int q = idx % QV;
+        const int r = (idx / QV) % TR;
+        const int sk = idx / (QV * TR);            // = sub * K + k
+        const int sub = sk / K, k = sk - sub * K;
+        float sum[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
+        if (r < rows) {
+          const int f = row_f[r], col = k * V + row_v[r];
+          const int e1 = min(csr_off[col + 1], P.nnz_cap);
+          const T* xs_sub = dzs + sub * (TR * CB) + q * EPL;
+          for (int en = csr_off[col]; en < e1; ++en) {
+            const float a = csr_a[en];
+            const frag_t xv = *reinterpret_cast<const frag_t*>(xs_sub + (f * V + csr_v[en]) * CB);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(xv[e]);
+          }
+        }
+        frag_t o;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
+        *reinterpret_cast<frag_t*>(us + (sk * TR + r) * CB + q * EPL) = o;
+      }
+      __syncthreads();
+      {
+        const T* src = dzg + pos0 * P.Cout + o0;
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+      }
+      __syncthreads();
+      if (P.S && iblk == 0) {
+        constexpr int NC = OT * CB;
+        for (int idx = tid; idx < V * NC; idx += NTHREADS) {
+          const int w = idx / NC, c = idx - w * NC;
+          const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
+          float sacc = 0.f;
+          for (int f = 0; f < nf; ++f) sacc += E::to_f(col[(f * V + w) * CB]);
+          S_l[idx] += sacc;
+        }
+      }
+    } else {
     // ---- stage dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
-    {
-      const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
-      if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
-      else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+      {
+        const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+      }
+      for (int r = tid; r < TR; r += NTHREADS)
+        urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
+      {
+        const long long row0 = (long long)(n * P.Tin + fin0) * V;
+        const int r_lo = fin0 < 0 ? -fin0 * V : 0;
+        const int r_hi = min(in_rows, (P.Tin - fin0) * V);
+        const float* sc = P.pre ? P.pre + i0 : nullptr;
+        const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
+        const T* src = gg + row0 * P.Cin + i0;
+        if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
+        else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
+      }
+      __syncthreads();
+  
     }
-    for (int r = tid; r < TR; r += NTHREADS)
-      urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
-    {
-      const long long row0 = (long long)(n * P.Tin + fin0) * V;
-      const int r_lo = fin0 < 0 ? -fin0 * V : 0;
-      const int r_hi = min(in_rows, (P.Tin - fin0) * V);
-      const float* sc = P.pre ? P.pre + i0 : nullptr;
-      const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
-      const T* src = gg + row0 * P.Cin + i0;
-      if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
-      else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
-    }
-    __syncthreads();
-
-    if (P.dbias && iblk == 0) {
+    if (!AGG && P.dbias && iblk == 0) {
       constexpr int NC = OT * CB;
       const int c = tid % NC;
       const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
@@ -187,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       auto load_k = [&](int kk, float& a, float (&b)[JT]) {
         const int p = pbase + 2 * kk + h;
         a = dz_w[p * CB + r];
-        const T* ub = us_w + urow[p] * CB + r;
+        const T* ub = us_w + (AGG ? p : (int)urow[p]) * CB + r;
 #pragma unroll
         for (int j = 0; j < JT; ++j) b[j] = ub[toff[j]];
       };
@@ -216,8 +311,8 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       for (int kk = 0; kk < NK; ++kk) {
         const int pb = pbase + 16 * kk + 8 * h + q;          // this lane addresses rows pb and pb+4 of its 8 positions
         a = tr_pair(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
-        const T* u0 = us_w + urow[pb] * CB + coff;
-        const T* u1 = us_w + urow[pb + 4] * CB + coff;
+        const T* u0 = us_w + (AGG ? pb : (int)urow[pb]) * CB + coff;
+        const T* u1 = us_w + (AGG ? pb + 4 : (int)urow[pb + 4]) * CB + coff;
 #pragma unroll
         for (int j = 0; j < JT; ++j) b[j] = tr_pair(u0 + toff[j], u1 + toff[j]);
 #pragma unroll
@@ -238,7 +333,14 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       }
     }
   }
-  if (P.dbias && iblk == 0) {
+  if (AGG && P.S && iblk == 0) {
+    constexpr int NC = OT * CB;
+    for (int idx = tid; idx < V * NC; idx += NTHREADS) {
+      const int w = idx / NC, c = idx - w * NC;
+      if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[idx]);
+    }
+  }
+  if (!AGG && P.dbias && iblk == 0) {
     constexpr int NC = OT * CB;
     if (NC == 32) bsum += __shfl_xor(bsum, 32);
     const int c = tid % NC;
@@ -246,15 +348,21 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   }
 }
 
-template <typename T, int JT, int OT, int IT, int PS>
+template <typename T, int JT, int OT, int IT, int PS, bool AGG>
 int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
   const int esz = sizeof(T);
   P.n_iblk = ceil_div(P.Cin, IT * CB);
   const int n_oblk = ceil_div(P.Cout, OT * CB);
-  P.urows = P.Fin * P.V;
+  P.urows = AGG ? P.ntaps * TR : P.Fin * P.V;
   size_t off = (size_t)2 * TR * 2;
-  off = (off + 15) & ~(size_t)15; P.off_urow = (int)off; off += (size_t)TR * 2;
-  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)OT * TR * CB * esz;
+  off = (off + 15) & ~(size_t)15; P.off_urow = (int)off;
+  off += AGG ? (size_t)(P.ntaps * P.V + 1) * 4 : (size_t)TR * 2;
+  if (AGG) {
+    off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
+    off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
+    off = (off + 15) & ~(size_t)15; P.off_S = (int)off; off += (size_t)P.V * OT * CB * 4;
+  }
+  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)(AGG && IT > OT ? IT : OT) * TR * CB * esz;
   off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)IT * P.urows * CB * esz;
   if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
   const int blocks = n_oblk * P.n_iblk;
@@ -262,7 +370,7 @@ int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   dim3 grid(gx, blocks);
-  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS>;
+  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -274,15 +382,15 @@ int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
   return ISTGCN_OK;
 }
 
-template <typename T, int JT>
+template <typename T, int JT, bool AGG>
 int launch_JT(TwgParams& P, int grid_cap, hipStream_t stream) {
   // channel block per workgroup: as wide as the layer and LDS allow (fewer redundant reads of dz / g, more MFMA work
   // per staged byte); narrow layers fall back to one 32x32 pair split four ways over positions.
   if constexpr (sizeof(T) == 2) {
-    if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 1>(P, grid_cap, stream);
+    if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 1, AGG>(P, grid_cap, stream);
   }
-  if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 2>(P, grid_cap, stream);
-  return launch_cfg<T, JT, 1, 1, 4>(P, grid_cap, stream);
+  if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 2, AGG>(P, grid_cap, stream);
+  return launch_cfg<T, JT, 1, 1, 4, AGG>(P, grid_cap, stream);
 }
 
 template <typename T>
@@ -294,10 +402,22 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.Fin = P.in_mul * (P.F - 1) + (mx - mn) + 1;
   P.tiles_per_seq = ceil_div(P.Tz, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  if (P.ntaps <= 1) return launch_JT<T, 1>(P, grid_cap, stream);
-  if (P.ntaps <= 3) return launch_JT<T, 3>(P, grid_cap, stream);
-  if (P.ntaps <= 9) return launch_JT<T, 9>(P, grid_cap, stream);
-  return launch_JT<T, 15>(P, grid_cap, stream);
+  if (P.ntaps <= 1) return launch_JT<T, 1, false>(P, grid_cap, stream);
+  if (P.ntaps <= 3) return launch_JT<T, 3, false>(P, grid_cap, stream);
+  if (P.ntaps <= 9) return launch_JT<T, 9, false>(P, grid_cap, stream);
+  return launch_JT<T, 15, false>(P, grid_cap, stream);
+}
+
+template <typename T>
+int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
+  P.min_off = 0;
+  P.F = TR / P.V;
+  P.Fin = P.F;
+  P.tiles_per_seq = ceil_div(P.Tz, P.F);
+  P.total_tiles = P.NM * P.tiles_per_seq;
+  if (P.ntaps <= 1) return launch_JT<T, 1, true>(P, grid_cap, stream);
+  if (P.ntaps <= 3) return launch_JT<T, 3, true>(P, grid_cap, stream);
+  return launch_JT<T, 4, true>(P, grid_cap, stream);
 }
 
 }  // namespace
@@ -319,4 +439,20 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
+}
+
+// Graph-conv weight gradient: same kernel, the K "taps" being the K adjacency partitions (aggregated images of x).
+extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,
+                                int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
+  if (!dy || !x || !A || !dW) return ISTGCN_EINVAL;
+  if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
+  if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
+  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (NM == 0 || T == 0) return ISTGCN_OK;
+  TwgParams P{};
+  P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
+  P.NM = NM; P.Tin = T; P.Tz = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = K; P.in_mul = 1;
+  if (grid_cap < 1) grid_cap = 1024;
+  if (dtype == 0) return launch_agg_T<float>(P, grid_cap, (hipStream_t)stream);
+  return launch_agg_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }

@@ -99,12 +99,10 @@ class GraphConvFn(torch.autograd.Function):
         K, cout, cin = W3.shape
         dy = dy.contiguous()
         need_A = ctx.needs_input_grad[1]
-        dW, dA, S = ops.gcn_wgrad(dy, x, A_eff, W3 if need_A else None, want_dA=need_A, want_S=ctx.has_b,
-                                  nnz_cap=ctx.nnz_cap)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wt = ops.pack_gcn_weight(W3.permute(2, 0, 1), dy.dtype)          # W'[i][k][c]
-            dx = ops.gcn_forward(dy, A_eff.transpose(1, 2).contiguous(), wt, cin, nnz_cap=ctx.nnz_cap)
+        dW, S = ops.gcn_wgrad(dy, x, A_eff, want_S=ctx.has_b, nnz_cap=ctx.nnz_cap)
+        dx = dA = None
+        if ctx.needs_input_grad[0] or need_A:
+            dx, dA = ops.gcn_bwd_data(dy, A_eff, W3, x=x, want_dA=need_A, nnz_cap=ctx.nnz_cap)
         return dx, dA, (S if ctx.has_b else None), dW, None
 
 
@@ -221,14 +219,12 @@ class STGCNBlockFn(torch.autograd.Function):
         dg = ops.affine2(d1, g, abc1)
         # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in
         need_A = ctx.needs_input_grad[5]
-        dWg, dA, S = ops.gcn_wgrad(dg, x, A_eff, Wg3 if need_A else None, want_dA=need_A, want_S=ctx.has_b,
-                                   nnz_cap=cfg.nnz_cap)
+        dWg, S = ops.gcn_wgrad(dg, x, A_eff, want_S=ctx.has_b, nnz_cap=cfg.nnz_cap)
         dWr = dbr = dgr = dbetar = None
-        dx = None
-        if ctx.needs_input_grad[4] or cfg.residual == 'conv':
-            wt = ops.pack_gcn_weight(Wg3.permute(2, 0, 1), dt)
+        dx = dA = None
+        if ctx.needs_input_grad[4] or need_A or cfg.residual == 'conv':
             addend = dres if cfg.residual == 'id' else None
-            dx = ops.gcn_forward(dg, A_eff.transpose(1, 2).contiguous(), wt, cin, addend=addend, nnz_cap=cfg.nnz_cap)
+            dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cfg.nnz_cap)
         if cfg.residual == 'conv':
             abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training)
             dr = ops.affine2(dres, r, abcr)

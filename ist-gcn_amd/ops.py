@@ -201,40 +201,67 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
 
 
 # ----------------------------------------------------------------------------------------------
-# graph-conv parameter gradients (istgcn_gcn_wgrad)
+# graph-conv backward: istgcn_gcn_bwd_data (dx + dA) and istgcn_gcn_wgrad (dW + S)
 # ----------------------------------------------------------------------------------------------
-def pack_gcn_wq(w3, dtype):
-    """w3: [K][Cout][Cin] fp32 (the raw Conv2d weight viewed per partition) -> fragments of W^T for the dxa product:
-    element [ct][it][k][kg][h][r][e] = w3[k][32*ct + kg*2*EPL + h*EPL + e][32*it + r]."""
+def gcn_bwd_geometry(cin, cout, K, dt):
+    vals = [ctypes.c_int() for _ in range(6)]
+    _call('istgcn_gcn_bwd_geometry', cin, cout, K, dt, *[ctypes.byref(v) for v in vals])
+    return tuple(v.value for v in vals)  # CCi, nchi, CCc, nchc, KKp, EPL
+
+
+def pack_gcn_wb(w3, dtype):
+    """w3: [K][Cout][Cin] fp32 -> fragments [nchi][nchc][NKGc][MTK][2][32][EPL] of the dxa product:
+    row kk = k*CCi + (i - ich*CCi) (zero padded to KKp), contraction index c = cch*CCc + kg*2*EPL + h*EPL + e."""
     K, cout, cin = w3.shape
-    epl = 4 if dtype == torch.float32 else 8
-    nct, nit = (cout + 31) // 32, (cin + 31) // 32
-    w = F.pad(w3, (0, nit * 32 - cin, 0, nct * 32 - cout))
-    w = w.reshape(K, nct, 32 // (2 * epl), 2, epl, nit, 32).permute(1, 5, 0, 2, 3, 6, 4)
+    cci, nchi, ccc, nchc, kkp, epl = gcn_bwd_geometry(cin, cout, K, _DT[dtype])
+    w = F.pad(w3.permute(2, 0, 1), (0, nchc * ccc - cout, 0, 0, 0, nchi * cci - cin))      # [Cin_p][K][Cout_p]
+    w = w.reshape(nchi, cci, K, nchc, ccc).permute(0, 2, 1, 3, 4).reshape(nchi, K * cci, nchc, ccc)
+    w = F.pad(w, (0, 0, 0, 0, 0, kkp - K * cci))
+    nkg = ccc // (2 * epl)
+    w = w.reshape(nchi, kkp // 32, 32, nchc, nkg, 2, epl).permute(0, 3, 4, 1, 5, 2, 6)
     return w.to(dtype).contiguous()
 
 
-def gcn_wgrad(dy, x, A, w3=None, want_dA=True, want_S=True, nnz_cap=None, grid_cap=0):
-    """istgcn_gcn_wgrad -> (dW [K][Cout][Cin], dA [K][V][V] or None, S [V][Cout] or None), all fp32."""
+def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0):
+    """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None)."""
+    NM, T, V, Cout = dy.shape
+    K, cout2, Cin = w3.shape
+    assert cout2 == Cout and A.shape == (K, V, V) and A.dtype == torch.float32
+    dev = dy.device
+    dx = torch.empty((NM, T, V, Cin), dtype=dy.dtype, device=dev)
+    dA = None
+    if want_dA:
+        assert x is not None and x.shape == dx.shape and x.dtype == dy.dtype
+        dA = torch.zeros((K, V, V), dtype=torch.float32, device=dev)
+    if addend is not None:
+        assert addend.shape == dx.shape and addend.dtype == dy.dtype
+    wb = pack_gcn_wb(w3, dy.dtype)
+    if nnz_cap is None:
+        nnz_cap = K * V * V
+    _check_dev(dy, x, A, wb, addend, dx, dA)
+    _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(wb), _ptr(addend), _ptr(dx),
+          _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
+          work=(2.0 * NM * T * V * Cout * K * Cin + 2.0 * NM * T * V * V * K * Cin,
+                float(NM * T * V) * (Cout + Cin * (1 + (1 if want_dA else 0) + (1 if addend is not None else 0))) * _esz(dy)))
+    return dx, dA
+
+
+def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0):
+    """istgcn_gcn_wgrad -> (dW [K][Cout][Cin] fp32, S [V][Cout] fp32 or None)."""
     NM, T, V, Cout = dy.shape
     Cin = x.shape[3]
     K = A.shape[0]
     assert x.shape[:3] == dy.shape[:3] and x.dtype == dy.dtype and A.shape == (K, V, V)
     dev = dy.device
     dW = torch.zeros((K, Cout, Cin), dtype=torch.float32, device=dev)
-    dA = torch.zeros((K, V, V), dtype=torch.float32, device=dev) if want_dA else None
     S = torch.zeros((V, Cout), dtype=torch.float32, device=dev) if want_S else None
-    wq = None
-    if want_dA:
-        assert w3 is not None and w3.shape == (K, Cout, Cin)
-        wq = pack_gcn_wq(w3, dy.dtype)
     if nnz_cap is None:
         nnz_cap = K * V * V
-    _check_dev(dy, x, A, wq, dW, dA, S)
-    _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(wq), _ptr(dW), _ptr(dA), _ptr(S), NM, T, V, Cin, Cout,
-          K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
-          work=((2.0 if want_dA else 1.0) * 2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)))
-    return dW, dA, S
+    _check_dev(dy, x, A, dW, S)
+    _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(dW), _ptr(S), NM, T, V, Cin, Cout, K, int(nnz_cap),
+          dtype_code(dy), grid_cap, _stream(dy),
+          work=(2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)))
+    return dW, S
 
 
 # ----------------------------------------------------------------------------------------------

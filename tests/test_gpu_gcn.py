@@ -198,10 +198,13 @@ def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
     if dt == torch.bfloat16:
         xin, rin = x.bfloat16().float(), r.bfloat16().float()
     w3 = W.view(K, cout, cin).contiguous().to(d)
-    dW, dA, S = ops.gcn_wgrad(to_ntvc(rin).to(d, dt), to_ntvc(xin).to(d, dt), Aeff.detach().to(d).contiguous(), w3,
-                              nnz_cap=int((Aeff != 0).sum()))
+    cap = int((Aeff != 0).sum())
+    dyg, xg, Ag = to_ntvc(rin).to(d, dt), to_ntvc(xin).to(d, dt), Aeff.detach().to(d).contiguous()
+    dW, S = ops.gcn_wgrad(dyg, xg, Ag, nnz_cap=cap)
+    dx2, dA = ops.gcn_bwd_data(dyg, Ag, w3, x=xg, nnz_cap=cap)
     torch.cuda.synchronize()
     dW, dA, S = dW.cpu(), dA.cpu(), S.cpu()
+    assert diag('gcnbwd_%s_c%d_%s_dx' % (unit, ci, str(dt)[6:]), to_nctv(dx2.float()), g[b + unit + '.dx'], TOL[dt]) < TOL[dt]
     tol = 3e-5 if dt == torch.float32 else 1e-2
     name = 'gcnwg_%s_c%d_%s' % (unit, ci, str(dt)[6:])
     assert diag(name + '_dW', dW.view(K * cout, cin, 1, 1), g[b + unit + '.dW'], tol) < tol
@@ -236,9 +239,19 @@ def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
     y = R.graph_einsum(torch.nn.functional.conv2d(x, W), A)
     y.backward(dy)
     d = dev()
-    dW, dA, S = ops.gcn_wgrad(to_ntvc(dy).to(d, dt), to_ntvc(x).to(d, dt), A.detach().to(d), W.detach().view(K, cout, cin).to(d),
-                              nnz_cap=int((A != 0).sum()))
+    cap = int((A != 0).sum())
+    dyg, xg = to_ntvc(dy).to(d, dt), to_ntvc(x).to(d, dt)
+    add = torch.randn(NM, cin, T, V, generator=gen)
+    if dt == torch.bfloat16:
+        add = add.bfloat16().float()
+    dW, S = ops.gcn_wgrad(dyg, xg, A.detach().to(d), nnz_cap=cap)
+    dx2, dA = ops.gcn_bwd_data(dyg, A.detach().to(d), W.detach().view(K, cout, cin).to(d), x=xg,
+                               addend=to_ntvc(add).to(d, dt), nnz_cap=cap)
     torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    R.graph_einsum(torch.nn.functional.conv2d(xr, W.detach()), A.detach()).backward(dy)
+    assert diag('gcnbwdrand_%s_%s_dx' % ('x'.join(map(str, shape[:6])), str(dt)[6:]), to_nctv(dx2.float()), xr.grad + add,
+                TOL[dt]) < TOL[dt]
     tol = 3e-5 if dt == torch.float32 else 1e-2
     name = 'gcnwgrand_%s_%s' % ('x'.join(map(str, shape[:6])), str(dt)[6:])
     assert diag(name + '_dW', dW.cpu().view_as(W), W.grad, tol) < tol
