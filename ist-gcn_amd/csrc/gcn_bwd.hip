@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   unsigned char* r_v = smem + P.off_rv;                                              // [cap] v of entry
   unsigned short* r_kw = reinterpret_cast<unsigned short*>(smem + P.off_rkw);        // [cap] k*V + w
   float* r_a = reinterpret_cast<float*>(smem + P.off_ra);                            // [cap]
-  float* dacc = reinterpret_cast<float*>(smem + P.off_dacc);                         // [cap]
+  int* r_ofs = reinterpret_cast<int*>(smem + P.off_dacc);                            // [cap] (k*TR + w)*CCi: dxa offset of entry
   unsigned char* row_f = smem + P.off_rows;                                          // [TR]
   unsigned char* row_v = row_f + TR;                                                 // [TR]
   T* dys = reinterpret_cast<T*>(smem + P.off_dys);                                   // [TR][ds_stride]  (later: x chunk)
@@ -57,7 +57,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   {
     float* A_l = reinterpret_cast<float*>(dxa);
     for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = P.A[i];
-    for (int c = tid; c < P.nnz_cap; c += NTHREADS) dacc[c] = 0.f;
     for (int r = tid; r < TR; r += NTHREADS) {
       int f = r / V;
       row_f[r] = (unsigned char)f;
@@ -84,7 +83,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         for (int w = 0; w < V; ++w) {
           const float a = A_l[(k * V + tid) * V + w];
           if (a != 0.f) {
-            if (e < P.nnz_cap) { r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = a; }
+            if (e < P.nnz_cap) {
+              r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = a;
+              r_ofs[e] = (k * TR + w) * CCi;
+            }
             ++e;
           }
         }
@@ -92,6 +94,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
     __syncthreads();
   }
   const int nnz = min(r_off[V], P.nnz_cap);
+  constexpr int NPE = 16;                    // entries per thread: 16 * 256 >= K*V*V (checked on the host)
+  float dsum[NPE];
+#pragma unroll
+  for (int pe = 0; pe < NPE; ++pe) dsum[pe] = 0.f;
 
   const T* dyg = reinterpret_cast<const T*>(P.dy);
   const T* xg = reinterpret_cast<const T*>(P.x);
@@ -169,62 +175,70 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
                                nullptr, 0, tid, NTHREADS);
       __syncthreads();
 
-      // ---- dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM ----
-      for (int idx = tid; idx < rows * Qi; idx += NTHREADS) {
-        const int r = idx / Qi, q = idx - r * Qi;
-        const int i0 = ib + q * EPL;
-        if (i0 >= P.Cin) continue;
-        const int f = row_f[r], v = row_v[r];
-        float sum[EPL];
+      // ---- dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM.
+      //      Wave w owns joints v = w, w+4, ... (wave-uniform entry lists); lanes span (frame, channel vector). ----
+      {
+        const int npair = nf * Qi;
+        for (int v = wave; v < V; v += 4) {
+          const int e0 = r_off[v], e1 = min(r_off[v + 1], P.nnz_cap);
+          for (int pr = lane; pr < npair; pr += 64) {
+            const int f = pr / Qi, q = pr - f * Qi;
+            const int i0 = ib + q * EPL;
+            if (i0 >= P.Cin) continue;
+            float sum[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
-        const int e1 = min(r_off[v + 1], P.nnz_cap);
-        for (int en = r_off[v]; en < e1; ++en) {
-          const int kw = r_kw[en];
-          const int k = kw / V, w = kw - k * V;
-          const float a = r_a[en];
-          const frag_t dv = *reinterpret_cast<const frag_t*>(dxa + (k * TR + f * V + w) * CCi + q * EPL);
+            for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
+            const T* dbase = dxa + (f * V) * CCi + q * EPL;
+            for (int en = e0; en < e1; ++en) {
+              const float a = r_a[en];
+              const frag_t dv = *reinterpret_cast<const frag_t*>(dbase + r_ofs[en]);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(dv[e]);
-        }
-        const size_t g = (pos0 + r) * P.Cin + i0;
-        if (VEC) {
-          frag_t o;
-          if (addg) {
-            const frag_t av = *reinterpret_cast<const frag_t*>(addg + g);
+              for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(dv[e]);
+            }
+            const size_t g = (pos0 + f * V + v) * P.Cin + i0;
+            if (VEC) {
+              frag_t o;
+              if (addg) {
+                const frag_t av = *reinterpret_cast<const frag_t*>(addg + g);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) sum[e] += E::to_f(av[e]);
-          }
+                for (int e = 0; e < EPL; ++e) sum[e] += E::to_f(av[e]);
+              }
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
-          *reinterpret_cast<frag_t*>(dxg + g) = o;
-        } else {
+              for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
+              *reinterpret_cast<frag_t*>(dxg + g) = o;
+            } else {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            if (i0 + e < P.Cin) {
-              float fv = sum[e];
-              if (addg) fv += E::to_f(addg[g + e]);
-              dxg[g + e] = E::from_f(fv);
+              for (int e = 0; e < EPL; ++e) {
+                if (i0 + e < P.Cin) {
+                  float fv = sum[e];
+                  if (addg) fv += E::to_f(addg[g + e]);
+                  dxg[g + e] = E::from_f(fv);
+                }
+              }
             }
           }
         }
       }
-      // ---- adjacency gradient on the pattern ----
+      // ---- adjacency gradient on the pattern: thread t owns entries t, t+256, ... and keeps their sums in registers
+      //      across tiles and chunks (flushed once per workgroup) ----
       if (P.dA) {
-        for (int idx = tid; idx < nnz * nf; idx += NTHREADS) {
-          const int en = idx / nf, f = idx - en * nf;
-          const int kw = r_kw[en];
-          const int k = kw / V, w = kw - k * V;
-          const T* xr = dys + (f * V + r_v[en]) * DS;
-          const T* dr = dxa + (k * TR + f * V + w) * CCi;
-          float s = 0.f;
-          for (int q = 0; q < Qi; ++q) {
-            const frag_t a = *reinterpret_cast<const frag_t*>(xr + q * EPL);
-            const frag_t b = *reinterpret_cast<const frag_t*>(dr + q * EPL);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+        for (int pe = 0; pe < NPE; ++pe) {
+          const int en = tid + pe * NTHREADS;
+          if (en < nnz) {
+            const T* xr = dys + r_v[en] * DS;
+            const T* dr = dxa + r_ofs[en];
+            float s = 0.f;
+            for (int f = 0; f < nf; ++f) {
+              for (int q = 0; q < Qi; ++q) {
+                const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
+                const frag_t b = *reinterpret_cast<const frag_t*>(dr + (f * V) * CCi + q * EPL);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+              }
+            }
+            dsum[pe] += s;
           }
-          atomicAdd(&dacc[en], s);
         }
       }
       __syncthreads();
@@ -232,11 +246,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   }
 
   if (P.dA) {
-    __syncthreads();
-    for (int en = tid; en < nnz; en += NTHREADS) {
-      const int kw = r_kw[en];
-      const int k = kw / V, w = kw - k * V;
-      atomicAdd(P.dA + (k * V + r_v[en]) * V + w, dacc[en]);
+#pragma unroll
+    for (int pe = 0; pe < NPE; ++pe) {
+      const int en = tid + pe * NTHREADS;
+      if (en < nnz) {
+        const int kw = r_kw[en];
+        const int k = kw / V, w = kw - k * V;
+        atomicAdd(P.dA + (k * V + r_v[en]) * V + w, dsum[pe]);
+      }
     }
   }
 }
@@ -326,7 +343,7 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   if (!dy || !A || !Wb || !dx) return ISTGCN_EINVAL;
   if (dA && !x) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
-  if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
+  if (nnz_cap < 1 || nnz_cap > K * V * V || (dA && nnz_cap > 16 * NTHREADS)) return ISTGCN_EINVAL;
   if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
   GbdParams P{};

@@ -52,6 +52,8 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);         // [2][MT*32]
   unsigned char* row_f = smem + P.off_rows;                          // [128]
   unsigned char* row_w = row_f + TILE_ROWS;                          // [128]
+  unsigned char* col_k = row_w + TILE_ROWS;                          // [K*V]
+  unsigned char* col_w = col_k + P.K * P.V;                          // [K*V]
   T* xs = reinterpret_cast<T*>(smem + P.off_work);                   // [128][xs_stride]
   T* xa = xs + TILE_ROWS * P.xs_stride;                              // [128][xa_stride]
   T* outs = xs;                                                      // [128][out_stride] (aliases xs/xa)
@@ -75,6 +77,8 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
   __syncthreads();
   for (int col = tid; col < KV; col += NTHREADS) {
     int k = col / V, w = col - k * V, cnt = 0;
+    col_k[col] = (unsigned char)k;
+    col_w[col] = (unsigned char)w;
     for (int v = 0; v < V; ++v) cnt += (P.A[(k * V + v) * V + w] != 0.f);
     csr_off[col + 1] = cnt;
   }
@@ -98,22 +102,8 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
   }
   __syncthreads();
 
-  // aggregation thread map: 8 rows x 32 vector slots per pass; a thread owns <=2 vector slots
   const int Q = P.CCeff / EPL;            // channel vectors per partition
   const int NV = P.KKp / EPL;             // vectors per xa row (incl. zero padding)
-  const int a_slot = tid & 31;
-  const int a_row0 = tid >> 5;
-  int a_k[2], a_q[2];
-  bool a_on[2], a_real[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    int vq = a_slot + 32 * s;
-    a_on[s] = vq < NV;
-    a_real[s] = vq < K * Q;
-    a_k[s] = a_real[s] ? vq / Q : 0;
-    a_q[s] = a_real[s] ? vq - a_k[s] * Q : 0;
-  }
-
   const T* xg = reinterpret_cast<const T*>(P.x);
   const T* Wp = reinterpret_cast<const T*>(P.Wp);
   T* yg = reinterpret_cast<T*>(P.y);
@@ -155,29 +145,40 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
         }
       }
       __syncthreads();
-      // ---- sparse aggregation xs -> xa (all 128 rows written: pad rows / pad columns are zero) ----
-      for (int r = a_row0; r < TILE_ROWS; r += 8) {
-        const int f = row_f[r], w = row_w[r];
+      // ---- sparse aggregation xs -> xa.  Wave w owns adjacency columns col = w, w+4, ... (their compressed lists are
+      //      wave-uniform: no divergence, LDS broadcast reads); lanes span (frame, channel vector).  Rows >= rows are
+      //      never written: they only feed output rows that are never stored. ----
+      {
+        const int npair = nf * Q;
+        for (int col = wave; col < KV; col += 4) {
+          const int k = col_k[col], w = col_w[col];
+          const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
+          for (int pr = lane; pr < npair; pr += 64) {
+            const int f = pr / Q, q = pr - f * Q;
+            const T* xrow = xs + (f * V) * P.xs_stride + q * EPL;
+            float sum[EPL];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (!a_on[s]) continue;
-          float sum[EPL];
-#pragma unroll
-          for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
-          if (a_real[s] && r < rows) {
-            const int col = a_k[s] * V + w;
-            const int e1 = min(csr_off[col + 1], P.nnz_cap);
-            for (int e = csr_off[col]; e < e1; ++e) {
+            for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
+            for (int e = e0; e < e1; ++e) {
               const float a = csr_a[e];
-              const frag_t xv = *reinterpret_cast<const frag_t*>(xs + (f * V + csr_v[e]) * P.xs_stride + a_q[s] * EPL);
+              const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[e] * P.xs_stride);
 #pragma unroll
               for (int j = 0; j < EPL; ++j) sum[j] += a * E::to_f(xv[j]);
             }
-          }
-          frag_t o;
+            frag_t o;
 #pragma unroll
-          for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
-          *reinterpret_cast<frag_t*>(xa + r * P.xa_stride + (a_slot + 32 * s) * EPL) = o;
+            for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
+            *reinterpret_cast<frag_t*>(xa + (f * V + w) * P.xa_stride + k * P.CCeff + q * EPL) = o;
+          }
+        }
+        if (NV > K * Q) {          // contraction padding columns (tiny Cin only) must be finite: zero them
+          const int padv = NV - K * Q;
+          for (int idx = tid; idx < TILE_ROWS * padv; idx += NTHREADS) {
+            const int r = idx / padv, c = idx - r * padv;
+            frag_t o;
+            zero_frag<T>(o);
+            *reinterpret_cast<frag_t*>(xa + r * P.xa_stride + (K * Q + c) * EPL) = o;
+          }
         }
       }
       __syncthreads();
@@ -362,7 +363,7 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
   off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
   off = (off + 15) & ~(size_t)15; P.off_stat = (int)off; off += (size_t)2 * MT * 32 * 4;
-  off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TILE_ROWS;
+  off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TILE_ROWS + 2 * P.K * P.V;
   off = (off + 15) & ~(size_t)15; P.off_work = (int)off;
   size_t work = (size_t)TILE_ROWS * (P.xs_stride + P.xa_stride) * sizeof(T);
   size_t ost = (size_t)TILE_ROWS * P.out_stride * sizeof(T);

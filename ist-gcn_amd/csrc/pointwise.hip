@@ -136,15 +136,34 @@ __global__ void bn_bwd_coef_kernel(const double* stats, int rep, double count, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// In the element-wise kernels the grid stride (gridDim.x * 256 threads) is a multiple of the vectors per row whenever
+// QC divides 256, so a thread always lands on the same channel vector: its per-channel coefficients are loaded once
+// (`fixed_q`); otherwise they are re-read per element (the generic path for odd channel counts).
 template <typename T, int VW>
 __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const float* coef2, const T* res, const float* coefr,
                                                           T* out, size_t rows, int C, DropCfg D) {
   const int QC = C / VW;
   const size_t total = rows * QC;
+  const bool fixed_q = (NT % QC) == 0;
+  float s2[VW], b2[VW], sr[VW], br[VW];
+  if (fixed_q) {
+    const int c0 = (threadIdx.x % QC) * VW;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      s2[j] = coef2[c0 + j]; b2[j] = coef2[C + c0 + j];
+      sr[j] = coefr ? coefr[c0 + j] : 1.f; br[j] = coefr ? coefr[C + c0 + j] : 0.f;
+    }
+  }
   for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
-    const int q = (int)(idx % QC);
-    const int c0 = q * VW;
     const size_t e0 = idx * VW;
+    if (!fixed_q) {
+      const int c0 = (int)(idx % QC) * VW;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        s2[j] = coef2[c0 + j]; b2[j] = coef2[C + c0 + j];
+        sr[j] = coefr ? coefr[c0 + j] : 1.f; br[j] = coefr ? coefr[C + c0 + j] : 0.f;
+      }
+    }
     float zv[VW], rv[VW], m[VW];
     load_vec<T, VW>(z + e0, zv);
     if (res) load_vec<T, VW>(res + e0, rv);
@@ -157,9 +176,9 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
     }
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
-      float y = zv[j] * coef2[c0 + j] + coef2[C + c0 + j];
+      float y = zv[j] * s2[j] + b2[j];
       if (D.on) y *= m[j];
-      if (res) y += coefr ? rv[j] * coefr[c0 + j] + coefr[C + c0 + j] : rv[j];
+      if (res) y += rv[j] * sr[j] + br[j];
       zv[j] = fmaxf(y, 0.f);
     }
     store_vec<T, VW>(out + e0, zv);
@@ -176,9 +195,13 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
   const int q = threadIdx.x % QC;
   const int c0 = q * VW;
   const size_t rstep = (size_t)gridDim.x * (NT / QC);
-  float a1[VW], a2[VW], b1[VW], b2[VW];
+  float a1[VW], a2[VW], b1[VW], b2[VW], mz[VW], rz[VW], mr[VW], rr_[VW];
 #pragma unroll
-  for (int j = 0; j < VW; ++j) { a1[j] = a2[j] = b1[j] = b2[j] = 0.f; }
+  for (int j = 0; j < VW; ++j) {
+    a1[j] = a2[j] = b1[j] = b2[j] = 0.f;
+    mz[j] = coef2[2 * C + c0 + j]; rz[j] = coef2[3 * C + c0 + j];
+    mr[j] = r ? coefr[2 * C + c0 + j] : 0.f; rr_[j] = r ? coefr[3 * C + c0 + j] : 0.f;
+  }
   for (size_t row = (size_t)blockIdx.x * (NT / QC) + threadIdx.x / QC; row < rows; row += rstep) {
     const size_t e0 = row * C + c0;
     float dv[VW], ov[VW], zv[VW], rv[VW], m[VW];
@@ -199,10 +222,10 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
       dv[j] = d;
       const float dm = D.on ? d * m[j] : d;
       a1[j] += dm;
-      a2[j] += dm * (zv[j] - coef2[2 * C + c0 + j]) * coef2[3 * C + c0 + j];
+      a2[j] += dm * (zv[j] - mz[j]) * rz[j];
       if (r) {
         b1[j] += d;
-        b2[j] += d * (rv[j] - coefr[2 * C + c0 + j]) * coefr[3 * C + c0 + j];
+        b2[j] += d * (rv[j] - mr[j]) * rr_[j];
       }
     }
     store_vec<T, VW>(dres + e0, dv);
@@ -234,9 +257,20 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
                                                     DropCfg D) {
   const int QC = C / VW;
   const size_t total = rows * QC;
+  const bool fixed_q = (NT % QC) == 0;
+  float ca[VW], cb[VW], cc[VW];
+  if (fixed_q) {
+    const int c0 = (threadIdx.x % QC) * VW;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { ca[j] = abc[c0 + j]; cb[j] = abc[C + c0 + j]; cc[j] = abc[2 * C + c0 + j]; }
+  }
   for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
-    const int c0 = (int)(idx % QC) * VW;
     const size_t e0 = idx * VW;
+    if (!fixed_q) {
+      const int c0 = (int)(idx % QC) * VW;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) { ca[j] = abc[c0 + j]; cb[j] = abc[C + c0 + j]; cc[j] = abc[2 * C + c0 + j]; }
+    }
     float dv[VW], xv[VW], m[VW];
     load_vec<T, VW>(d + e0, dv);
     if (x) load_vec<T, VW>(x + e0, xv);
@@ -251,8 +285,8 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
     for (int j = 0; j < VW; ++j) {
       float v = dv[j];
       if (D.on) v *= m[j];
-      v = v * abc[c0 + j];
-      if (x) v += xv[j] * abc[C + c0 + j] + abc[2 * C + c0 + j];
+      v = v * ca[j];
+      if (x) v += xv[j] * cb[j] + cc[j];
       dv[j] = v;
     }
     store_vec<T, VW>(out + e0, dv);

@@ -202,30 +202,43 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
         else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid);
       }
       __syncthreads();
-      const int K = P.ntaps;
-      for (int idx = tid; idx < IT * K * TR * QV; idx += NTHREADS) {
-        const int q = idx % QV;
-        const int r = (idx / QV) % TR;
-        const int sk = idx / (QV * TR);            // = sub * K + k
-        const int sub = sk / K, k = sk - sub * K;
-        float sum[EPL];
+      const int K = P.ntaps, KV = K * V;
+      {
+        // wave w owns adjacency columns col = w, w+4, ...; lanes span (sub-tile, frame, channel vector)
+        const int npair = IT * nf * QV;
+        for (int col = wave; col < KV; col += 4) {
+          const int k = col / V, w = col - k * V;
+          const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
+          for (int pr = lane; pr < npair; pr += 64) {
+            const int q = pr % QV;
+            const int f = (pr / QV) % nf;
+            const int sub = pr / (QV * nf);
+            const T* xrow = dzs + sub * (TR * CB) + (f * V) * CB + q * EPL;
+            float sum[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
-        if (r < rows) {
-          const int f = row_f[r], col = k * V + row_v[r];
-          const int e1 = min(csr_off[col + 1], P.nnz_cap);
-          const T* xs_sub = dzs + sub * (TR * CB) + q * EPL;
-          for (int en = csr_off[col]; en < e1; ++en) {
-            const float a = csr_a[en];
-            const frag_t xv = *reinterpret_cast<const frag_t*>(xs_sub + (f * V + csr_v[en]) * CB);
+            for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
+            for (int en = e0; en < e1; ++en) {
+              const float a = csr_a[en];
+              const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[en] * CB);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(xv[e]);
+              for (int e = 0; e < EPL; ++e) sum[e] += a * E::to_f(xv[e]);
+            }
+            frag_t o;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
+            *reinterpret_cast<frag_t*>(us + ((sub * K + k) * TR + f * V + w) * CB + q * EPL) = o;
           }
         }
-        frag_t o;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
-        *reinterpret_cast<frag_t*>(us + (sk * TR + r) * CB + q * EPL) = o;
+        // positions >= rows are contracted too (against zero dz rows): keep their image rows finite (zero)
+        const int padr = TR - rows;
+        for (int idx = tid; idx < IT * K * padr * QV; idx += NTHREADS) {
+          const int q = idx % QV;
+          const int r = rows + (idx / QV) % padr;
+          const int sk = idx / (QV * padr);
+          frag_t o;
+          zero_frag<T>(o);
+          *reinterpret_cast<frag_t*>(us + (sk * TR + r) * CB + q * EPL) = o;
+        }
       }
       __syncthreads();
       {
