@@ -86,9 +86,64 @@ __device__ static inline void stage_block(const T* __restrict__ g, size_t gstrid
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   typedef typename E::frag frag_t;
-  const int tot = R * Q;
   const bool pow2 = (Q & (Q - 1)) == 0;
   const int lq = 31 - __builtin_clz(Q);
+  if (pow2 && Q <= nthreads) {
+    // a thread keeps one channel vector q and walks rows r0, r0+RS, ...: one add per item instead of a div/mod,
+    // and the per-channel affine lives in registers
+    const int q = tid & (Q - 1), r0 = tid >> lq, RS = nthreads >> lq;
+    const bool qlive = q * EPL < c_lim;
+    float scv[EPL], shv[EPL];
+    if (sc) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const bool in = VEC ? qlive : (q * EPL + e < c_lim);
+        scv[e] = in ? sc[q * EPL + e] : 0.f;
+        shv[e] = in ? sh[q * EPL + e] : 0.f;
+      }
+    }
+    const T* src = g + (size_t)r0 * gstride + q * EPL;
+    T* dst = lds + r0 * lstride + q * EPL;
+    const size_t gstep = (size_t)RS * gstride;
+    const int lstep = RS * lstride;
+    for (int r = r0; r < R; r += RS * U) {
+      frag_t v[U];
+      bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + u * RS;
+        live[u] = qlive && rr >= r_lo && rr < r_hi && rr < R;
+        zero_frag<T>(v[u]);
+        if (live[u]) {
+          if (VEC) v[u] = *reinterpret_cast<const frag_t*>(src + u * gstep);
+          else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[u * gstep + e];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r + u * RS < R) {
+          if (sc && live[u]) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              if (VEC || q * EPL + e < c_lim) {
+                float fv = E::to_f(v[u][e]) * scv[e] + shv[e];
+                if (relu) fv = fmaxf(fv, 0.f);
+                v[u][e] = E::from_f(fv);
+              }
+            }
+          }
+          *reinterpret_cast<frag_t*>(dst + u * lstep) = v[u];
+        }
+      }
+      src += (size_t)U * gstep;
+      dst += U * lstep;
+    }
+    return;
+  }
+  const int tot = R * Q;
   for (int base = tid; base < tot; base += nthreads * U) {
     frag_t v[U];
     int rr[U], qq[U];
@@ -96,8 +151,7 @@ __device__ static inline void stage_block(const T* __restrict__ g, size_t gstrid
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int it = base + u * nthreads;
-      int r, q;
-      if (pow2) { r = it >> lq; q = it & (Q - 1); } else { r = it / Q; q = it - r * Q; }
+      const int r = it / Q, q = it - r * Q;
       rr[u] = r; qq[u] = q;
       live[u] = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
       zero_frag<T>(v[u]);

@@ -31,8 +31,8 @@ struct GcnFwdParams {
   int nnz_cap, stats_rep;
   int F, tiles_per_seq, total_tiles;
   int CCeff, nch, KKp, NKG, MTtot;
-  int xs_stride, xa_stride, out_stride;   // in elements
-  int off_csr_v, off_csr_a, off_stat, off_rows, off_work;  // LDS byte offsets
+  int xs_stride, xa_stride, out_stride, xs_rows;   // in elements / rows
+  int off_csr_v, off_csr_a, off_stat, off_rows, off_afrag, off_work;  // LDS byte offsets
 };
 
 constexpr int TILE_ROWS = 128;
@@ -54,8 +54,9 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
   unsigned char* row_w = row_f + TILE_ROWS;                          // [128]
   unsigned char* col_k = row_w + TILE_ROWS;                          // [K*V]
   unsigned char* col_w = col_k + P.K * P.V;                          // [K*V]
-  T* xs = reinterpret_cast<T*>(smem + P.off_work);                   // [128][xs_stride]
-  T* xa = xs + TILE_ROWS * P.xs_stride;                              // [128][xa_stride]
+  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);               // bf16 only: [K][2][64][8] MFMA fragments of A_k
+  T* xs = reinterpret_cast<T*>(smem + P.off_work);                   // [xs_rows][xs_stride]
+  T* xa = xs + P.xs_rows * P.xs_stride;                              // [128][xa_stride]
   T* outs = xs;                                                      // [128][out_stride] (aliases xs/xa)
 
   const int tid = threadIdx.x;
@@ -102,12 +103,37 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
   }
   __syncthreads();
 
+  if constexpr (sizeof(T) == 2) {
+    // B-operand fragments of the adjacency for the MFMA aggregation: lane (w = lane&31, h = lane>>5), k-step s,
+    // element j holds A[k][v = 16s + 8h + j][w] (zero outside the V x V block)
+    for (int idx = tid; idx < K * 2 * 64; idx += NTHREADS) {
+      const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
+      const int w = ln & 31, h = ln >> 5;
+      frag_t fr;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        const int v = 16 * sstep + 8 * h + j;
+        fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
+      }
+      *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
+    }
+    __syncthreads();
+  }
   const int Q = P.CCeff / EPL;            // channel vectors per partition
   const int NV = P.KKp / EPL;             // vectors per xa row (incl. zero padding)
   const T* xg = reinterpret_cast<const T*>(P.x);
   const T* Wp = reinterpret_cast<const T*>(P.Wp);
   T* yg = reinterpret_cast<T*>(P.y);
   const T* addg = reinterpret_cast<const T*>(P.addend);
+
+  // BatchNorm partial sums: a thread always copies out the same channel vector, so it keeps its sums in registers for
+  // the whole grid-stride walk and the cross-lane reduction happens once per workgroup, not once per tile
+  constexpr int NPASS_ = (MT + 1) / 2;
+  float st1[NPASS_][EPL], st2[NPASS_][EPL];
+#pragma unroll
+  for (int ps = 0; ps < NPASS_; ++ps)
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { st1[ps][j] = 0.f; st2[ps][j] = 0.f; }
 
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int n = tile / P.tiles_per_seq;
@@ -145,32 +171,90 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
         }
       }
       __syncthreads();
-      // ---- sparse aggregation xs -> xa.  Wave w owns adjacency columns col = w, w+4, ... (their compressed lists are
-      //      wave-uniform: no divergence, LDS broadcast reads); lanes span (frame, channel vector).  Rows >= rows are
-      //      never written: they only feed output rows that are never stored. ----
-      {
-        const int npair = nf * Q;
-        for (int col = wave; col < KV; col += 4) {
-          const int k = col_k[col], w = col_w[col];
-          const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
-          for (int pr = lane; pr < npair; pr += 64) {
-            const int f = pr / Q, q = pr - f * Q;
-            const T* xrow = xs + (f * V) * P.xs_stride + q * EPL;
-            float sum[EPL];
+      bool agg_done = false;
+      if constexpr (sizeof(T) == 2) if (V <= 32) {
+        agg_done = true;
+        // ---- bf16: aggregation on the matrix cores.  Per (frame f, 32-channel tile ct): D[i][w] = sum_v x[(f,v)][i] *
+        //      A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows v beyond the frame
+        //      multiply zero adjacency rows), A_k fragments from LDS; the VALU version of this pass cost ~2500
+        //      instructions per wave and tile (conversions + addressing) against 24 MFMAs of real work. ----
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int CT = (P.CCeff + 31) >> 5;
+        const int npair = nf * CT;
+        const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
+        const int q4 = (lane & 15) >> 2, pp = lane & 3;
+        // the last frame's 32-row k-range reaches rows [rows, (nf-1)*V + 32): keep them finite (they meet zero adjacency)
+        const int zrows = (nf - 1) * V + 32 - rows, zq = P.xs_stride / EPL;
+        for (int idx = tid; idx < zrows * zq; idx += NTHREADS) {
+          frag_t z;
+          zero_frag<T>(z);
+          *reinterpret_cast<frag_t*>(xs + (rows + idx / zq) * P.xs_stride + (idx % zq) * EPL) = z;
+        }
+        __syncthreads();
+        for (int pr = wave; pr < npair; pr += 4) {
+          const int f = pr / CT, ct = pr - f * CT;
+          frag_t a[2];
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
-            for (int e = e0; e < e1; ++e) {
-              const float a = csr_a[e];
-              const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[e] * P.xs_stride);
+          for (int sstep = 0; sstep < 2; ++sstep) {
+            const T* r0 = xs + (f * V + 16 * sstep + 8 * h + q4) * P.xs_stride + ct * 32 + cblk + 4 * pp;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)r0);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * P.xs_stride));
+            bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+            a[sstep][0] = l4[0]; a[sstep][1] = l4[1]; a[sstep][2] = l4[2]; a[sstep][3] = l4[3];
+            a[sstep][4] = h4[0]; a[sstep][5] = h4[1]; a[sstep][6] = h4[2]; a[sstep][7] = h4[3];
+          }
+          const int w = lane & 31;
+          for (int k = 0; k < K; ++k) {
+            f32x16 d;
 #pragma unroll
-              for (int j = 0; j < EPL; ++j) sum[j] += a * E::to_f(xv[j]);
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            const frag_t b0 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
+            const frag_t b1 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
+            if (w < V) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int i0 = ct * 32 + 8 * g + 4 * (lane >> 5);
+                if (i0 < P.CCeff) {
+                  float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                  store4(xa + (f * V + w) * P.xa_stride + k * P.CCeff + i0, v4);
+                }
+              }
             }
-            frag_t o;
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
-            *reinterpret_cast<frag_t*>(xa + (f * V + w) * P.xa_stride + k * P.CCeff + q * EPL) = o;
           }
         }
+      }
+      if (!agg_done) {
+      // ---- sparse aggregation xs -> xa.  Wave w owns adjacency columns col = w, w+4, ... (their compressed lists are
+        //      wave-uniform: no divergence, LDS broadcast reads); lanes span (frame, channel vector).  Rows >= rows are
+        //      never written: they only feed output rows that are never stored. ----
+        {
+          const int npair = nf * Q;
+          for (int col = wave; col < KV; col += 4) {
+            const int k = col_k[col], w = col_w[col];
+            const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
+            for (int pr = lane; pr < npair; pr += 64) {
+              const int f = pr / Q, q = pr - f * Q;
+              const T* xrow = xs + (f * V) * P.xs_stride + q * EPL;
+              float sum[EPL];
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
+              for (int e = e0; e < e1; ++e) {
+                const float a = csr_a[e];
+                const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[e] * P.xs_stride);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) sum[j] += a * E::to_f(xv[j]);
+              }
+              frag_t o;
+#pragma unroll
+              for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
+              *reinterpret_cast<frag_t*>(xa + (f * V + w) * P.xa_stride + k * P.CCeff + q * EPL) = o;
+            }
+          }
+        }
+      }
+      {
         if (NV > K * Q) {          // contraction padding columns (tiny Cin only) must be finite: zero them
           const int padv = NV - K * Q;
           for (int idx = tid; idx < TILE_ROWS * padv; idx += NTHREADS) {
@@ -229,12 +313,16 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
             for (int g = 0; g < 4; ++g) {
               const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
               const int cg = cbase_blk + ps * 64 + cl;
-              float v4[4];
+              float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+              if (P.bterm && p < rows) {
+                const float* bsrc = P.bterm + w * P.Cout + cg;
+                if (VEC_OUT && cg + 3 < P.Cout) {
+                  const f32x4 bv = *reinterpret_cast<const f32x4*>(bsrc);
+                  v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
+                } else {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                float bv = 0.f;
-                if (P.bterm && p < rows && cg + j < P.Cout) bv = P.bterm[w * P.Cout + cg + j];
-                v4[j] = acc[m][4 * g + j] + bv;
+                  for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) v4[j] += bsrc[j];
+                }
               }
               store4(outs + p * P.out_stride + cl, v4);
             }
@@ -279,33 +367,30 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
             }
           }
         }
-        if (P.stats) {
-          // lanes that share a channel vector differ by multiples of VPR
 #pragma unroll
-          for (int j = 0; j < EPL; ++j) {
-#pragma unroll
-            for (int msk = VPR; msk < 64; msk <<= 1) {
-              s1[j] += __shfl_xor(s1[j], msk);
-              s2[j] += __shfl_xor(s2[j], msk);
-            }
-          }
-          if (lane < VPR && col_live) {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-              const int cl = ps * 64 + vq * EPL + j;
-              if (cbase_blk + cl < P.Cout) {
-                atomicAdd(&stat[cl], s1[j]);
-                atomicAdd(&stat[MT * 32 + cl], s2[j]);
-              }
-            }
-          }
-        }
+        for (int j = 0; j < EPL; ++j) { st1[ps][j] += s1[j]; st2[ps][j] += s2[j]; }
       }
       __syncthreads();
     }
   }
 
   if (P.stats) {
+    constexpr int VPR = 64 / EPL;
+    const int vq = tid % VPR;
+#pragma unroll
+    for (int ps = 0; ps < NPASS_; ++ps) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        float a = st1[ps][j], b = st2[ps][j];
+#pragma unroll
+        for (int msk = VPR; msk < 64; msk <<= 1) { a += __shfl_xor(a, msk); b += __shfl_xor(b, msk); }
+        const int cl = ps * 64 + vq * EPL + j;
+        if (lane < VPR && cl < MT * 32 && cbase_blk + cl < P.Cout) {
+          atomicAdd(&stat[cl], a);
+          atomicAdd(&stat[MT * 32 + cl], b);
+        }
+      }
+    }
     __syncthreads();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
     for (int c = tid; c < MT * 32; c += NTHREADS) {
@@ -356,7 +441,10 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   P.F = TILE_ROWS / P.V;
   P.tiles_per_seq = ceil_div(P.Tlog, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  P.xs_stride = P.CCeff + EPL;
+  const bool mfma_agg = sizeof(T) == 2 && P.V <= 32;
+  P.xs_stride = mfma_agg ? round_up(P.CCeff, 32) : P.CCeff + EPL;
+  P.xs_rows = mfma_agg ? (P.F - 1) * P.V + 32 : TILE_ROWS;
+  if (P.xs_rows < TILE_ROWS) P.xs_rows = TILE_ROWS;
   P.xa_stride = P.KKp + EPL;
   P.out_stride = 64 + EPL;
   size_t off = (size_t)(P.K * P.V + 1) * sizeof(int);
@@ -364,8 +452,9 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
   off = (off + 15) & ~(size_t)15; P.off_stat = (int)off; off += (size_t)2 * MT * 32 * 4;
   off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TILE_ROWS + 2 * P.K * P.V;
+  off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += sizeof(T) == 2 ? (size_t)P.K * 2 * 64 * 16 : 0;
   off = (off + 15) & ~(size_t)15; P.off_work = (int)off;
-  size_t work = (size_t)TILE_ROWS * (P.xs_stride + P.xa_stride) * sizeof(T);
+  size_t work = ((size_t)P.xs_rows * P.xs_stride + (size_t)TILE_ROWS * P.xa_stride) * sizeof(T);
   size_t ost = (size_t)TILE_ROWS * P.out_stride * sizeof(T);
   off += work > ost ? work : ost;
   if (off > 160 * 1024) return ISTGCN_EINVAL;

@@ -83,6 +83,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
   const int chunk = (P.total_tiles + 7) >> 3;
   const int xcd = blockIdx.x & 7;
 
+  // BatchNorm partial sums: a thread always copies out the same channel vector.  Where registers allow (small
+  // accumulator footprints) the sums stay in registers for the whole grid-stride walk and are reduced across lanes once
+  // per workgroup; the register-heavy instantiations reduce per tile instead.
+  constexpr bool REG_STATS = MT * NT < 8;
+  constexpr int NPASS_ = (MT + 1) / 2;
+  float st1[REG_STATS ? NPASS_ : 1][EPL], st2[REG_STATS ? NPASS_ : 1][EPL];
+#pragma unroll
+  for (int ps = 0; ps < (REG_STATS ? NPASS_ : 1); ++ps)
+#pragma unroll
+    for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] = 0.f; st2[ps][jj] = 0.f; }
+
   for (int slot = blockIdx.x >> 3; slot < chunk; slot += G8) {
     const int tile = xcd * chunk + slot;
     if (tile >= P.total_tiles) break;
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
         const long long row0 = (long long)(n * P.Tin + fin0) * V;
         const int r_lo = fin0 < 0 ? -fin0 * V : 0;
         const int r_hi = min(in_rows, (P.Tin - fin0) * V);
-        stage_block<T, 8, VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
+        stage_block<T, (MT * NT >= 8 ? 4 : 8), VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
                                Q, P.pre ? P.pre + cb : nullptr, P.pre ? P.pre + P.Cin + cb : nullptr, P.pre_relu, tid,
                                NTHREADS);
       }
@@ -180,11 +191,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
               for (int g = 0; g < 4; ++g) {
                 const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
                 const int cg = cbase_blk + ps * 64 + cl;
-                float v4[4];
+                float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
+                if (P.bias) {
+                  if (VEC && cg + 3 < P.Cout) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + cg);
+                    v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
+                  } else {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                  float bv = (P.bias && cg + jj < P.Cout) ? P.bias[cg + jj] : 0.f;
-                  v4[jj] = acc[m][t][4 * g + jj] + bv;
+                    for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) v4[jj] += P.bias[cg + jj];
+                  }
                 }
                 store4(outs + sr * P.out_stride + cl, v4);
               }
@@ -241,7 +256,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
               }
             }
           }
-          if (P.stats) {
+          if constexpr (REG_STATS) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] += s1[jj]; st2[ps][jj] += s2[jj]; }
+          } else if (P.stats) {
 #pragma unroll
             for (int jj = 0; jj < EPL; ++jj) {
 #pragma unroll
@@ -268,6 +286,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
   }
 
   if (P.stats) {
+    if constexpr (REG_STATS) {
+      constexpr int VPR = 64 / EPL;
+      const int vq = tid % VPR;
+#pragma unroll
+      for (int ps = 0; ps < NPASS_; ++ps) {
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+          float a = st1[ps][jj], b = st2[ps][jj];
+#pragma unroll
+          for (int msk = VPR; msk < 64; msk <<= 1) { a += __shfl_xor(a, msk); b += __shfl_xor(b, msk); }
+          const int cl = ps * 64 + vq * EPL + jj;
+          if (lane < VPR && cl < MT * 32 && cbase_blk + cl < P.Cout) {
+            atomicAdd(&stat[cl], a);
+            atomicAdd(&stat[MT * 32 + cl], b);
+          }
+        }
+      }
+    }
     __syncthreads();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
     for (int c = tid; c < MT * 32; c += NTHREADS) {
