@@ -53,7 +53,7 @@ __device__ static inline bf16x8 tr_pair(const __bf16* lo_addr, const __bf16* hi_
 template <typename T, int U, bool VEC>
 __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gstride, int c_lim, T* lds, int sub_elems,
                                              int R, int r_lo, int r_hi, int nsub, const float* __restrict__ sc,
-                                             const float* __restrict__ sh, int relu, int tid) {
+                                             const float* __restrict__ sh, int relu, int tid, int nthreads) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int QV = CB / EPL;
@@ -61,13 +61,13 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
   const int Q = nsub * QV;                 // power of two
   const int lq = 31 - __builtin_clz(Q);
   const int tot = R * Q;
-  for (int base = tid; base < tot; base += NTHREADS * U) {
+  for (int base = tid; base < tot; base += nthreads * U) {
     frag_t v[U];
     int rr[U], qq[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int it = base + u * NTHREADS;
+      const int it = base + u * nthreads;
       const int r = it >> lq, q = it & (Q - 1);
       rr[u] = r; qq[u] = q;
       live[u] = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
@@ -83,7 +83,7 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int it = base + u * NTHREADS;
+      const int it = base + u * nthreads;
       if (it < tot) {
         if (sc && live[u]) {
 #pragma unroll
@@ -102,9 +102,14 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
   }
 }
 
-template <typename T, int JT, int OT, int IT, int PS, bool AGG>
-__global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P) {
-  static_assert(OT * IT * PS == 4, "one (o-tile, i-tile, position-slice) per wave");
+// TS = tap split: the taps of one (o-tile, i-tile, position-slice) are divided over TS waves (workgroup = 4*TS waves), so
+// a wave keeps ceil(JT/TS) accumulator tiles: twice the waves per CU at the same LDS footprint for the 9/15-tap layers.
+template <typename T, int JT, int OT, int IT, int PS, bool AGG, int TS>
+__global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(const TwgParams P) {
+  static_assert(OT * IT * PS == 4 || OT * IT * PS == 8, "one (o-tile, i-tile, position-slice) per wave group");
+  constexpr int NWG = OT * IT * PS;                // waves per tap group
+  constexpr int NTH = 64 * NWG * TS;
+  constexpr int JTW = (JT + TS - 1) / TS;
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int NPOS = TR / PS;                  // positions contracted by one wave per tile
@@ -123,12 +128,13 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V;
   const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
-  const int ot = wave % OT, it = (wave / OT) % IT, ps = wave / (OT * IT);
+  const int w4 = wave % NWG, ts = wave / NWG;
+  const int ot = w4 % OT, it = (w4 / OT) % IT, ps = w4 / (OT * IT);
   const int o0 = oblk * (OT * CB), i0 = iblk * (IT * CB);
   const bool vec = (P.Cin % EPL == 0) && (P.Cout % EPL == 0);
   const int u_sub = P.urows * CB;
 
-  for (int r = tid; r < TR; r += NTHREADS) {
+  for (int r = tid; r < TR; r += NTH) {
     int f = r / V;
     row_f[r] = (unsigned short)f;
     row_v[r] = (unsigned short)(r - f * V);
@@ -137,11 +143,11 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     // adjacency -> LDS (coalesced), then per-column compressed lists
     const int K = P.ntaps, KV = K * V;
     float* A_l = reinterpret_cast<float*>(us);
-    for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = P.A[i];
-    for (int c = tid; c <= KV; c += NTHREADS) csr_off[c] = 0;
-    for (int c = tid; c < V * OT * CB; c += NTHREADS) S_l[c] = 0.f;
+    for (int i = tid; i < K * V * V; i += NTH) A_l[i] = P.A[i];
+    for (int c = tid; c <= KV; c += NTH) csr_off[c] = 0;
+    for (int c = tid; c < V * OT * CB; c += NTH) S_l[c] = 0.f;
     __syncthreads();
-    for (int col = tid; col < KV; col += NTHREADS) {
+    for (int col = tid; col < KV; col += NTH) {
       int k = col / V, w = col - k * V, cnt = 0;
       for (int v = 0; v < V; ++v) cnt += (A_l[(k * V + v) * V + w] != 0.f);
       csr_off[col + 1] = cnt;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       csr_off[KV] = run;
     }
     __syncthreads();
-    for (int col = tid; col < KV; col += NTHREADS) {
+    for (int col = tid; col < KV; col += NTH) {
       int k = col / V, w = col - k * V, e = csr_off[col];
       for (int v = 0; v < V; ++v) {
         float a = A_l[(k * V + v) * V + w];
@@ -166,17 +172,21 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
   }
   __syncthreads();
 
-  f32x16 acc[JT];
+  f32x16 acc[JTW];
 #pragma unroll
-  for (int j = 0; j < JT; ++j)
+  for (int j = 0; j < JTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float bsum = 0.f;
 
   // per-tap element offset into a u sub-tile (taps beyond ntaps alias tap 0: computed, never flushed)
-  int toff[JT];
+  int toff[JTW];
 #pragma unroll
-  for (int j = 0; j < JT; ++j) toff[j] = AGG ? (j < P.ntaps ? j : 0) * TR * CB : (P.tap_off[j] - P.min_off) * V * CB;
+  for (int jj = 0; jj < JTW; ++jj) {
+    const int j = ts * JTW + jj;                     // this wave's taps; padding taps alias tap 0 (computed, never flushed)
+    const int jv = j < P.ntaps ? j : 0;
+    toff[jj] = AGG ? jv * TR * CB : (P.tap_off[jv] - P.min_off) * V * CB;
+  }
 
   const T* dzg = reinterpret_cast<const T*>(P.dz);
   const T* gg = reinterpret_cast<const T*>(P.g);
@@ -198,15 +208,15 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
       {
         const T* src = gg + pos0 * P.Cin + i0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
       }
       __syncthreads();
       const int K = P.ntaps, KV = K * V;
       {
         // wave w owns adjacency columns col = w, w+4, ...; lanes span (sub-tile, frame, channel vector)
         const int npair = IT * nf * QV;
-        for (int col = wave; col < KV; col += 4) {
+        for (int col = wave; col < KV; col += NWG * TS) {
           const int k = col / V, w = col - k * V;
           const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
           for (int pr = lane; pr < npair; pr += 64) {
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
         }
         // positions >= rows are contracted too (against zero dz rows): keep their image rows finite (zero)
         const int padr = TR - rows;
-        for (int idx = tid; idx < IT * K * padr * QV; idx += NTHREADS) {
+        for (int idx = tid; idx < IT * K * padr * QV; idx += NTH) {
           const int q = idx % QV;
           const int r = rows + (idx / QV) % padr;
           const int sk = idx / (QV * padr);
@@ -243,13 +253,13 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       __syncthreads();
       {
         const T* src = dzg + pos0 * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
       }
       __syncthreads();
       if (P.S && iblk == 0) {
         constexpr int NC = OT * CB;
-        for (int idx = tid; idx < V * NC; idx += NTHREADS) {
+        for (int idx = tid; idx < V * NC; idx += NTH) {
           const int w = idx / NC, c = idx - w * NC;
           const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
           float sacc = 0.f;
@@ -261,10 +271,10 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     // ---- stage dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
       {
         const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
       }
-      for (int r = tid; r < TR; r += NTHREADS)
+      for (int r = tid; r < TR; r += NTH)
         urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
       {
         const long long row0 = (long long)(n * P.Tin + fin0) * V;
@@ -273,8 +283,8 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
         const float* sc = P.pre ? P.pre + i0 : nullptr;
         const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
         const T* src = gg + row0 * P.Cin + i0;
-        if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
-        else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid);
+        if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid, NTH);
+        else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid, NTH);
       }
       __syncthreads();
   
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
       constexpr int NC = OT * CB;
       const int c = tid % NC;
       const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
-      for (int r = tid / NC; r < rows; r += NTHREADS / NC) bsum += E::to_f(col[r * CB]);
+      for (int r = tid / NC; r < rows; r += NTH / NC) bsum += E::to_f(col[r * CB]);
     }
 
     // ---- D_j[o][i] += dz[p][o] * u[row(p) + tap_j][i] over this wave's positions ----
@@ -291,45 +301,73 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
     if constexpr (sizeof(T) == 4) {
       constexpr int NK = NPOS / 2;
       const int r = lane & 31, h = lane >> 5;
-      float a0, a1, b0[JT], b1[JT];
-      auto load_k = [&](int kk, float& a, float (&b)[JT]) {
+      float a0, a1, b0[JTW], b1[JTW];
+      auto load_k = [&](int kk, float& a, float (&b)[JTW]) {
         const int p = pbase + 2 * kk + h;
         a = dz_w[p * CB + r];
         const T* ub = us_w + (AGG ? p : (int)urow[p]) * CB + r;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) b[j] = ub[toff[j]];
+        for (int j = 0; j < JTW; ++j) b[j] = ub[toff[j]];
       };
-      auto mma_k = [&](float a, const float (&b)[JT]) {
+      auto mma_k = [&](float a, const float (&b)[JTW]) {
 #pragma unroll
-        for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < JTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
       };
-      load_k(0, a0, b0);
-      for (int kk = 0; kk < NK; kk += 2) {
-        load_k(kk + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_k(min(kk + 2, NK - 1), a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+      if constexpr (JTW >= 8) {
+        for (int kk = 0; kk < NK; ++kk) {
+          load_k(kk, a0, b0);
+          mma_k(a0, b0);
+        }
+      } else {
+        load_k(0, a0, b0);
+        for (int kk = 0; kk < NK; kk += 2) {
+          load_k(kk + 1, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_k(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_k(min(kk + 2, NK - 1), a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_k(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     } else {
       constexpr int NK = NPOS / 16;
       const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
       const int q = (lane & 15) >> 2, pp = lane & 3;
       const int coff = cblk + 4 * pp;
-      bf16x8 a, b[JT];
-#pragma unroll
-      for (int kk = 0; kk < NK; ++kk) {
+      bf16x8 a0, a1, b0[JTW], b1[JTW];
+      auto load_k = [&](int kk, bf16x8& a, bf16x8 (&b)[JTW]) {
         const int pb = pbase + 16 * kk + 8 * h + q;          // this lane addresses rows pb and pb+4 of its 8 positions
         a = tr_pair(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
         const T* u0 = us_w + (AGG ? pb : (int)urow[pb]) * CB + coff;
         const T* u1 = us_w + (AGG ? pb + 4 : (int)urow[pb + 4]) * CB + coff;
 #pragma unroll
-        for (int j = 0; j < JT; ++j) b[j] = tr_pair(u0 + toff[j], u1 + toff[j]);
+        for (int j = 0; j < JTW; ++j) b[j] = tr_pair(u0 + toff[j], u1 + toff[j]);
+      };
+      auto mma_k = [&](const bf16x8& a, const bf16x8 (&b)[JTW]) {
 #pragma unroll
-        for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < JTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
+      };
+      if constexpr (NK == 1 || JTW >= 8) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          load_k(kk, a0, b0);
+          mma_k(a0, b0);
+        }
+      } else {
+        load_k(0, a0, b0);
+#pragma unroll
+        for (int kk = 0; kk < NK; kk += 2) {
+          load_k(kk + 1, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_k(a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_k(kk + 2 < NK ? kk + 2 : NK - 1, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_k(a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     __syncthreads();
@@ -337,18 +375,19 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
 
   // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per atomic instruction ----
 #pragma unroll
-  for (int j = 0; j < JT; ++j) {
+  for (int jj = 0; jj < JTW; ++jj) {
+    const int j = ts * JTW + jj;
     if (j < P.ntaps) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-        if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[j][r]);
+        if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[jj][r]);
       }
     }
   }
   if (AGG && P.S && iblk == 0) {
     constexpr int NC = OT * CB;
-    for (int idx = tid; idx < V * NC; idx += NTHREADS) {
+    for (int idx = tid; idx < V * NC; idx += NTH) {
       const int w = idx / NC, c = idx - w * NC;
       if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[idx]);
     }
@@ -363,6 +402,7 @@ __global__ __launch_bounds__(NTHREADS) void tconv_wgrad_kernel(const TwgParams P
 
 template <typename T, int JT, int OT, int IT, int PS, bool AGG>
 int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
+  constexpr int TS = JT >= 9 ? 2 : 1;
   const int esz = sizeof(T);
   P.n_iblk = ceil_div(P.Cin, IT * CB);
   const int n_oblk = ceil_div(P.Cout, OT * CB);
@@ -383,14 +423,14 @@ int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   dim3 grid(gx, blocks);
-  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG>;
+  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG, TS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ea_ != hipSuccess) return 2000 + (int)ea_;
     attr_done = true;
   }
-  ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), off, stream, P);
+  ISTGCN_LAUNCH(kfn, grid, dim3(64 * OT * IT * PS * TS), off, stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
@@ -399,11 +439,20 @@ template <typename T, int JT, bool AGG>
 int launch_JT(TwgParams& P, int grid_cap, hipStream_t stream) {
   // channel block per workgroup: as wide as the layer and LDS allow (fewer redundant reads of dz / g, more MFMA work
   // per staged byte); narrow layers fall back to one 32x32 pair split four ways over positions.
-  if constexpr (sizeof(T) == 2) {
-    if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 1, AGG>(P, grid_cap, stream);
+  if constexpr (AGG) {
+    // few accumulator tiles per wave (K <= 4): spend the registers on waves instead -- 8 waves, finer position slices
+    if constexpr (sizeof(T) == 2) {
+      if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 2, AGG>(P, grid_cap, stream);
+    }
+    if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 4, AGG>(P, grid_cap, stream);
+    return launch_cfg<T, JT, 1, 1, 8, AGG>(P, grid_cap, stream);
+  } else {
+    if constexpr (sizeof(T) == 2) {
+      if (P.Cout > 32 && P.Cin > 32) return launch_cfg<T, JT, 2, 2, 1, AGG>(P, grid_cap, stream);
+    }
+    if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 2, AGG>(P, grid_cap, stream);
+    return launch_cfg<T, JT, 1, 1, 4, AGG>(P, grid_cap, stream);
   }
-  if (P.Cout > 32) return launch_cfg<T, JT, 2, 1, 2, AGG>(P, grid_cap, stream);
-  return launch_cfg<T, JT, 1, 1, 4, AGG>(P, grid_cap, stream);
 }
 
 template <typename T>
