@@ -29,7 +29,7 @@ struct GbdParams {
   float* dA;             // [K][V][V] accumulated, or null
   int NM, T, V, Cin, Cout, K, nnz_cap;
   int F, tiles_per_seq, total_tiles, CCi, nchi, CCc, nchc, NKGc, ds_stride;
-  int off_rv, off_rkw, off_ra, off_dacc, off_rows, off_dys, off_dxa;
+  int off_rv, off_rkw, off_ra, off_dacc, off_rows, off_afrag, off_dys, off_dxa;
 };
 
 template <typename T, int MTK, bool VEC>
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   unsigned char* row_f = smem + P.off_rows;                                          // [TR]
   unsigned char* row_v = row_f + TR;                                                 // [TR]
   T* dys = reinterpret_cast<T*>(smem + P.off_dys);                                   // [TR][ds_stride]  (later: x chunk)
-  T* dxa = reinterpret_cast<T*>(smem + P.off_dxa);                                   // [K][TR][CCi]
+  T* dxa = reinterpret_cast<T*>(smem + P.off_dxa);                                   // [K][TR][CCi] (+32 zero rows)
+  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                               // bf16: [K][2][64][8] fragments of A_k^T
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V, K = P.K, CCi = P.CCi, DS = P.ds_stride;
@@ -92,6 +93,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         }
     }
     __syncthreads();
+  }
+  const bool mfma_agg = sizeof(T) == 2 && V <= 32;
+  if (mfma_agg) {
+    // B-operand fragments of A_k^T for the transposed aggregation on the matrix cores: lane (v = lane&31, h), k-step s,
+    // element j holds A[k][v][w = 16s + 8h + j]; and 32 zero rows behind the last dxa image (the last frame's k-range)
+    for (int idx = tid; idx < K * 2 * 64; idx += NTHREADS) {
+      const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
+      const int v = ln & 31, h = ln >> 5;
+      frag_t fr;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        const int w = 16 * sstep + 8 * h + j;
+        fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
+      }
+      *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
+    }
+    for (int idx = tid; idx < 32 * Qi; idx += NTHREADS) {
+      frag_t z;
+      zero_frag<T>(z);
+      *reinterpret_cast<frag_t*>(dxa + (size_t)K * TR * CCi + idx * EPL) = z;
+    }
   }
   const int nnz = min(r_off[V], P.nnz_cap);
   constexpr int NPE = 16;                    // entries per thread: 16 * 256 >= K*V*V (checked on the host)
@@ -175,7 +197,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
                                nullptr, 0, tid, NTHREADS);
       __syncthreads();
 
-      // ---- dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM.
+      bool agg_done = false;
+      if constexpr (sizeof(T) == 2) if (mfma_agg) {
+        // ---- bf16: transposed aggregation on the matrix cores.  Per (frame f, 32-channel tile ct):
+        //      D[i][v] = sum_k sum_w dxa_k[(f,w)][i] * A_k[v][w]; dxa^T comes straight from the row-major images with
+        //      ds_read_b64_tr_b16, the adjacency fragments from LDS; lane = joint v, 4 consecutive channels per quad. ----
+        agg_done = true;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int CT = (CCi + 31) >> 5;
+        const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
+        const int q4 = (lane & 15) >> 2, pp = lane & 3;
+        const int v = lane & 31;
+        for (int pr = wave; pr < nf * CT; pr += 4) {
+          const int f = pr / CT, ct = pr - f * CT;
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int sstep = 0; sstep < 2; ++sstep) {
+              const T* r0 = dxa + (k * TR + f * V + 16 * sstep + 8 * h + q4) * CCi + ct * 32 + cblk + 4 * pp;
+              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)r0);
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * CCi));
+              bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+              frag_t a;
+              a[0] = l4[0]; a[1] = l4[1]; a[2] = l4[2]; a[3] = l4[3];
+              a[4] = h4[0]; a[5] = h4[1]; a[6] = h4[2]; a[7] = h4[3];
+              const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, d, 0, 0, 0);
+            }
+          }
+          if (v < V) {
+            const size_t grow = (pos0 + f * V + v) * P.Cin + ib;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int il = ct * 32 + 8 * g + 4 * (lane >> 5);
+              if (il < CCi && ib + il < P.Cin) {
+                float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                if (VEC) {
+                  if (addg) {
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(addg + grow + il);
+                    v4[0] += (float)av[0]; v4[1] += (float)av[1]; v4[2] += (float)av[2]; v4[3] += (float)av[3];
+                  }
+                  bf16x4 o = {(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
+                  *reinterpret_cast<bf16x4*>(dxg + grow + il) = o;
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    if (ib + il + e < P.Cin) {
+                      float fv = v4[e];
+                      if (addg) fv += E::to_f(addg[grow + il + e]);
+                      dxg[grow + il + e] = E::from_f(fv);
+                    }
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if (!agg_done) {
+      // ---- (VALU path) dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM.
       //      Wave w owns joints v = w, w+4, ... (wave-uniform entry lists); lanes span (frame, channel vector). ----
       {
         const int npair = nf * Qi;
@@ -219,6 +301,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
           }
         }
       }
+      }
       // ---- adjacency gradient on the pattern: thread t owns entries t, t+256, ... and keeps their sums in registers
       //      across tiles and chunks (flushed once per workgroup) ----
       if (P.dA) {
@@ -233,8 +316,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
               for (int q = 0; q < Qi; ++q) {
                 const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
                 const frag_t b = *reinterpret_cast<const frag_t*>(dr + (f * V) * CCi + q * EPL);
+                if constexpr (sizeof(T) == 2) {
+                  // v_dot2c_f32_bf16: two bf16 products per lane-op, no conversions
+                  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+                  for (int e = 0; e < EPL; e += 2) {
+                    const bf16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
+                    s = __builtin_amdgcn_fdot2_f32_bf16(a2, b2, s, false);
+                  }
+                } else {
+#pragma unroll
+                  for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+                }
               }
             }
             dsum[pe] += s;
@@ -306,9 +399,10 @@ int launch_T(GbdParams& P, const GbdGeom& G, int grid_cap, hipStream_t stream) {
   off = (off + 15) & ~(size_t)15; P.off_ra = (int)off; off += (size_t)P.nnz_cap * 4;
   off = (off + 15) & ~(size_t)15; P.off_dacc = (int)off; off += (size_t)P.nnz_cap * 4;
   off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TR;
+  off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += esz == 2 ? (size_t)P.K * 2 * 64 * 16 : 0;
   off = (off + 15) & ~(size_t)15; P.off_dys = (int)off; off += (size_t)TR * P.ds_stride * esz;
   off = (off + 15) & ~(size_t)15; P.off_dxa = (int)off;
-  size_t dxa = (size_t)P.K * TR * P.CCi * esz, al = (size_t)P.K * P.V * P.V * 4;
+  size_t dxa = ((size_t)P.K * TR + 32) * P.CCi * esz, al = (size_t)P.K * P.V * P.V * 4;
   off += dxa > al ? dxa : al;
   if (off > 160 * 1024) return ISTGCN_EINVAL;
   int gx = P.total_tiles < grid_cap ? P.total_tiles : grid_cap;

@@ -42,8 +42,14 @@ struct TconvParams {
   int us_stride, out_stride, off_stat, off_work;
 };
 
-template <typename T, int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P) {
+// WM = waves along the channel axis: the workgroup has 4*WM waves; wave (wr = wave & 3, wm = wave >> 2) owns row slab wr
+// and the MT/WM output-channel tiles [wm*MTW, (wm+1)*MTW).  WM = 2 doubles the waves per CU at the same LDS footprint
+// (these kernels wait on memory and barriers more than half of their wave-cycles).
+template <typename T, int MT, int NT, bool VEC, int WM>
+__global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvParams P) {
+  constexpr int NTH = NTHREADS * WM;
+  constexpr int MTW = MT / WM;
+  static_assert(MT % WM == 0, "channel tiles must split evenly over the channel waves");
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int KGS = E::KGS;
@@ -57,18 +63,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
   T* us = reinterpret_cast<T*>(smem + P.off_work);                           // [Fin*V][us_stride]
   T* outs = us;                                                              // [128][out_stride]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = tid >> 8;
   const int V = P.V;
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
   const int Q = P.CC / EPL;
 
-  for (int r = tid; r < TR; r += NTHREADS) {
+  for (int r = tid; r < TR; r += NTH) {
     int f = r / V;
     row_f[r] = (unsigned short)f;
     row_v[r] = (unsigned short)(r - f * V);
   }
-  for (int c = tid; c < 2 * MT * 32; c += NTHREADS) stat[c] = 0.f;
+  for (int c = tid; c < 2 * MT * 32; c += NTH) stat[c] = 0.f;
   if (tid < P.ntaps) tap_roff[tid] = (P.tap_off[tid] - P.min_off) * V;
   __syncthreads();
 
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
   // BatchNorm partial sums: a thread always copies out the same channel vector.  Where registers allow (small
   // accumulator footprints) the sums stay in registers for the whole grid-stride walk and are reduced across lanes once
   // per workgroup; the register-heavy instantiations reduce per tile instead.
-  constexpr bool REG_STATS = MT * NT < 8;
+  constexpr bool REG_STATS = MTW * NT < 8;
   constexpr int NPASS_ = (MT + 1) / 2;
   float st1[REG_STATS ? NPASS_ : 1][EPL], st2[REG_STATS ? NPASS_ : 1][EPL];
 #pragma unroll
@@ -104,9 +110,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
     const int fin0 = P.in_mul * m0 + P.min_off;          // first staged input frame (may be < 0)
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[MTW][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
         const long long row0 = (long long)(n * P.Tin + fin0) * V;
         const int r_lo = fin0 < 0 ? -fin0 * V : 0;
         const int r_hi = min(in_rows, (P.Tin - fin0) * V);
-        stage_block<T, (MT * NT >= 8 ? 4 : 8), VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
+        stage_block<T, (MTW * NT >= 8 ? 4 : 8), VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
                                Q, P.pre ? P.pre + cb : nullptr, P.pre ? P.pre + P.Cin + cb : nullptr, P.pre_relu, tid,
-                               NTHREADS);
+                               NTH);
       }
       __syncthreads();
       // ---- taps x k-groups on the matrix cores, software pipelined: the weight fragments (L2) and the shifted
@@ -139,20 +145,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
         const int lkg = 31 - __builtin_clz(P.NKG);
         const T* wbase = Wp + (((size_t)ch * nit) * P.MTtot + mt0) * 64 * EPL + lane * EPL;
         const int hoff = (lane >> 5) * EPL;
-        frag_t a0[MT], a1[MT], b0[NT], b1[NT];
-        auto load_step = [&](int it, frag_t (&a)[MT], frag_t (&b)[NT]) {
+        frag_t a0[MTW], a1[MTW], b0[NT], b1[NT];
+        auto load_step = [&](int it, frag_t (&a)[MTW], frag_t (&b)[NT]) {
           const int j = it >> lkg, kg = it & (P.NKG - 1);
           const int roff = tap_roff[j];
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            a[m] = *reinterpret_cast<const frag_t*>(wbase + ((size_t)it * P.MTtot + m) * 64 * EPL);
+          for (int m = 0; m < MTW; ++m)
+            a[m] = *reinterpret_cast<const frag_t*>(wbase + ((size_t)it * P.MTtot + wm * MTW + m) * 64 * EPL);
 #pragma unroll
           for (int t = 0; t < NT; ++t)
             b[t] = *reinterpret_cast<const frag_t*>(us + (brow[t] + roff) * P.us_stride + kg * KGS + hoff);
         };
-        auto mma_step = [&](const frag_t (&a)[MT], const frag_t (&b)[NT]) {
+        auto mma_step = [&](const frag_t (&a)[MTW], const frag_t (&b)[NT]) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MTW; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
         };
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
     // ---- epilogue: per (row slab t, 64-channel pass) through LDS, coalesced stores, BatchNorm sums ----
     constexpr int NPASS = (MT + 1) / 2;
     constexpr int VPR = 64 / EPL;
-    constexpr int RSTEP = NTHREADS / VPR;
+    constexpr int RSTEP = NTH / VPR;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -185,8 +191,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
           const int sr = wave * 32 + (lane & 31);       // staging row
 #pragma unroll
           for (int ml = 0; ml < 2; ++ml) {
-            const int m = 2 * ps + ml;
-            if (m < MT) {
+            const int mg = 2 * ps + ml;                  // channel tile of this pass; held by channel-wave mg / MTW
+            const int m = mg % MTW;
+            if (mg < MT && mg / MTW == wm) {
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
                 const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
     }
     __syncthreads();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
-    for (int c = tid; c < MT * 32; c += NTHREADS) {
+    for (int c = tid; c < MT * 32; c += NTH) {
       if (cbase_blk + c < P.Cout) {
         atomic_add_f64(dst + cbase_blk + c, (double)stat[c]);
         atomic_add_f64(dst + P.Cout + cbase_blk + c, (double)stat[MT * 32 + c]);
@@ -317,17 +324,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void tconv_kernel(const TconvParams P)
 
 template <typename T, int MT, int NT>
 int launch3(const TconvParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+  constexpr int WM = 1;   // WM = 2 (8 waves) needs <= 128 VGPRs for two workgroups per CU; the staging/epilogue code does not fit yet
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
 #define GO(VV)                                                                                              \
   do {                                                                                                      \
-    auto kfn = tconv_kernel<T, MT, NT, VV>;                                                                 \
+    auto kfn = tconv_kernel<T, MT, NT, VV, WM>;                                                                 \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
       hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS * WM), lds, stream, P);                                          \
   } while (0)
   if (vec) GO(true); else GO(false);
 #undef GO
