@@ -30,7 +30,7 @@ struct TwgParams {
   // graph-conv mode (AGG): the "taps" are the K adjacency partitions, u_k = sum_v A[k][v][w] x[(t,v)][:]
   const float* A;        // [K][V][V]
   float* S;              // [V][Cout] or null: sum_{n,t} dz[n,t,w,c]
-  int nnz_cap, off_csr_v, off_csr_a, off_S;
+  int nnz_cap, off_csr_v, off_csr_a, off_S, off_afrag, dz_rows;
   int NM, Tin, Tz, V, Cin, Cout, ntaps, in_mul, pre_relu;
   int tap_off[MAX_TAPS];
   int F, tiles_per_seq, total_tiles, min_off, Fin, n_iblk, urows;
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
   unsigned char* csr_v = smem + P.off_csr_v;
   float* csr_a = reinterpret_cast<float*>(smem + P.off_csr_a);
   float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][OT*CB]
+  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // AGG bf16: [K][2][64][8] fragments of A_k
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V;
@@ -169,6 +170,30 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
         }
       }
     }
+    if constexpr (sizeof(T) == 2) {
+      if (P.dz_rows > TR) {
+        // fragments of A_k for the MFMA aggregation (lane (w = lane&31, h), k-step s, element j = A[k][16s+8h+j][w])
+        // and the zero rows behind every x sub-tile
+        for (int idx = tid; idx < K * 2 * 64; idx += NTH) {
+          const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
+          const int w = ln & 31, h = ln >> 5;
+          typename E::frag fr;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) {
+            const int v = 16 * sstep + 8 * h + j;
+            fr[j] = E::from_f((v < V && w < V) ? A_l[(k * V + v) * V + w] : 0.f);
+          }
+          *reinterpret_cast<typename E::frag*>(afrag + idx * EPL) = fr;
+        }
+        constexpr int NSUB = IT > OT ? IT : OT;
+        for (int idx = tid; idx < NSUB * 32 * (CB / EPL); idx += NTH) {
+          const int sub = idx / (32 * (CB / EPL)), rem = idx - sub * (32 * (CB / EPL));
+          typename E::frag z;
+          zero_frag<T>(z);
+          *reinterpret_cast<typename E::frag*>(dzs + (sub * P.dz_rows + TR) * CB + rem * EPL) = z;
+        }
+      }
+    }
   }
   __syncthreads();
 
@@ -190,7 +215,8 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
 
   const T* dzg = reinterpret_cast<const T*>(P.dz);
   const T* gg = reinterpret_cast<const T*>(P.g);
-  const T* dz_w = dzs + ot * (TR * CB);
+  const int dz_sub = P.dz_rows * CB;               // sub-tile stride of the dz / x staging region
+  const T* dz_w = dzs + ot * dz_sub;
   const T* us_w = us + it * u_sub;
   typedef typename E::frag frag_t;
   constexpr int QV = CB / EPL;
@@ -208,12 +234,46 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
       const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
       {
         const T* src = gg + pos0 * P.Cin + i0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, TR * CB, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
       }
       __syncthreads();
       const int K = P.ntaps, KV = K * V;
       {
+        bool agg_done = false;
+        if constexpr (sizeof(T) == 2) if (P.dz_rows > TR) {
+          // bf16: D[i][w] = sum_v x[(f,v)][i] * A_k[v][w] on the matrix cores, x^T via ds_read_b64_tr_b16 (as gcn_fwd)
+          agg_done = true;
+          const int grp = lane >> 4, hh = grp >> 1, cblk = (grp & 1) * 16;
+          const int q4 = (lane & 15) >> 2, pp = lane & 3;
+          const int w = lane & 31;
+          for (int pr = wave; pr < IT * nf; pr += NWG * TS) {
+            const int sub = pr / nf, f = pr - sub * nf;
+            bf16x8 a[2];
+#pragma unroll
+            for (int sstep = 0; sstep < 2; ++sstep) {
+              const T* r0 = dzs + (sub * P.dz_rows + f * V + 16 * sstep + 8 * hh + q4) * CB + cblk + 4 * pp;
+              a[sstep] = tr_pair(r0, r0 + 4 * CB);
+            }
+            for (int k = 0; k < K; ++k) {
+              f32x16 d;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) d[r] = 0.f;
+              const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
+              const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
+              if (w < V) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                  store4(us + ((sub * K + k) * TR + f * V + w) * CB + 8 * g + 4 * (lane >> 5), v4);
+                }
+              }
+            }
+          }
+        }
+        if (!agg_done) {
         // wave w owns adjacency columns col = w, w+4, ...; lanes span (sub-tile, frame, channel vector)
         const int npair = IT * nf * QV;
         for (int col = wave; col < KV; col += NWG * TS) {
@@ -223,7 +283,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
             const int q = pr % QV;
             const int f = (pr / QV) % nf;
             const int sub = pr / (QV * nf);
-            const T* xrow = dzs + sub * (TR * CB) + (f * V) * CB + q * EPL;
+            const T* xrow = dzs + sub * dz_sub + (f * V) * CB + q * EPL;
             float sum[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
@@ -239,6 +299,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
             *reinterpret_cast<frag_t*>(us + ((sub * K + k) * TR + f * V + w) * CB + q * EPL) = o;
           }
         }
+        }
         // positions >= rows are contracted too (against zero dz rows): keep their image rows finite (zero)
         const int padr = TR - rows;
         for (int idx = tid; idx < IT * K * padr * QV; idx += NTH) {
@@ -253,15 +314,15 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
       __syncthreads();
       {
         const T* src = dzg + pos0 * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
       }
       __syncthreads();
       if (P.S && iblk == 0) {
         constexpr int NC = OT * CB;
         for (int idx = tid; idx < V * NC; idx += NTH) {
           const int w = idx / NC, c = idx - w * NC;
-          const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
+          const T* col = dzs + (c / CB) * dz_sub + (c % CB);
           float sacc = 0.f;
           for (int f = 0; f < nf; ++f) sacc += E::to_f(col[(f * V + w) * CB]);
           S_l[idx] += sacc;
@@ -271,8 +332,8 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
     // ---- stage dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
       {
         const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, TR * CB, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
+        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
       }
       for (int r = tid; r < TR; r += NTH)
         urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
@@ -292,7 +353,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
     if (!AGG && P.dbias && iblk == 0) {
       constexpr int NC = OT * CB;
       const int c = tid % NC;
-      const T* col = dzs + (c / CB) * (TR * CB) + (c % CB);
+      const T* col = dzs + (c / CB) * dz_sub + (c % CB);
       for (int r = tid / NC; r < rows; r += NTH / NC) bsum += E::to_f(col[r * CB]);
     }
 
@@ -415,7 +476,10 @@ int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
     off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
     off = (off + 15) & ~(size_t)15; P.off_S = (int)off; off += (size_t)P.V * OT * CB * 4;
   }
-  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)(AGG && IT > OT ? IT : OT) * TR * CB * esz;
+  const bool mfma_agg = AGG && esz == 2 && P.V <= 32;
+  P.dz_rows = mfma_agg ? TR + 32 : TR;             // MFMA aggregation reads a 32-row k-range per frame: zero rows behind
+  if (mfma_agg) { off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)P.ntaps * 2 * 64 * 16; }
+  off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)(AGG && IT > OT ? IT : OT) * P.dz_rows * CB * esz;
   off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)IT * P.urows * CB * esz;
   if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
   const int blocks = n_oblk * P.n_iblk;
