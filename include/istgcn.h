@@ -70,7 +70,7 @@ int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, f
 
 /* Temporal (k,1) convolution over the frame axis as an implicit GEMM (and its data gradient):
  *   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) ),
- *   m in [0, Mlog); input frames outside [0, Tin) contribute zero.
+ *   m in [0, Mlog); input frames outside [0, Tin) contribute zero; tap_off must be equally spaced.
  * = nn.Conv2d(C, C, (9,1), (stride,1), (4,0)) net/st_gcnold.py:167-173 with the preceding BatchNorm2d+ReLU
  *   (:165-166) applied on the fly (`pre` = [2][Cin] scale, shift; pre_relu) and the following BatchNorm2d's
  *   (:174) batch sums emitted (`stats`); the three-branch Inception-TCN of

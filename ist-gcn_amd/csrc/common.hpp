@@ -184,6 +184,29 @@ __device__ static inline void stage_block(const T* __restrict__ g, size_t gstrid
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Register-ring software pipeline for an MFMA loop whose operand fragments come from L2/LDS: the loads of step
+// it + D - 1 are issued before the MFMAs of step it, so D - 1 steps of matrix work cover the load latency (one bf16
+// step is only 128-256 MFMA cycles, an L2 hit 500-900).  `load(it, a, b)` fills one ring slot, `mma(a, b)` consumes
+// it.  No data-dependent control flow surrounds the loads (out-of-range steps re-load the last step), so the
+// compiler's vmcnt/lgkmcnt bookkeeping is exact; sched_barrier pins the issue order.
+// ---------------------------------------------------------------------------------------------------------
+template <int D, int NA, int NB, typename FragT, typename LoadF, typename MmaF>
+__device__ static inline void mfma_ring(int nit, LoadF load, MmaF mma) {
+  FragT a[D][NA], b[D][NB];
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) load(min(d, nit - 1), a[d], b[d]);
+  for (int it0 = 0; it0 < nit; it0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      load(min(it0 + d + D - 1, nit - 1), a[(d + D - 1) % D], b[(d + D - 1) % D]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + d < nit) mma(a[d], b[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 __device__ static inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -270,28 +270,18 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
       {
         const T* brow = xa + (wave * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
         const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-        frag_t a0[MT], a1[MT], b0, b1;
-        auto load_step = [&](int kg, frag_t (&a)[MT], frag_t& b) {
+        auto load_step = [&](int kg, frag_t (&a)[MT], frag_t (&b)[1]) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
-          b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
+          b[0] = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
         };
-        load_step(0, a0, b0);
-        for (int kg = 0; kg < P.NKG; kg += 2) {
-          load_step(min(kg + 1, P.NKG - 1), a1, b1);
-          __builtin_amdgcn_sched_barrier(0);
+        auto mma_step = [&](const frag_t (&a)[MT], const frag_t (&b)[1]) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a0[m], b0);
-          __builtin_amdgcn_sched_barrier(0);
-          load_step(min(kg + 2, P.NKG - 1), a0, b0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (kg + 1 < P.NKG) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a1[m], b1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+          for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a[m], b[0]);
+        };
+        constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MT <= 2 ? 4 : (MT <= 4 ? 3 : 2));
+        mfma_ring<DEPTH, MT, 1, frag_t>(P.NKG, load_step, mma_step);
       }
       __syncthreads();   // xa / xs free again (next chunk or the epilogue's staging buffer)
     }

@@ -20,6 +20,19 @@
 // Tiles of one sequence are kept on one XCD (grid-stride order below) so halo re-reads hit that XCD's L2.
 #include "common.hpp"
 
+#ifdef ISTGCN_STAMP
+// diagnostic build only: per-phase cycle sums (lane 0 of every wave), read back with istgcn_debug_stamps
+__device__ unsigned long long g_stamp[8];
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+    if (lane == 0) st_acc[i] += t_ - st_prev;                                                      \
+    st_prev = __builtin_amdgcn_s_memtime();                                                        \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int NTHREADS = 256;
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
   int* tap_roff = reinterpret_cast<int*>(stat + 2 * MT * 32);                 // [MAX_TAPS] LDS row offset per tap
   T* us = reinterpret_cast<T*>(smem + P.off_work);                           // [Fin*V][us_stride]
-  T* outs = us;                                                              // [128][out_stride]
+  T* outs = us;                                                              // [TR][out_stride]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = tid >> 8;
   const int V = P.V;
@@ -100,9 +113,13 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
 #pragma unroll
     for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] = 0.f; st2[ps][jj] = 0.f; }
 
+#ifdef ISTGCN_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int slot = blockIdx.x >> 3; slot < chunk; slot += G8) {
     const int tile = xcd * chunk + slot;
     if (tile >= P.total_tiles) break;
+    STAMP(0);
     const int n = tile / P.tiles_per_seq;
     const int m0 = (tile - n * P.tiles_per_seq) * P.F;
     const int nf = min(P.F, P.Mlog - m0);
@@ -137,7 +154,9 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
                                Q, P.pre ? P.pre + cb : nullptr, P.pre ? P.pre + P.Cin + cb : nullptr, P.pre_relu, tid,
                                NTH);
       }
+      STAMP(1);
       __syncthreads();
+      STAMP(2);
       // ---- taps x k-groups on the matrix cores, software pipelined: the weight fragments (L2) and the shifted
       //      activation fragments (LDS) of step it+1 are in flight while the MFMAs of step it issue ----
       {
@@ -145,10 +164,11 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
         const int lkg = 31 - __builtin_clz(P.NKG);
         const T* wbase = Wp + (((size_t)ch * nit) * P.MTtot + mt0) * 64 * EPL + lane * EPL;
         const int hoff = (lane >> 5) * EPL;
-        frag_t a0[MTW], a1[MTW], b0[NT], b1[NT];
+        const int roff0 = (P.tap_off[0] - P.min_off) * V;
+        const int rstep = P.ntaps > 1 ? (P.tap_off[1] - P.tap_off[0]) * V : 0;
         auto load_step = [&](int it, frag_t (&a)[MTW], frag_t (&b)[NT]) {
           const int j = it >> lkg, kg = it & (P.NKG - 1);
-          const int roff = tap_roff[j];
+          const int roff = roff0 + j * rstep;              // taps are an arithmetic progression (checked on the host)
 #pragma unroll
           for (int m = 0; m < MTW; ++m)
             a[m] = *reinterpret_cast<const frag_t*>(wbase + ((size_t)it * P.MTtot + wm * MTW + m) * 64 * EPL);
@@ -162,135 +182,141 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
 #pragma unroll
             for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
         };
-        // steps beyond the last one re-load the last step (never consumed): no data-dependent control flow around the
-        // loads, so the compiler's vmcnt bookkeeping is exact and the MFMAs of step `it` wait only for step `it`.
-        load_step(0, a0, b0);
-        for (int it = 0; it < nit; it += 2) {
-          load_step(min(it + 1, nit - 1), a1, b1);
-          __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it hides behind
-          mma_step(a0, b0);
-          __builtin_amdgcn_sched_barrier(0);
-          load_step(min(it + 2, nit - 1), a0, b0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (it + 1 < nit) mma_step(a1, b1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // ring depth: fp32 steps are 4x longer (4 MFMAs of 64 cycles per k-group), two slots cover L2; bf16 needs more
+        constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MTW * NT <= 4 ? 4 : 3);
+        mfma_ring<DEPTH, MTW, NT, frag_t>(nit, load_step, mma_step);
       }
+      STAMP(3);
       __syncthreads();
+      STAMP(4);
     }
 
-    // ---- epilogue: per (row slab t, 64-channel pass) through LDS, coalesced stores, BatchNorm sums ----
+    // ---- epilogue: one pass per 64-channel pair over ALL TR rows of the tile (in-kernel stamps showed this stage at
+    //      35-50 % of the bf16 kernel when it made one pass per 32-row slab): accumulators -> LDS (row-major, channels
+    //      innermost) -> coalesced 16-byte stores with the mask / BatchNorm sums applied on the way out ----
     constexpr int NPASS = (MT + 1) / 2;
     constexpr int VPR = 64 / EPL;
     constexpr int RSTEP = NTH / VPR;
+    const bool dense_rows = P.out_mul == 1;        // the tile's output rows are then one contiguous run in HBM
+    const size_t out_base = ((size_t)(n * P.Tout + m0 * P.out_mul + P.out_off) * V) * P.Cout;
+    // per-channel constants of this thread's channel vector (fixed across passes up to the 64-channel offset)
+    const int vq = tid % VPR;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        {
-          const int sr = wave * 32 + (lane & 31);       // staging row
+      for (int t = 0; t < NT; ++t) {
+        const int sr = wave * (32 * NT) + t * 32 + (lane & 31);       // staging row = tile row
 #pragma unroll
-          for (int ml = 0; ml < 2; ++ml) {
-            const int mg = 2 * ps + ml;                  // channel tile of this pass; held by channel-wave mg / MTW
-            const int m = mg % MTW;
-            if (mg < MT && mg / MTW == wm) {
+        for (int ml = 0; ml < 2; ++ml) {
+          const int mg = 2 * ps + ml;                  // channel tile of this pass; held by channel-wave mg / MTW
+          const int m = mg % MTW;
+          if (mg < MT && mg / MTW == wm) {
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-                const int cg = cbase_blk + ps * 64 + cl;
-                float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
-                if (P.bias) {
-                  if (VEC && cg + 3 < P.Cout) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + cg);
-                    v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
-                  } else {
+            for (int g = 0; g < 4; ++g) {
+              const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
+              const int cg = cbase_blk + ps * 64 + cl;
+              float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
+              if (P.bias) {
+                if (VEC && cg + 3 < P.Cout) {
+                  const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + cg);
+                  v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
+                } else {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) v4[jj] += P.bias[cg + jj];
-                  }
+                  for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) v4[jj] += P.bias[cg + jj];
                 }
-                store4(outs + sr * P.out_stride + cl, v4);
               }
+              store4(outs + sr * P.out_stride + cl, v4);
             }
           }
         }
-        __syncthreads();
-        {
-          const int vq = tid % VPR;
-          const int cg = cbase_blk + ps * 64 + vq * EPL;
-          const bool col_live = (ps * 64 + vq * EPL) < MT * 32 && cg < P.Cout;
-          float s1[EPL], s2[EPL];
+      }
+      __syncthreads();
+      {
+        const int cg = cbase_blk + ps * 64 + vq * EPL;
+        const bool col_live = (ps * 64 + vq * EPL) < MT * 32 && cg < P.Cout;
+        float s1[EPL], s2[EPL], msc[EPL], msh[EPL], mmu[EPL], mrs[EPL];
 #pragma unroll
-          for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; }
-          if (col_live) {
-            for (int sr = tid / VPR; sr < 128; sr += RSTEP) {
-              const int p = (sr >> 5) * (32 * NT) + t * 32 + (sr & 31);
-              if (p >= rows) continue;
-              const int f = row_f[p], v = row_v[p];
-              const size_t g = ((size_t)(n * P.Tout + (m0 + f) * P.out_mul + P.out_off) * V + v) * P.Cout + cg;
-              frag_t sv = *reinterpret_cast<const frag_t*>(outs + sr * P.out_stride + vq * EPL);
+        for (int jj = 0; jj < EPL; ++jj) {
+          s1[jj] = 0.f; s2[jj] = 0.f;
+          const bool in = P.mode == 1 && col_live && cg + jj < P.Cout;
+          msc[jj] = in ? P.maux[cg + jj] : 0.f;
+          msh[jj] = in ? P.maux[P.Cout + cg + jj] : 0.f;
+          mmu[jj] = in ? P.maux[2 * P.Cout + cg + jj] : 0.f;
+          mrs[jj] = in ? P.maux[3 * P.Cout + cg + jj] : 0.f;
+        }
+        if (col_live) {
+          for (int p = tid / VPR; p < rows; p += RSTEP) {
+            size_t g;
+            if (dense_rows) g = out_base + (size_t)p * P.Cout + cg;
+            else g = ((size_t)(n * P.Tout + (m0 + row_f[p]) * P.out_mul + P.out_off) * V + row_v[p]) * P.Cout + cg;
+            frag_t sv = *reinterpret_cast<const frag_t*>(outs + p * P.out_stride + vq * EPL);
+            if (P.mode == 1) {
               frag_t av;
-              if (P.mode == 1) {
-                if (VEC) av = *reinterpret_cast<const frag_t*>(auxg + g);
-                else {
+              if (VEC) av = *reinterpret_cast<const frag_t*>(auxg + g);
+              else {
 #pragma unroll
-                  for (int jj = 0; jj < EPL; ++jj) av[jj] = (cg + jj < P.Cout) ? auxg[g + jj] : E::from_f(0.f);
-                }
+                for (int jj = 0; jj < EPL; ++jj) av[jj] = (cg + jj < P.Cout) ? auxg[g + jj] : E::from_f(0.f);
               }
 #pragma unroll
               for (int jj = 0; jj < EPL; ++jj) {
                 if (VEC || cg + jj < P.Cout) {
-                  float fv = E::to_f(sv[jj]);
-                  if (P.mode == 1) {
-                    const int c = cg + jj;
-                    const float xa = E::to_f(av[jj]);
-                    const bool on = xa * P.maux[c] + P.maux[P.Cout + c] > 0.f;
-                    fv = on ? fv : 0.f;
-                    const T o = E::from_f(fv);
-                    sv[jj] = o;
-                    fv = E::to_f(o);
-                    s1[jj] += fv;
-                    s2[jj] += fv * (xa - P.maux[2 * P.Cout + c]) * P.maux[3 * P.Cout + c];
-                  } else {
-                    s1[jj] += fv;
-                    s2[jj] += fv * fv;
-                  }
+                  const float xa = E::to_f(av[jj]);
+                  const T o = E::from_f(xa * msc[jj] + msh[jj] > 0.f ? E::to_f(sv[jj]) : 0.f);
+                  sv[jj] = o;
+                  const float fv = E::to_f(o);
+                  s1[jj] += fv;
+                  s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
                 }
               }
-              if (VEC) *reinterpret_cast<frag_t*>(outg + g) = sv;
-              else {
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g + jj] = sv[jj];
-              }
-            }
-          }
-          if constexpr (REG_STATS) {
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] += s1[jj]; st2[ps][jj] += s2[jj]; }
-          } else if (P.stats) {
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) {
-#pragma unroll
-              for (int msk = VPR; msk < 64; msk <<= 1) {
-                s1[jj] += __shfl_xor(s1[jj], msk);
-                s2[jj] += __shfl_xor(s2[jj], msk);
-              }
-            }
-            if (lane < VPR && col_live) {
+            } else {
 #pragma unroll
               for (int jj = 0; jj < EPL; ++jj) {
-                const int cl = ps * 64 + vq * EPL + jj;
-                if (cbase_blk + cl < P.Cout) {
-                  atomicAdd(&stat[cl], s1[jj]);
-                  atomicAdd(&stat[MT * 32 + cl], s2[jj]);
+                if (VEC || cg + jj < P.Cout) {
+                  const float fv = E::to_f(sv[jj]);
+                  s1[jj] += fv;
+                  s2[jj] += fv * fv;
                 }
+              }
+            }
+            if (VEC) *reinterpret_cast<frag_t*>(outg + g) = sv;
+            else {
+#pragma unroll
+              for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g + jj] = sv[jj];
+            }
+          }
+        }
+        if constexpr (REG_STATS) {
+#pragma unroll
+          for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] += s1[jj]; st2[ps][jj] += s2[jj]; }
+        } else if (P.stats) {
+#pragma unroll
+          for (int jj = 0; jj < EPL; ++jj) {
+#pragma unroll
+            for (int msk = VPR; msk < 64; msk <<= 1) {
+              s1[jj] += __shfl_xor(s1[jj], msk);
+              s2[jj] += __shfl_xor(s2[jj], msk);
+            }
+          }
+          if (lane < VPR && col_live) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+              const int cl = ps * 64 + vq * EPL + jj;
+              if (cbase_blk + cl < P.Cout) {
+                atomicAdd(&stat[cl], s1[jj]);
+                atomicAdd(&stat[MT * 32 + cl], s2[jj]);
               }
             }
           }
         }
-        __syncthreads();
       }
+      __syncthreads();
     }
+    STAMP(5);
   }
+#ifdef ISTGCN_STAMP
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
+#endif
 
   if (P.stats) {
     if constexpr (REG_STATS) {
@@ -378,7 +404,7 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
   off = (off + 15) & ~(size_t)15; G->off_stat = (int)off; off += (size_t)2 * G->MT * 32 * 4 + MAX_TAPS * 4;
   off = (off + 15) & ~(size_t)15; G->off_work = (int)off;
   size_t work = (size_t)G->Fin * V * G->us_stride * esz;
-  size_t ost = (size_t)128 * G->out_stride * esz;
+  size_t ost = (size_t)128 * best_nt * G->out_stride * esz;
   off += work > ost ? work : ost;
   G->lds = (int)off;
   return off <= 160 * 1024 ? ISTGCN_OK : ISTGCN_EINVAL;
@@ -424,6 +450,8 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   if (Mlog > 0 && (Mlog - 1) * out_mul + out_off >= Tout) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;
   if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  for (int j = 2; j < ntaps; ++j)      // taps must be equally spaced (every forward / data-gradient phase of a conv is)
+    if (tap_off[j] - tap_off[j - 1] != tap_off[1] - tap_off[0]) return ISTGCN_EINVAL;
   if (NM == 0 || Mlog == 0) return ISTGCN_OK;
   TconvParams P{};
   P.in = in; P.Wp = Wp; P.bias = bias; P.pre = pre; P.aux = aux; P.maux = maux; P.out = out; P.stats = stats;
@@ -438,3 +466,14 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }
+
+#ifdef ISTGCN_STAMP
+extern "C" int istgcn_debug_stamps(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return ISTGCN_ELAUNCH;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return ISTGCN_ELAUNCH;
+  }
+  return ISTGCN_OK;
+}
+#endif

@@ -14,6 +14,18 @@
 // hides behind the MFMAs of the previous k-step.
 #include "common.hpp"
 
+#ifdef ISTGCN_STAMP
+__device__ unsigned long long g_stamp_wg[8];
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
+    if (lane == 0) st_acc[i] += t_ - st_prev;                                                      \
+    st_prev = __builtin_amdgcn_s_memtime();                                                        \
+  } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int NTHREADS = 256;
@@ -39,6 +51,17 @@ struct TwgParams {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
+
 __device__ static inline bf16x8 tr_pair(const __bf16* lo_addr, const __bf16* hi_addr) {
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_addr);
   s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_addr);
@@ -49,62 +72,84 @@ __device__ static inline bf16x8 tr_pair(const __bf16* lo_addr, const __bf16* hi_
   return o;
 }
 
-// sub-tiled staging: vector q of a row goes to sub-tile q / QV
+// sub-tiled staging: vector q of a row goes to sub-tile q / QV.  Split in two so the global loads of the NEXT tile can
+// be in flight (in registers) while the matrix cores work on the current one: item it = it0 + tid + u*nthreads.
 template <typename T, int U, bool VEC>
-__device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gstride, int c_lim, T* lds, int sub_elems,
-                                             int R, int r_lo, int r_hi, int nsub, const float* __restrict__ sc,
-                                             const float* __restrict__ sh, int relu, int tid, int nthreads) {
+__device__ static inline void load_subtiles(typename Elem<T>::frag (&v)[U], const T* __restrict__ g, size_t gstride,
+                                            int c_lim, int R, int r_lo, int r_hi, int nsub, int it0, int tid,
+                                            int nthreads) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int QV = CB / EPL;
-  typedef typename E::frag frag_t;
   const int Q = nsub * QV;                 // power of two
   const int lq = 31 - __builtin_clz(Q);
   const int tot = R * Q;
-  for (int base = tid; base < tot; base += nthreads * U) {
-    frag_t v[U];
-    int rr[U], qq[U];
-    bool live[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int it = base + u * nthreads;
-      const int r = it >> lq, q = it & (Q - 1);
-      rr[u] = r; qq[u] = q;
-      live[u] = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
-      zero_frag<T>(v[u]);
-      if (live[u]) {
-        const T* src = g + (size_t)r * gstride + q * EPL;
-        if (VEC) v[u] = *reinterpret_cast<const frag_t*>(src);
-        else {
+  for (int u = 0; u < U; ++u) {
+    const int it = it0 + tid + u * nthreads;
+    const int r = it >> lq, q = it & (Q - 1);
+    const bool live = it < tot && r >= r_lo && r < r_hi && q * EPL < c_lim;
+    zero_frag<T>(v[u]);
+    if (live) {
+      const T* src = g + (size_t)r * gstride + q * EPL;
+      if (VEC) v[u] = *reinterpret_cast<const typename E::frag*>(src);
+      else {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[e];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int it = base + u * nthreads;
-      if (it < tot) {
-        if (sc && live[u]) {
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) {
-            if (VEC || qq[u] * EPL + e < c_lim) {
-              float fv = E::to_f(v[u][e]) * sc[qq[u] * EPL + e] + sh[qq[u] * EPL + e];
-              if (relu) fv = fmaxf(fv, 0.f);
-              v[u][e] = E::from_f(fv);
-            }
-          }
-        }
-        const int sub = qq[u] / QV, ql = qq[u] - sub * QV;
-        *reinterpret_cast<frag_t*>(lds + sub * sub_elems + rr[u] * CB + ql * EPL) = v[u];
+        for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[e];
       }
     }
   }
 }
 
+template <typename T, int U, bool VEC>
+__device__ static inline void commit_subtiles(typename Elem<T>::frag (&v)[U], int c_lim, T* lds, int sub_elems, int R,
+                                              int r_lo, int r_hi, int nsub, const float* __restrict__ sc,
+                                              const float* __restrict__ sh, int relu, int it0, int tid, int nthreads) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  constexpr int QV = CB / EPL;
+  const int Q = nsub * QV;
+  const int lq = 31 - __builtin_clz(Q);
+  const int tot = R * Q;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int it = it0 + tid + u * nthreads;
+    if (it < tot) {
+      const int r = it >> lq, q = it & (Q - 1);
+      const bool live = r >= r_lo && r < r_hi && q * EPL < c_lim;
+      if (sc && live) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          if (VEC || q * EPL + e < c_lim) {
+            float fv = E::to_f(v[u][e]) * sc[q * EPL + e] + sh[q * EPL + e];
+            if (relu) fv = fmaxf(fv, 0.f);
+            v[u][e] = E::from_f(fv);
+          }
+        }
+      }
+      const int sub = q / QV, ql = q - sub * QV;
+      *reinterpret_cast<typename E::frag*>(lds + sub * sub_elems + r * CB + ql * EPL) = v[u];
+    }
+  }
+}
+
+// synchronous staging of items [it0, R*Q): the rare tiles larger than the prefetch registers cover
+template <typename T, int U, bool VEC>
+__device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gstride, int c_lim, T* lds, int sub_elems,
+                                             int R, int r_lo, int r_hi, int nsub, const float* __restrict__ sc,
+                                             const float* __restrict__ sh, int relu, int it0, int tid, int nthreads) {
+  constexpr int QV = CB / Elem<T>::EPL;
+  const int tot = R * nsub * QV;
+  for (int base = it0; base < tot; base += nthreads * U) {
+    typename Elem<T>::frag v[U];
+    load_subtiles<T, U, VEC>(v, g, gstride, c_lim, R, r_lo, r_hi, nsub, base, tid, nthreads);
+    commit_subtiles<T, U, VEC>(v, c_lim, lds, sub_elems, R, r_lo, r_hi, nsub, sc, sh, relu, base, tid, nthreads);
+  }
+}
+
 // TS = tap split: the taps of one (o-tile, i-tile, position-slice) are divided over TS waves (workgroup = 4*TS waves), so
 // a wave keeps ceil(JT/TS) accumulator tiles: twice the waves per CU at the same LDS footprint for the 9/15-tap layers.
-template <typename T, int JT, int OT, int IT, int PS, bool AGG, int TS>
+template <typename T, int JT, int OT, int IT, int PS, bool AGG, int TS, bool VEC>
 __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(const TwgParams P) {
   static_assert(OT * IT * PS == 4 || OT * IT * PS == 8, "one (o-tile, i-tile, position-slice) per wave group");
   constexpr int NWG = OT * IT * PS;                // waves per tap group
@@ -132,7 +177,6 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
   const int w4 = wave % NWG, ts = wave / NWG;
   const int ot = w4 % OT, it = (w4 / OT) % IT, ps = w4 / (OT * IT);
   const int o0 = oblk * (OT * CB), i0 = iblk * (IT * CB);
-  const bool vec = (P.Cin % EPL == 0) && (P.Cout % EPL == 0);
   const int u_sub = P.urows * CB;
 
   for (int r = tid; r < TR; r += NTH) {
@@ -221,22 +265,53 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
   typedef typename E::frag frag_t;
   constexpr int QV = CB / EPL;
 
+#ifdef ISTGCN_STAMP
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- register prefetch of the next tile's global data (issued before the MFMA loop, consumed after it) ----
+  constexpr int UZ = (TR * OT * QV + NTH - 1) / NTH;      // dz tile vectors per thread (exact cover)
+  constexpr int UX = (TR * IT * QV + NTH - 1) / NTH;      // AGG: x tile vectors per thread
+  constexpr int UH = (336 * IT * QV + NTH - 1) / NTH;     // u halo tile (<= 336 rows in the common layers) ...
+  constexpr int UU = AGG ? UX : (UH < 8 ? UH : 8);        // ... prefetched; larger halos finish synchronously
+  frag_t pz[UZ], pu[UU];
+  auto prefetch = [&](int tile) {
+    const int n = tile / P.tiles_per_seq;
+    const int m0 = (tile - n * P.tiles_per_seq) * P.F;
+    const int nf = min(P.F, P.Tz - m0);
+    const int rows = nf * V;
+    const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
+    {
+      const T* src = dzg + pos0 * P.Cout + o0;
+      load_subtiles<T, UZ, VEC>(pz, src, (size_t)P.Cout, P.Cout - o0, TR, 0, rows, OT, 0, tid, NTH);
+    }
+    if constexpr (AGG) {
+      const T* src = gg + pos0 * P.Cin + i0;
+      load_subtiles<T, UU, VEC>(pu, src, (size_t)P.Cin, P.Cin - i0, TR, 0, rows, IT, 0, tid, NTH);
+    } else {
+      const int fin0 = P.in_mul * m0 + P.min_off;
+      const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;
+      const long long row0 = (long long)(n * P.Tin + fin0) * V;
+      const int r_lo = fin0 < 0 ? -fin0 * V : 0;
+      const int r_hi = min(in_rows, (P.Tin - fin0) * V);
+      const T* src = gg + row0 * P.Cin + i0;
+      load_subtiles<T, UU, VEC>(pu, src, (size_t)P.Cin, P.Cin - i0, in_rows, r_lo, r_hi, IT, 0, tid, NTH);
+    }
+  };
+  if ((int)blockIdx.x < P.total_tiles) prefetch(blockIdx.x);
+
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+    STAMP(0);
     const int n = tile / P.tiles_per_seq;
     const int m0 = (tile - n * P.tiles_per_seq) * P.F;
     const int nf = min(P.F, P.Tz - m0);
     const int rows = nf * V;
     const int fin0 = P.in_mul * m0 + P.min_off;
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;
+    const int next_tile = tile + gridDim.x;
 
     if constexpr (AGG) {
       // ---- x tile -> dz region, K aggregated images -> us, then the dz tile over the x tile ----
-      const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
-      {
-        const T* src = gg + pos0 * P.Cin + i0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cin, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cin, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, tid, NTH);
-      }
+      commit_subtiles<T, UU, VEC>(pu, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, 0, tid, NTH);
       __syncthreads();
       const int K = P.ntaps, KV = K * V;
       {
@@ -312,12 +387,9 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
         }
       }
       __syncthreads();
-      {
-        const T* src = dzg + pos0 * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-      }
+      commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
       __syncthreads();
+      if (next_tile < P.total_tiles) prefetch(next_tile);
       if (P.S && iblk == 0) {
         constexpr int NC = OT * CB;
         for (int idx = tid; idx < V * NC; idx += NTH) {
@@ -329,12 +401,8 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
         }
       }
     } else {
-    // ---- stage dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
-      {
-        const T* src = dzg + ((size_t)(n * P.Tz + m0) * V) * P.Cout + o0;
-        if (vec) stage_subtiles<T, 4, true>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-        else stage_subtiles<T, 4, false>(src, (size_t)P.Cout, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, tid, NTH);
-      }
+    // ---- dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
+      commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
       for (int r = tid; r < TR; r += NTH)
         urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
       {
@@ -344,12 +412,15 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
         const float* sc = P.pre ? P.pre + i0 : nullptr;
         const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
         const T* src = gg + row0 * P.Cin + i0;
-        if (vec) stage_subtiles<T, 8, true>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid, NTH);
-        else stage_subtiles<T, 8, false>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, tid, NTH);
+        commit_subtiles<T, UU, VEC>(pu, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, 0, tid, NTH);
+        if (in_rows * IT * QV > UU * NTH) {            // halo larger than the prefetch registers cover
+          stage_subtiles<T, 4, VEC>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, UU * NTH, tid, NTH);
+        }
       }
       __syncthreads();
-  
+      if (next_tile < P.total_tiles) prefetch(next_tile);
     }
+    STAMP(1);
     if (!AGG && P.dbias && iblk == 0) {
       constexpr int NC = OT * CB;
       const int c = tid % NC;
@@ -357,6 +428,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
       for (int r = tid / NC; r < rows; r += NTH / NC) bsum += E::to_f(col[r * CB]);
     }
 
+    STAMP(2);
     // ---- D_j[o][i] += dz[p][o] * u[row(p) + tap_j][i] over this wave's positions ----
     const int pbase = ps * NPOS;
     if constexpr (sizeof(T) == 4) {
@@ -374,7 +446,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
 #pragma unroll
         for (int j = 0; j < JTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
       };
-      if constexpr (JTW >= 8) {
+      if constexpr (JTW > 4) {
         for (int kk = 0; kk < NK; ++kk) {
           load_k(kk, a0, b0);
           mma_k(a0, b0);
@@ -410,7 +482,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
 #pragma unroll
         for (int j = 0; j < JTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
       };
-      if constexpr (NK == 1 || JTW >= 8) {
+      if constexpr (NK == 1 || JTW > 4 || AGG) {
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
           load_k(kk, a0, b0);
@@ -431,8 +503,14 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
         }
       }
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
   }
+  STAMP(5);
+#ifdef ISTGCN_STAMP
+  const unsigned long long t_flush0 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per atomic instruction ----
 #pragma unroll
@@ -459,11 +537,17 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
     const int c = tid % NC;
     if ((NC == 64 || lane < 32) && o0 + c < P.Cout) atomicAdd(P.dbias + o0 + c, bsum);
   }
+#ifdef ISTGCN_STAMP
+  if (lane == 0) {
+    st_acc[6] += __builtin_amdgcn_s_memtime() - t_flush0;
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp_wg[i], st_acc[i]);
+  }
+#endif
 }
 
-template <typename T, int JT, int OT, int IT, int PS, bool AGG>
-int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
-  constexpr int TS = JT >= 9 ? 2 : 1;
+template <typename T, int JT, int OT, int IT, int PS, bool AGG, bool VEC>
+int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
+  constexpr int TS = JT >= 9 ? 3 : 1;
   const int esz = sizeof(T);
   P.n_iblk = ceil_div(P.Cin, IT * CB);
   const int n_oblk = ceil_div(P.Cout, OT * CB);
@@ -483,20 +567,42 @@ int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
   off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)IT * P.urows * CB * esz;
   if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
   const int blocks = n_oblk * P.n_iblk;
-  int gx = grid_cap / blocks;
-  if (gx < 1) gx = 1;
-  if (gx > P.total_tiles) gx = P.total_tiles;
-  dim3 grid(gx, blocks);
-  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG, TS>;
+  auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG, TS, VEC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ea_ != hipSuccess) return 2000 + (int)ea_;
     attr_done = true;
   }
+  // persistent grid: exactly the workgroups that are resident at once (every extra one pays a full flush of its
+  // accumulators through atomics and waits for a slot anyway)
+  if (grid_cap < 1) {
+    static size_t occ_lds = ~(size_t)0;
+    static int occ = 1;
+    if (occ_lds != off) {
+      int o = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)kfn, 64 * OT * IT * PS * TS, off) != hipSuccess || o < 1)
+        o = 1;
+      occ = o;
+      occ_lds = off;
+    }
+    grid_cap = occ * device_cus();
+  }
+  int gx = grid_cap / blocks;
+  if (gx < 1) gx = 1;
+  if (gx > P.total_tiles) gx = P.total_tiles;
+  dim3 grid(gx, blocks);
   ISTGCN_LAUNCH(kfn, grid, dim3(64 * OT * IT * PS * TS), off, stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
+}
+
+template <typename T, int JT, int OT, int IT, int PS, bool AGG>
+int launch_cfg(TwgParams& P, int grid_cap, hipStream_t stream) {
+  // whole 16-byte channel vectors everywhere (every layer but the 3-channel input) or the element-wise variant
+  constexpr int EPL = Elem<T>::EPL;
+  if (P.Cin % EPL == 0 && P.Cout % EPL == 0) return launch_vec<T, JT, OT, IT, PS, AGG, true>(P, grid_cap, stream);
+  return launch_vec<T, JT, OT, IT, PS, AGG, false>(P, grid_cap, stream);
 }
 
 template <typename T, int JT, bool AGG>
@@ -562,7 +668,6 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   P.pre_relu = pre_relu;
   for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
   for (int j = ntaps; j < MAX_TAPS; ++j) P.tap_off[j] = tap_off[0];    // padding taps: valid addresses, never flushed
-  if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }
@@ -578,7 +683,17 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
   TwgParams P{};
   P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
   P.NM = NM; P.Tin = T; P.Tz = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = K; P.in_mul = 1;
-  if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_agg_T<float>(P, grid_cap, (hipStream_t)stream);
   return launch_agg_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }
+
+#ifdef ISTGCN_STAMP
+extern "C" int istgcn_debug_stamps_wgrad(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_wg), 8 * sizeof(unsigned long long)) != hipSuccess) return ISTGCN_ELAUNCH;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wg), z, sizeof(z)) != hipSuccess) return ISTGCN_ELAUNCH;
+  }
+  return ISTGCN_OK;
+}
+#endif
