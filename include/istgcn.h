@@ -66,7 +66,8 @@ int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const voi
                         float* dA, int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap, int dtype,
                         int grid_cap, void* stream);
 int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V, int Cin,
-                     int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream);
+                     int Cout, int K, int nnz_cap, int dtype, int grid_cap, float* ws, long long ws_floats,
+                     void* stream);
 
 /* Temporal (k,1) convolution over the frame axis as an implicit GEMM (and its data gradient):
  *   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) ),
@@ -96,7 +97,7 @@ int istgcn_tconv(const void* in, const void* Wp, const float* bias, const float*
  *   dW [ntaps][Cout][Cin] fp32 and dbias [Cout] fp32 (or NULL) are ACCUMULATED into: the caller zeroes them. */
 int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, float* dbias,
                        int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
-                       int in_mul, int dtype, int grid_cap, void* stream);
+                       int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats, void* stream);
 
 /* BatchNorm2d bookkeeping (train-mode statistics are batch sums the MFMA kernels emit in their epilogues).
  * istgcn_bn_finalize: stats [rep][2][C] fp64 (sum, sum of squares) over `count` elements per channel ->

@@ -15,7 +15,7 @@
 #include "common.hpp"
 
 #ifdef ISTGCN_STAMP
-__device__ unsigned long long g_stamp_wg[8];
+__device__ unsigned long long g_stamp_wg[16];
 #define STAMP(i)                                                                                   \
   do {                                                                                             \
     unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
@@ -46,7 +46,12 @@ struct TwgParams {
   int NM, Tin, Tz, V, Cin, Cout, ntaps, in_mul, pre_relu;
   int tap_off[MAX_TAPS];
   int F, tiles_per_seq, total_tiles, min_off, Fin, n_iblk, urows;
+  int capf;              // frames the u region holds (>= Fin): > Fin lets the halo window slide instead of being re-staged
   int off_urow, off_dz, off_u;   // LDS byte offsets
+  // optional partial-sum workspace: slice s = [ntaps*Cout*Cin | aux] fp32, one slice per (workgroup.x, position slice);
+  // a second kernel sums the slices (no same-address atomic chains).  null: flush with atomics.
+  float* ws;
+  long long ws_slice;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -150,7 +155,7 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
 // TS = tap split: the taps of one (o-tile, i-tile, position-slice) are divided over TS waves (workgroup = 4*TS waves), so
 // a wave keeps ceil(JT/TS) accumulator tiles: twice the waves per CU at the same LDS footprint for the 9/15-tap layers.
 template <typename T, int JT, int OT, int IT, int PS, bool AGG, int TS, bool VEC>
-__global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(const TwgParams P) {
+__global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgrad_kernel(const TwgParams P) {
   static_assert(OT * IT * PS == 4 || OT * IT * PS == 8, "one (o-tile, i-tile, position-slice) per wave group");
   constexpr int NWG = OT * IT * PS;                // waves per tap group
   constexpr int NTH = 64 * NWG * TS;
@@ -261,19 +266,28 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
   const T* gg = reinterpret_cast<const T*>(P.g);
   const int dz_sub = P.dz_rows * CB;               // sub-tile stride of the dz / x staging region
   const T* dz_w = dzs + ot * dz_sub;
-  const T* us_w = us + it * u_sub;
   typedef typename E::frag frag_t;
   constexpr int QV = CB / EPL;
 
 #ifdef ISTGCN_STAMP
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
 #endif
   // ---- register prefetch of the next tile's global data (issued before the MFMA loop, consumed after it) ----
   constexpr int UZ = (TR * OT * QV + NTH - 1) / NTH;      // dz tile vectors per thread (exact cover)
   constexpr int UX = (TR * IT * QV + NTH - 1) / NTH;      // AGG: x tile vectors per thread
-  constexpr int UH = (336 * IT * QV + NTH - 1) / NTH;     // u halo tile (<= 336 rows in the common layers) ...
-  constexpr int UU = AGG ? UX : (UH < 8 ? UH : 8);        // ... prefetched; larger halos finish synchronously
+  constexpr int UH = (264 * IT * QV + NTH - 1) / NTH;     // u rows fetched per tile (new frames of the sliding window) ...
+  constexpr int UU = AGG ? UX : (UH < 8 ? UH : 8);        // ... prefetched; anything beyond finishes synchronously
   frag_t pz[UZ], pu[UU];
+  // A workgroup walks CONSECUTIVE tiles (frames m0, m0+F, ... of one sequence, then the next sequence): the halo'd u
+  // window of a tile overlaps its predecessor's in Fin - in_mul*F frames, which stay in LDS; only the new frames are
+  // fetched and transformed.  The window slides through a region of capf frames and is moved back to the front when it
+  // reaches the end.  A tile is "fresh" (whole window staged) at a sequence start or when the region has no slack.
+  const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
+  const int adv = P.in_mul * P.F, keep = P.Fin - adv;
+  const bool slide = !AGG && keep > 0 && P.capf >= P.Fin + adv;
+  const int keep_items = keep * V * IT * QV;
+  auto is_fresh = [&](int tile) { return !slide || tile == t_begin || tile % P.tiles_per_seq == 0; };
   auto prefetch = [&](int tile) {
     const int n = tile / P.tiles_per_seq;
     const int m0 = (tile - n * P.tiles_per_seq) * P.F;
@@ -294,12 +308,15 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
       const int r_lo = fin0 < 0 ? -fin0 * V : 0;
       const int r_hi = min(in_rows, (P.Tin - fin0) * V);
       const T* src = gg + row0 * P.Cin + i0;
-      load_subtiles<T, UU, VEC>(pu, src, (size_t)P.Cin, P.Cin - i0, in_rows, r_lo, r_hi, IT, 0, tid, NTH);
+      load_subtiles<T, UU, VEC>(pu, src, (size_t)P.Cin, P.Cin - i0, in_rows, r_lo, r_hi, IT, is_fresh(tile) ? 0 : keep_items,
+                                tid, NTH);
     }
   };
-  if ((int)blockIdx.x < P.total_tiles) prefetch(blockIdx.x);
+  if (t_begin < t_end) prefetch(t_begin);
+  int wslot = 0;                                          // frame slot of the current window in the u region
+  const T* us_w = us + it * u_sub;
 
-  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
+  for (int tile = t_begin; tile < t_end; ++tile) {
     STAMP(0);
     const int n = tile / P.tiles_per_seq;
     const int m0 = (tile - n * P.tiles_per_seq) * P.F;
@@ -307,7 +324,11 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
     const int rows = nf * V;
     const int fin0 = P.in_mul * m0 + P.min_off;
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;
-    const int next_tile = tile + gridDim.x;
+    const int next_tile = tile + 1;
+#ifdef ISTGCN_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);
+#endif
 
     if constexpr (AGG) {
       // ---- x tile -> dz region, K aggregated images -> us, then the dz tile over the x tile ----
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
       __syncthreads();
       commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
       __syncthreads();
-      if (next_tile < P.total_tiles) prefetch(next_tile);
+      if (next_tile < t_end) prefetch(next_tile);
       if (P.S && iblk == 0) {
         constexpr int NC = OT * CB;
         for (int idx = tid; idx < V * NC; idx += NTH) {
@@ -403,22 +424,43 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
     } else {
     // ---- dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
       commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
+      STAMP(8);
       for (int r = tid; r < TR; r += NTH)
         urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
+      STAMP(9);
       {
+        const bool fresh = is_fresh(tile);
+        if (fresh) wslot = 0;
+        else {
+          wslot += adv;
+          if (wslot + P.Fin > P.capf) {                   // window at the end of the region: overlap back to the front
+            for (int idx = tid; idx < keep_items; idx += NTH) {
+              const int q = idx % (IT * QV), r = idx / (IT * QV);
+              const int sub = q / QV, ql = q - sub * QV;
+              T* rowp = us + sub * u_sub + r * CB + ql * EPL;
+              *reinterpret_cast<frag_t*>(rowp) = *reinterpret_cast<const frag_t*>(rowp + wslot * V * CB);
+            }
+            wslot = 0;
+          }
+        }
+        T* uwin = us + wslot * V * CB;
+        us_w = uwin + it * u_sub;
+        const int it0 = fresh ? 0 : keep_items;
         const long long row0 = (long long)(n * P.Tin + fin0) * V;
         const int r_lo = fin0 < 0 ? -fin0 * V : 0;
         const int r_hi = min(in_rows, (P.Tin - fin0) * V);
         const float* sc = P.pre ? P.pre + i0 : nullptr;
         const float* sh = P.pre ? P.pre + P.Cin + i0 : nullptr;
         const T* src = gg + row0 * P.Cin + i0;
-        commit_subtiles<T, UU, VEC>(pu, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, 0, tid, NTH);
-        if (in_rows * IT * QV > UU * NTH) {            // halo larger than the prefetch registers cover
-          stage_subtiles<T, 4, VEC>(src, (size_t)P.Cin, P.Cin - i0, us, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, UU * NTH, tid, NTH);
+        commit_subtiles<T, UU, VEC>(pu, P.Cin - i0, uwin, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, it0, tid, NTH);
+        if (in_rows * IT * QV > it0 + UU * NTH) {          // more than the prefetch registers cover (fresh windows)
+          stage_subtiles<T, 4, VEC>(src, (size_t)P.Cin, P.Cin - i0, uwin, u_sub, in_rows, r_lo, r_hi, IT, sc, sh, P.pre_relu, it0 + UU * NTH, tid, NTH);
         }
       }
+      STAMP(10);
       __syncthreads();
-      if (next_tile < P.total_tiles) prefetch(next_tile);
+      STAMP(11);
+      if (next_tile < t_end) prefetch(next_tile);
     }
     STAMP(1);
     if (!AGG && P.dbias && iblk == 0) {
@@ -512,37 +554,109 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS) void tconv_wgrad_kernel(con
   const unsigned long long t_flush0 = __builtin_amdgcn_s_memtime();
 #endif
 
-  // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per atomic instruction ----
+  // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per instruction ----
+  if (P.ws) {
+    float* sl = P.ws + (size_t)(blockIdx.x * PS + ps) * P.ws_slice;
 #pragma unroll
-  for (int jj = 0; jj < JTW; ++jj) {
-    const int j = ts * JTW + jj;
-    if (j < P.ntaps) {
+    for (int jj = 0; jj < JTW; ++jj) {
+      const int j = ts * JTW + jj;
+      if (j < P.ntaps) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-        if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[jj][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+          if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[jj][r];
+        }
       }
     }
-  }
-  if (AGG && P.S && iblk == 0) {
-    constexpr int NC = OT * CB;
-    for (int idx = tid; idx < V * NC; idx += NTH) {
-      const int w = idx / NC, c = idx - w * NC;
-      if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[idx]);
+    if (iblk == 0) {
+      constexpr int NC = OT * CB;
+      float* aux = P.ws + (size_t)(blockIdx.x * PS) * P.ws_slice + (size_t)P.ntaps * P.Cout * P.Cin;
+      if (AGG && P.S) {
+        for (int idx = tid; idx < V * NC; idx += NTH) {
+          const int w = idx / NC, c = idx - w * NC;
+          if (o0 + c < P.Cout) {
+            aux[w * P.Cout + o0 + c] = S_l[idx];
+#pragma unroll
+            for (int p = 1; p < PS; ++p) aux[p * P.ws_slice + w * P.Cout + o0 + c] = 0.f;
+          }
+        }
+      }
+      if (!AGG && P.dbias) {
+        float* red = reinterpret_cast<float*>(dzs);       // tile loop is over: reuse the dz region
+        if (tid < NC) red[tid] = 0.f;
+        __syncthreads();
+        atomicAdd(red + tid % NC, bsum);
+        __syncthreads();
+        if (tid < NC && o0 + tid < P.Cout) {
+          aux[o0 + tid] = red[tid];
+#pragma unroll
+          for (int p = 1; p < PS; ++p) aux[p * P.ws_slice + o0 + tid] = 0.f;
+        }
+      }
     }
-  }
-  if (!AGG && P.dbias && iblk == 0) {
-    constexpr int NC = OT * CB;
-    if (NC == 32) bsum += __shfl_xor(bsum, 32);
-    const int c = tid % NC;
-    if ((NC == 64 || lane < 32) && o0 + c < P.Cout) atomicAdd(P.dbias + o0 + c, bsum);
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < JTW; ++jj) {
+      const int j = ts * JTW + jj;
+      if (j < P.ntaps) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+          if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[jj][r]);
+        }
+      }
+    }
+    if (AGG && P.S && iblk == 0) {
+      constexpr int NC = OT * CB;
+      for (int idx = tid; idx < V * NC; idx += NTH) {
+        const int w = idx / NC, c = idx - w * NC;
+        if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[idx]);
+      }
+    }
+    if (!AGG && P.dbias && iblk == 0) {
+      constexpr int NC = OT * CB;
+      if (NC == 32) bsum += __shfl_xor(bsum, 32);
+      const int c = tid % NC;
+      if ((NC == 64 || lane < 32) && o0 + c < P.Cout) atomicAdd(P.dbias + o0 + c, bsum);
+    }
   }
 #ifdef ISTGCN_STAMP
   if (lane == 0) {
     st_acc[6] += __builtin_amdgcn_s_memtime() - t_flush0;
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp_wg[i], st_acc[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_stamp_wg[i], st_acc[i]);
   }
 #endif
+}
+
+// dst[e] += sum over slices [s0, s1) of ws[s*slice + e]; float4 per thread, slices split over blockIdx.y
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, long long slice, int nsl,
+                                                           float* __restrict__ d0, int n0, float* __restrict__ d1,
+                                                           int n1) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n0 + n1) return;
+  const int per = (nsl + gridDim.y - 1) / gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = min(nsl, s0 + per);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool v4 = (slice % 4 == 0) && (n0 % 4 == 0) && (e + 3 < n0 + n1);
+  if (v4) {
+    const float* src = ws + e;
+#pragma unroll 4
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)s * slice);
+      a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+    }
+  } else {
+    for (int s = s0; s < s1; ++s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (e + k < n0 + n1) a[k] += ws[(size_t)s * slice + e + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ek = e + k;
+    if (ek < n0) atomicAdd(d0 + ek, a[k]);
+    else if (ek < n0 + n1 && d1) atomicAdd(d1 + (ek - n0), a[k]);
+  }
 }
 
 template <typename T, int JT, int OT, int IT, int PS, bool AGG, bool VEC>
@@ -551,6 +665,7 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   const int esz = sizeof(T);
   P.n_iblk = ceil_div(P.Cin, IT * CB);
   const int n_oblk = ceil_div(P.Cout, OT * CB);
+  P.capf = P.Fin;
   P.urows = AGG ? P.ntaps * TR : P.Fin * P.V;
   size_t off = (size_t)2 * TR * 2;
   off = (off + 15) & ~(size_t)15; P.off_urow = (int)off;
@@ -564,7 +679,19 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.dz_rows = mfma_agg ? TR + 32 : TR;             // MFMA aggregation reads a 32-row k-range per frame: zero rows behind
   if (mfma_agg) { off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)P.ntaps * 2 * 64 * 16; }
   off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)(AGG && IT > OT ? IT : OT) * P.dz_rows * CB * esz;
-  off = (off + 15) & ~(size_t)15; P.off_u = (int)off; off += (size_t)IT * P.urows * CB * esz;
+  off = (off + 15) & ~(size_t)15; P.off_u = (int)off;
+  if (!AGG && JT >= 9) {
+    // one workgroup per CU anyway (accumulator registers): spend the LDS on slack for the sliding u window
+    const int adv = P.in_mul * P.F;
+    for (int n_adv = 3; n_adv >= 1; --n_adv)
+      if (P.Fin > adv && (n_adv + 1) * adv >= P.Fin - adv &&      // move-back source and destination stay disjoint
+          off + (size_t)IT * (P.Fin + n_adv * adv) * P.V * CB * esz <= 150 * 1024) {
+        P.capf = P.Fin + n_adv * adv;
+        P.urows = P.capf * P.V;
+        break;
+      }
+  }
+  off += (size_t)IT * P.urows * CB * esz;
   if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
   const int blocks = n_oblk * P.n_iblk;
   auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG, TS, VEC>;
@@ -592,8 +719,21 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   dim3 grid(gx, blocks);
+  const int n0 = P.ntaps * P.Cout * P.Cin, n1 = AGG ? P.V * P.Cout : P.Cout;
+  float* aux_dst = AGG ? P.S : P.dbias;
+  const int nsl = gx * PS;
+  if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;   // too small / atomics are as fast
+  P.ws_slice = n0 + n1;
   ISTGCN_LAUNCH(kfn, grid, dim3(64 * OT * IT * PS * TS), off, stream, P);
   ISTGCN_CHECK_LAUNCH();
+  if (P.ws) {
+    int ny = nsl / 16;
+    ny = ny < 1 ? 1 : (ny > 16 ? 16 : ny);
+    dim3 rgrid(ceil_div(n0 + (aux_dst ? n1 : 0), 1024), ny);
+    ISTGCN_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)P.ws, P.ws_slice, nsl, P.dW, n0,
+                  aux_dst, aux_dst ? n1 : 0);
+    ISTGCN_CHECK_LAUNCH();
+  }
   return ISTGCN_OK;
 }
 
@@ -656,7 +796,8 @@ int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
 
 extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW,
                                   float* dbias, int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps,
-                                  const int* tap_off, int in_mul, int dtype, int grid_cap, void* stream) {
+                                  const int* tap_off, int in_mul, int dtype, int grid_cap, float* ws,
+                                  long long ws_floats, void* stream) {
   if (!dz || !g || !dW || !tap_off) return ISTGCN_EINVAL;
   if (ntaps < 1 || ntaps > 15 || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1 || NM < 0 || Tz < 0)
     return ISTGCN_EINVAL;
@@ -666,6 +807,7 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;
   P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps; P.in_mul = in_mul;
   P.pre_relu = pre_relu;
+  P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;     // capacity until the launcher sets the slice length
   for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
   for (int j = ntaps; j < MAX_TAPS; ++j) P.tap_off[j] = tap_off[0];    // padding taps: valid addresses, never flushed
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
@@ -674,7 +816,8 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
 
 // Graph-conv weight gradient: same kernel, the K "taps" being the K adjacency partitions (aggregated images of x).
 extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,
-                                int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
+                                int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, float* ws,
+                                long long ws_floats, void* stream) {
   if (!dy || !x || !A || !dW) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
   if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
@@ -683,15 +826,16 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
   TwgParams P{};
   P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
   P.NM = NM; P.Tin = T; P.Tz = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = K; P.in_mul = 1;
+  P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;
   if (dtype == 0) return launch_agg_T<float>(P, grid_cap, (hipStream_t)stream);
   return launch_agg_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }
 
 #ifdef ISTGCN_STAMP
-extern "C" int istgcn_debug_stamps_wgrad(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_wg), 8 * sizeof(unsigned long long)) != hipSuccess) return ISTGCN_ELAUNCH;
+extern "C" int istgcn_debug_stamps_wgrad(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_wg), 16 * sizeof(unsigned long long)) != hipSuccess) return ISTGCN_ELAUNCH;
   if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wg), z, sizeof(z)) != hipSuccess) return ISTGCN_ELAUNCH;
   }
   return ISTGCN_OK;

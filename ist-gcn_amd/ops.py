@@ -184,6 +184,19 @@ def conv_taps_bwd(k, stride, phase):
     return [(j, (phase + pad - j) // stride) for j in range(k) if (phase + pad - j) % stride == 0]
 
 
+_WGRAD_WS = {}
+WGRAD_WS_FLOATS = 16 << 20          # 64 MiB per device: per-workgroup partial sums of the weight-gradient kernels
+
+
+def _wgrad_ws(dev):
+    """Partial-sum workspace of the wgrad kernels: one per (device, stream), so launches that can overlap never share."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=dev)
+    return ws
+
+
 def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=True, grid_cap=0):
     """istgcn_tconv_wgrad -> (dWf [ntaps][Cout][Cin] fp32, dbias [Cout] fp32 or None)."""
     NM, Tz, V, Cout = dz.shape
@@ -195,7 +208,8 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
     db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
     _check_dev(dz, g, pre, dW, db)
     _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
-          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap, _stream(dz),
+          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap,
+          _ptr(_wgrad_ws(dz.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dz),
           work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)))
     return dW, db
 
@@ -259,7 +273,7 @@ def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0):
         nnz_cap = K * V * V
     _check_dev(dy, x, A, dW, S)
     _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(dW), _ptr(S), NM, T, V, Cin, Cout, K, int(nnz_cap),
-          dtype_code(dy), grid_cap, _stream(dy),
+          dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dev)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
           work=(2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)))
     return dW, S
 
