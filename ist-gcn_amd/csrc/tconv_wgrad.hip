@@ -13,6 +13,8 @@
 // position axis straight from the row-major image); fp32 operand registers are double buffered so LDS latency
 // hides behind the MFMAs of the previous k-step.
 #include "common.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 #ifdef ISTGCN_STAMP
 __device__ unsigned long long g_stamp_wg[16];
@@ -42,7 +44,7 @@ struct TwgParams {
   // graph-conv mode (AGG): the "taps" are the K adjacency partitions, u_k = sum_v A[k][v][w] x[(t,v)][:]
   const float* A;        // [K][V][V]
   float* S;              // [V][Cout] or null: sum_{n,t} dz[n,t,w,c]
-  int nnz_cap, off_csr_v, off_csr_a, off_S, off_afrag, dz_rows;
+  int nnz_cap, off_csr_v, off_csr_a, off_S, off_afrag, dz_rows, mfma_agg;
   int NM, Tin, Tz, V, Cin, Cout, ntaps, in_mul, pre_relu;
   int tap_off[MAX_TAPS];
   int F, tiles_per_seq, total_tiles, min_off, Fin, n_iblk, urows;
@@ -155,7 +157,7 @@ __device__ static inline void stage_subtiles(const T* __restrict__ g, size_t gst
 // TS = tap split: the taps of one (o-tile, i-tile, position-slice) are divided over TS waves (workgroup = 4*TS waves), so
 // a wave keeps ceil(JT/TS) accumulator tiles: twice the waves per CU at the same LDS footprint for the 9/15-tap layers.
 template <typename T, int JT, int OT, int IT, int PS, bool AGG, int TS, bool VEC>
-__global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgrad_kernel(const TwgParams P) {
+__global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4 : 1) void tconv_wgrad_kernel(const TwgParams P) {
   static_assert(OT * IT * PS == 4 || OT * IT * PS == 8, "one (o-tile, i-tile, position-slice) per wave group");
   constexpr int NWG = OT * IT * PS;                // waves per tap group
   constexpr int NTH = 64 * NWG * TS;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
   int* csr_off = reinterpret_cast<int*>(smem + P.off_urow);                       // [K*V+1] (aliases urow: unused in AGG)
   unsigned char* csr_v = smem + P.off_csr_v;
   float* csr_a = reinterpret_cast<float*>(smem + P.off_csr_a);
-  float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][OT*CB]
+  float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][OT*CB + 1]
+  constexpr int SLS = OT * CB + 1;                                                 // odd stride: joints land in different banks
   T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // AGG bf16: [K][2][64][8] fragments of A_k
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
     float* A_l = reinterpret_cast<float*>(us);
     for (int i = tid; i < K * V * V; i += NTH) A_l[i] = P.A[i];
     for (int c = tid; c <= KV; c += NTH) csr_off[c] = 0;
-    for (int c = tid; c < V * OT * CB; c += NTH) S_l[c] = 0.f;
+    for (int c = tid; c < V * SLS; c += NTH) S_l[c] = 0.f;
     __syncthreads();
     for (int col = tid; col < KV; col += NTH) {
       int k = col / V, w = col - k * V, cnt = 0;
@@ -209,18 +212,20 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
       csr_off[KV] = run;
     }
     __syncthreads();
-    for (int col = tid; col < KV; col += NTH) {
-      int k = col / V, w = col - k * V, e = csr_off[col];
-      for (int v = 0; v < V; ++v) {
-        float a = A_l[(k * V + v) * V + w];
-        if (a != 0.f) {
-          if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
-          ++e;
+    if (!P.mfma_agg) {                         // VALU aggregation (the MFMA one reads A fragments instead)
+      for (int col = tid; col < KV; col += NTH) {
+        int k = col / V, w = col - k * V, e = csr_off[col];
+        for (int v = 0; v < V; ++v) {
+          float a = A_l[(k * V + v) * V + w];
+          if (a != 0.f) {
+            if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
+            ++e;
+          }
         }
       }
     }
     if constexpr (sizeof(T) == 2) {
-      if (P.dz_rows > TR) {
+      if (P.mfma_agg) {
         // fragments of A_k for the MFMA aggregation (lane (w = lane&31, h), k-step s, element j = A[k][16s+8h+j][w])
         // and the zero rows behind every x sub-tile
         for (int idx = tid; idx < K * 2 * 64; idx += NTH) {
@@ -235,8 +240,9 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
           *reinterpret_cast<typename E::frag*>(afrag + idx * EPL) = fr;
         }
         constexpr int NSUB = IT > OT ? IT : OT;
-        for (int idx = tid; idx < NSUB * 32 * (CB / EPL); idx += NTH) {
-          const int sub = idx / (32 * (CB / EPL)), rem = idx - sub * (32 * (CB / EPL));
+        const int ztail = (P.dz_rows - TR) * (CB / EPL);
+        for (int idx = tid; idx < NSUB * ztail; idx += NTH) {
+          const int sub = idx / ztail, rem = idx - sub * ztail;
           typename E::frag z;
           zero_frag<T>(z);
           *reinterpret_cast<typename E::frag*>(dzs + (sub * P.dz_rows + TR) * CB + rem * EPL) = z;
@@ -251,7 +257,14 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
   for (int j = 0; j < JTW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float bsum = 0.f;
+  // column sums of dz (conv bias gradient / S of the graph conv) are taken from the prefetch registers at commit time:
+  // a thread's channel vector q is the same for all its rows.  With several i-blocks the vectors are dealt out over them.
+  float bs[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) bs[e] = 0.f;
+  constexpr int QZ = OT * (CB / EPL);
+  const bool aux_any = P.ws ? iblk == 0 : iblk < (TR * QZ + NTH - 1) / NTH;     // i-blocks that own some vector
+  auto aux_own = [&](int u) { return P.ws ? iblk == 0 : (u % P.n_iblk == iblk); };
 
   // per-tap element offset into a u sub-tile (taps beyond ntaps alias tap 0: computed, never flushed)
   int toff[JTW];
@@ -333,17 +346,20 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
     if constexpr (AGG) {
       // ---- x tile -> dz region, K aggregated images -> us, then the dz tile over the x tile ----
       commit_subtiles<T, UU, VEC>(pu, P.Cin - i0, dzs, dz_sub, TR, 0, rows, IT, nullptr, nullptr, 0, 0, tid, NTH);
+      STAMP(8);
       __syncthreads();
+      STAMP(9);
       const int K = P.ntaps, KV = K * V;
       {
         bool agg_done = false;
-        if constexpr (sizeof(T) == 2) if (P.dz_rows > TR) {
+        if constexpr (sizeof(T) == 2) if (P.mfma_agg) {
           // bf16: D[i][w] = sum_v x[(f,v)][i] * A_k[v][w] on the matrix cores, x^T via ds_read_b64_tr_b16 (as gcn_fwd)
           agg_done = true;
           const int grp = lane >> 4, hh = grp >> 1, cblk = (grp & 1) * 16;
           const int q4 = (lane & 15) >> 2, pp = lane & 3;
           const int w = lane & 31;
-          for (int pr = wave; pr < IT * nf; pr += NWG * TS) {
+          for (int unit = wave; unit < IT * nf * K; unit += NWG * TS) {     // (sub-tile, frame, partition) units
+            const int k = unit % K, pr = unit / K;
             const int sub = pr / nf, f = pr - sub * nf;
             bf16x8 a[2];
 #pragma unroll
@@ -351,20 +367,18 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
               const T* r0 = dzs + (sub * P.dz_rows + f * V + 16 * sstep + 8 * hh + q4) * CB + cblk + 4 * pp;
               a[sstep] = tr_pair(r0, r0 + 4 * CB);
             }
-            for (int k = 0; k < K; ++k) {
-              f32x16 d;
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
+            f32x16 d;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) d[r] = 0.f;
-              const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
-              const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
-              if (w < V) {
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
+            if (w < V) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-                  store4(us + ((sub * K + k) * TR + f * V + w) * CB + 8 * g + 4 * (lane >> 5), v4);
-                }
+              for (int g = 0; g < 4; ++g) {
+                float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                store4(us + ((sub * K + k) * TR + f * V + w) * CB + 8 * g + 4 * (lane >> 5), v4);
               }
             }
           }
@@ -407,23 +421,48 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
           *reinterpret_cast<frag_t*>(us + (sk * TR + r) * CB + q * EPL) = o;
         }
       }
+      STAMP(10);
       __syncthreads();
+      STAMP(11);
       commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
       __syncthreads();
+      STAMP(12);
       if (next_tile < t_end) prefetch(next_tile);
-      if (P.S && iblk == 0) {
+      STAMP(13);
+      if (P.S) {
+        // S[w][c] += sum_f dz[(f,w)][c]: column sums of the staged tile, (w,c) cells dealt out over the i-blocks;
+        // the frame reads are issued together (a serial chain of LDS latencies costs more than the MFMA loop)
         constexpr int NC = OT * CB;
-        for (int idx = tid; idx < V * NC; idx += NTH) {
-          const int w = idx / NC, c = idx - w * NC;
-          const T* col = dzs + (c / CB) * dz_sub + (c % CB);
-          float sacc = 0.f;
-          for (int f = 0; f < nf; ++f) sacc += E::to_f(col[(f * V + w) * CB]);
-          S_l[idx] += sacc;
+        const int n_own = P.ws ? 1 : P.n_iblk, me = P.ws ? 0 : iblk;
+        if (!P.ws || iblk == 0) {
+          for (int idx = tid + me * NTH; idx < V * NC; idx += NTH * n_own) {
+            const int w = idx / NC, c = idx - w * NC;
+            const T* col = dzs + (c / CB) * dz_sub + (c % CB) + w * CB;
+            float sacc = 0.f;
+            for (int f0 = 0; f0 < nf; f0 += 8) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = f0 + j < nf ? E::to_f(col[(f0 + j) * V * CB]) : 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) sacc += v[j];
+            }
+            S_l[w * SLS + c] += sacc;
+          }
         }
       }
     } else {
     // ---- dz tile (zero pad rows) and the u tile with halo: pre(g), zero outside the sequence ----
       commit_subtiles<T, UZ, VEC>(pz, P.Cout - o0, dzs, dz_sub, TR, 0, rows, OT, nullptr, nullptr, 0, 0, tid, NTH);
+      if (P.dbias) {
+#pragma unroll
+        for (int u = 0; u < UZ; ++u) {
+          const int item = tid + u * NTH;
+          if (aux_own(u) && item / QZ < rows) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) bs[e] += E::to_f(pz[u][e]);
+          }
+        }
+      }
       STAMP(8);
       for (int r = tid; r < TR; r += NTH)
         urow[r] = r < rows ? (unsigned short)((P.in_mul * row_f[r]) * V + row_v[r]) : (unsigned short)0;
@@ -463,12 +502,6 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
       if (next_tile < t_end) prefetch(next_tile);
     }
     STAMP(1);
-    if (!AGG && P.dbias && iblk == 0) {
-      constexpr int NC = OT * CB;
-      const int c = tid % NC;
-      const T* col = dzs + (c / CB) * dz_sub + (c % CB);
-      for (int r = tid / NC; r < rows; r += NTH / NC) bsum += E::to_f(col[r * CB]);
-    }
 
     STAMP(2);
     // ---- D_j[o][i] += dz[p][o] * u[row(p) + tap_j][i] over this wave's positions ----
@@ -554,6 +587,16 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
   const unsigned long long t_flush0 = __builtin_amdgcn_s_memtime();
 #endif
 
+  float* red = reinterpret_cast<float*>(dzs);             // tile loop is over: reuse the dz region
+  if (!AGG && P.dbias && aux_any) {
+    constexpr int NC = OT * CB;
+    if (tid < NC) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) atomicAdd(red + (tid % QZ) * EPL + e, bs[e]);
+    __syncthreads();
+  }
+
   // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per instruction ----
   if (P.ws) {
     float* sl = P.ws + (size_t)(blockIdx.x * PS + ps) * P.ws_slice;
@@ -575,18 +618,13 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
         for (int idx = tid; idx < V * NC; idx += NTH) {
           const int w = idx / NC, c = idx - w * NC;
           if (o0 + c < P.Cout) {
-            aux[w * P.Cout + o0 + c] = S_l[idx];
+            aux[w * P.Cout + o0 + c] = S_l[w * SLS + c];
 #pragma unroll
             for (int p = 1; p < PS; ++p) aux[p * P.ws_slice + w * P.Cout + o0 + c] = 0.f;
           }
         }
       }
       if (!AGG && P.dbias) {
-        float* red = reinterpret_cast<float*>(dzs);       // tile loop is over: reuse the dz region
-        if (tid < NC) red[tid] = 0.f;
-        __syncthreads();
-        atomicAdd(red + tid % NC, bsum);
-        __syncthreads();
         if (tid < NC && o0 + tid < P.Cout) {
           aux[o0 + tid] = red[tid];
 #pragma unroll
@@ -606,18 +644,16 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, AGG ? 4 : 1) void tconv_wgr
         }
       }
     }
-    if (AGG && P.S && iblk == 0) {
+    if (AGG && P.S) {                                    // every i-block owns some (w,c) cells (zeros otherwise)
       constexpr int NC = OT * CB;
       for (int idx = tid; idx < V * NC; idx += NTH) {
         const int w = idx / NC, c = idx - w * NC;
-        if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[idx]);
+        if (o0 + c < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + c, S_l[w * SLS + c]);
       }
     }
-    if (!AGG && P.dbias && iblk == 0) {
+    if (!AGG && P.dbias && aux_any) {
       constexpr int NC = OT * CB;
-      if (NC == 32) bsum += __shfl_xor(bsum, 32);
-      const int c = tid % NC;
-      if ((NC == 64 || lane < 32) && o0 + c < P.Cout) atomicAdd(P.dbias + o0 + c, bsum);
+      if (tid < NC && o0 + tid < P.Cout) atomicAdd(P.dbias + o0 + tid, red[tid]);
     }
   }
 #ifdef ISTGCN_STAMP
@@ -670,13 +706,17 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   size_t off = (size_t)2 * TR * 2;
   off = (off + 15) & ~(size_t)15; P.off_urow = (int)off;
   off += AGG ? (size_t)(P.ntaps * P.V + 1) * 4 : (size_t)TR * 2;
-  if (AGG) {
-    off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
-    off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
-    off = (off + 15) & ~(size_t)15; P.off_S = (int)off; off += (size_t)P.V * OT * CB * 4;
-  }
   const bool mfma_agg = AGG && esz == 2 && P.V <= 32;
-  P.dz_rows = mfma_agg ? TR + 32 : TR;             // MFMA aggregation reads a 32-row k-range per frame: zero rows behind
+  P.mfma_agg = mfma_agg;
+  if (AGG) {
+    if (!mfma_agg) {                               // compressed adjacency columns: only the VALU aggregation reads them
+      off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
+      off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
+    }
+    off = (off + 15) & ~(size_t)15; P.off_S = (int)off; off += (size_t)P.V * (OT * CB + 1) * 4;
+  }
+  // MFMA aggregation reads a 32-row k-range per frame: zero rows behind the last frame
+  P.dz_rows = mfma_agg ? (TR > (P.F - 1) * P.V + 32 ? TR : (P.F - 1) * P.V + 32) : TR;
   if (mfma_agg) { off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)P.ntaps * 2 * 64 * 16; }
   off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += (size_t)(AGG && IT > OT ? IT : OT) * P.dz_rows * CB * esz;
   off = (off + 15) & ~(size_t)15; P.off_u = (int)off;
@@ -719,6 +759,11 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   dim3 grid(gx, blocks);
+  static const bool dbg = getenv("ISTGCN_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[istgcn] wgrad<%s JT=%d OT=%d IT=%d PS=%d TS=%d %s> Cin=%d Cout=%d taps=%d grid=(%d,%d) lds=%zu capf=%d Fin=%d\n",
+            esz == 2 ? "bf16" : "f32", JT, OT, IT, PS, TS, AGG ? "agg" : "conv", P.Cin, P.Cout, P.ntaps, gx, blocks, off,
+            P.capf, P.Fin);
   const int n0 = P.ntaps * P.Cout * P.Cin, n1 = AGG ? P.V * P.Cout : P.Cout;
   float* aux_dst = AGG ? P.S : P.dbias;
   const int nsl = gx * PS;

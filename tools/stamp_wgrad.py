@@ -7,7 +7,8 @@ from istgcn_amd.net.utils.graph import Graph
 lib = _lib.load()
 d = torch.device('cuda:0'); dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
 gr = Graph('ntu-rgb+d', 'spatial_3'); A = torch.tensor(gr.A + gr.A2 + gr.A3, dtype=torch.float32, device=d); cap = int((A != 0).sum())
-names = ['tile setup', 'prefetch issue / agg', 'dbias', 'MFMA loop', 'barrier', 'tail', 'flush', 'load wait', 'commit dz', 'urow', 'commit u', 'barrier1']
+names = ['tile setup', 'prefetch issue / agg', 'dbias', 'MFMA loop', 'barrier', 'tail', 'flush', 'load wait', 's8', 's9', 's10', 's11', 's12', 's13']
+# s8..s13 -- tconv: commit dz, urow, commit u, barrier | gcn: commit x, barrier, aggregate, barrier, commit dz+barrier, prefetch issue (s1 = S sums)
 for c, T in ((64, 300), (128, 150), (256, 75)):
     NM, V, k = 128, 25, 9
     g = torch.randn(NM, T, V, c, device=d).to(dt)
@@ -21,5 +22,5 @@ for c, T in ((64, 300), (128, 150), (256, 75)):
         for _ in range(5): f()
         torch.cuda.synchronize()
         lib.istgcn_debug_stamps_wgrad(out, 1)
-        v = list(out); tot = sum(v[:12]) or 1
-        print('C=%d %s: ' % (c, tag) + ', '.join('%s %.1f%%' % (n, 100 * x / tot) for n, x in zip(names, v[:12])), flush=True)
+        v = list(out); tot = sum(v[:14]) or 1
+        print('C=%d %s: ' % (c, tag) + ', '.join('%s %.1f%%' % (n, 100 * x / tot) for n, x in zip(names, v[:14])), flush=True)
