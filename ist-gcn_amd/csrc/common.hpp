@@ -220,6 +220,26 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
     hipLaunchKernelGGL(__VA_ARGS__);  \
   } while (0)
 
+// Workgroups of `kfn` resident on the whole device at once (occupancy x CUs).  The persistent kernels launch exactly
+// that many: every extra workgroup repeats the per-workgroup prologue (adjacency tables) / flush and waits for a slot
+// anyway.  Cached per (kernel, block size, LDS bytes); thread_local so DataParallel's per-device threads never race.
+inline int istgcn_resident_blocks(const void* kfn, int threads, size_t lds) {
+  struct Entry { const void* k; int threads; size_t lds; int blocks; };
+  thread_local Entry cache[64];
+  thread_local int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (cache[i].k == kfn && cache[i].threads == threads && cache[i].lds == lds) return cache[i].blocks;
+  int dev = 0, cus = 0, occ = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, threads, lds) != hipSuccess || occ < 1) occ = 1;
+  (void)hipGetLastError();
+  const int blocks = occ * cus;
+  if (n < 64) cache[n++] = Entry{kfn, threads, lds, blocks};
+  return blocks;
+}
+
 #define ISTGCN_CHECK_LAUNCH()                         \
   do {                                                \
     hipError_t e_ = hipGetLastError();                \

@@ -365,7 +365,7 @@ inline void gbd_geom(int Cin, int Cout, int K, int dtype, GbdGeom* G) {
 }
 
 template <typename T, int MTK>
-int launch_mtk(GbdParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+int launch_mtk(GbdParams& P, int grid_cap, size_t lds, hipStream_t stream) {
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
 #define GO(VV)                                                                                              \
   do {                                                                                                      \
@@ -376,7 +376,9 @@ int launch_mtk(GbdParams& P, dim3 grid, size_t lds, hipStream_t stream) {
       if (ea_ != hipSuccess) return 2000 + (int)ea_;                                                        \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                               \
+    int gx = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS, lds);             \
+    gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
+    ISTGCN_LAUNCH(kfn, dim3(gx), dim3(NTHREADS), lds, stream, P);                                           \
   } while (0)
   if (vec) GO(true); else GO(false);
 #undef GO
@@ -405,17 +407,15 @@ int launch_T(GbdParams& P, const GbdGeom& G, int grid_cap, hipStream_t stream) {
   size_t dxa = ((size_t)P.K * TR + 32) * P.CCi * esz, al = (size_t)P.K * P.V * P.V * 4;
   off += dxa > al ? dxa : al;
   if (off > 160 * 1024) return ISTGCN_EINVAL;
-  int gx = P.total_tiles < grid_cap ? P.total_tiles : grid_cap;
-  dim3 grid(gx);
   switch (G.MTK) {
-    case 1: return launch_mtk<T, 1>(P, grid, off, stream);
-    case 2: return launch_mtk<T, 2>(P, grid, off, stream);
-    case 3: return launch_mtk<T, 3>(P, grid, off, stream);
-    case 4: return launch_mtk<T, 4>(P, grid, off, stream);
-    case 5: return launch_mtk<T, 5>(P, grid, off, stream);
-    case 6: return launch_mtk<T, 6>(P, grid, off, stream);
-    case 7: return launch_mtk<T, 7>(P, grid, off, stream);
-    case 8: return launch_mtk<T, 8>(P, grid, off, stream);
+    case 1: return launch_mtk<T, 1>(P, grid_cap, off, stream);
+    case 2: return launch_mtk<T, 2>(P, grid_cap, off, stream);
+    case 3: return launch_mtk<T, 3>(P, grid_cap, off, stream);
+    case 4: return launch_mtk<T, 4>(P, grid_cap, off, stream);
+    case 5: return launch_mtk<T, 5>(P, grid_cap, off, stream);
+    case 6: return launch_mtk<T, 6>(P, grid_cap, off, stream);
+    case 7: return launch_mtk<T, 7>(P, grid_cap, off, stream);
+    case 8: return launch_mtk<T, 8>(P, grid_cap, off, stream);
     default: return ISTGCN_EINVAL;
   }
 }
@@ -445,7 +445,6 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;
   GbdGeom G;
   gbd_geom(Cin, Cout, K, dtype, &G);
-  if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
 }
 
 template <typename T, int MT>
-int launch_mt(const GcnFwdParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+int launch_mt(const GcnFwdParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   constexpr int EPL = Elem<T>::EPL;
   const bool vin = (P.Cin % EPL) == 0, vout = (P.Cout % EPL) == 0;
 #define GO(VI, VO)                                                                                          \
@@ -405,7 +405,9 @@ int launch_mt(const GcnFwdParams& P, dim3 grid, size_t lds, hipStream_t stream) 
       if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS), lds, stream, P);                                          \
+    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS, lds)) / gy;      \
+    gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
+    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS), lds, stream, P);                                       \
   } while (0)
   if (vin && vout) GO(true, true);
   else if (vin) GO(true, false);
@@ -448,14 +450,12 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   size_t ost = (size_t)TILE_ROWS * P.out_stride * sizeof(T);
   off += work > ost ? work : ost;
   if (off > 160 * 1024) return ISTGCN_EINVAL;
-  int gx = P.total_tiles < grid_x_cap ? P.total_tiles : grid_x_cap;
-  if (gx < 1) return ISTGCN_OK;
-  dim3 grid(gx, gy);
+  if (P.total_tiles < 1) return ISTGCN_OK;
   switch (MT) {
-    case 1: return launch_mt<T, 1>(P, grid, off, stream);
-    case 2: return launch_mt<T, 2>(P, grid, off, stream);
-    case 4: return launch_mt<T, 4>(P, grid, off, stream);
-    default: return launch_mt<T, 8>(P, grid, off, stream);
+    case 1: return launch_mt<T, 1>(P, grid_x_cap, gy, off, stream);
+    case 2: return launch_mt<T, 2>(P, grid_x_cap, gy, off, stream);
+    case 4: return launch_mt<T, 4>(P, grid_x_cap, gy, off, stream);
+    default: return launch_mt<T, 8>(P, grid_x_cap, gy, off, stream);
   }
 }
 
@@ -477,7 +477,6 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Tlog = Tlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K;
   P.in_t_stride = in_t_stride; P.out_t_stride = out_t_stride; P.nnz_cap = nnz_cap;
   P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
-  if (grid_cap < 1) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
   if (dtype == 1) return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
   return ISTGCN_EINVAL;

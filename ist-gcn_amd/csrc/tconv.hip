@@ -245,43 +245,58 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
           mrs[jj] = in ? P.maux[3 * P.Cout + cg + jj] : 0.f;
         }
         if (col_live) {
-          for (int p = tid / VPR; p < rows; p += RSTEP) {
-            size_t g;
-            if (dense_rows) g = out_base + (size_t)p * P.Cout + cg;
-            else g = ((size_t)(n * P.Tout + (m0 + row_f[p]) * P.out_mul + P.out_off) * V + row_v[p]) * P.Cout + cg;
-            frag_t sv = *reinterpret_cast<const frag_t*>(outs + p * P.out_stride + vq * EPL);
-            if (P.mode == 1) {
-              frag_t av;
-              if (VEC) av = *reinterpret_cast<const frag_t*>(auxg + g);
-              else {
+          // UB rows per batch: their LDS reads and (data gradient) aux loads are all issued before the first is used
+          constexpr int UB = 4;
+          for (int p0 = tid / VPR; p0 < rows; p0 += RSTEP * UB) {
+            frag_t sv[UB], av[UB];
+            size_t g[UB];
+            bool ok[UB];
 #pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) av[jj] = (cg + jj < P.Cout) ? auxg[g + jj] : E::from_f(0.f);
-              }
+            for (int u = 0; u < UB; ++u) {
+              const int p = p0 + u * RSTEP;
+              ok[u] = p < rows;
+              const int pc = ok[u] ? p : p0;
+              if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
+              else g[u] = ((size_t)(n * P.Tout + (m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
+              sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
+              if (P.mode == 1) {
+                if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
+                else {
 #pragma unroll
-              for (int jj = 0; jj < EPL; ++jj) {
-                if (VEC || cg + jj < P.Cout) {
-                  const float xa = E::to_f(av[jj]);
-                  const T o = E::from_f(xa * msc[jj] + msh[jj] > 0.f ? E::to_f(sv[jj]) : 0.f);
-                  sv[jj] = o;
-                  const float fv = E::to_f(o);
-                  s1[jj] += fv;
-                  s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
-                }
-              }
-            } else {
-#pragma unroll
-              for (int jj = 0; jj < EPL; ++jj) {
-                if (VEC || cg + jj < P.Cout) {
-                  const float fv = E::to_f(sv[jj]);
-                  s1[jj] += fv;
-                  s2[jj] += fv * fv;
+                  for (int jj = 0; jj < EPL; ++jj) av[u][jj] = (cg + jj < P.Cout) ? auxg[g[u] + jj] : E::from_f(0.f);
                 }
               }
             }
-            if (VEC) *reinterpret_cast<frag_t*>(outg + g) = sv;
-            else {
 #pragma unroll
-              for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g + jj] = sv[jj];
+            for (int u = 0; u < UB; ++u) {
+              if (!ok[u]) continue;
+              if (P.mode == 1) {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) {
+                  if (VEC || cg + jj < P.Cout) {
+                    const float xa = E::to_f(av[u][jj]);
+                    const T o = E::from_f(xa * msc[jj] + msh[jj] > 0.f ? E::to_f(sv[u][jj]) : 0.f);
+                    sv[u][jj] = o;
+                    const float fv = E::to_f(o);
+                    s1[jj] += fv;
+                    s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) {
+                  if (VEC || cg + jj < P.Cout) {
+                    const float fv = E::to_f(sv[u][jj]);
+                    s1[jj] += fv;
+                    s2[jj] += fv * fv;
+                  }
+                }
+              }
+              if (VEC) *reinterpret_cast<frag_t*>(outg + g[u]) = sv[u];
+              else {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g[u] + jj] = sv[u][jj];
+              }
             }
           }
         }
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
 }
 
 template <typename T, int MT, int NT>
-int launch3(const TconvParams& P, dim3 grid, size_t lds, hipStream_t stream) {
+int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   constexpr int WM = 1;   // WM = 2 (8 waves) needs <= 128 VGPRs for two workgroups per CU; the staging/epilogue code does not fit yet
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
 #define GO(VV)                                                                                              \
@@ -361,7 +376,9 @@ int launch3(const TconvParams& P, dim3 grid, size_t lds, hipStream_t stream) {
       if (ea_ != hipSuccess) return 2000 + (int)ea_; \
       attr_done = true;                                                                                     \
     }                                                                                                       \
-    ISTGCN_LAUNCH(kfn, grid, dim3(NTHREADS * WM), lds, stream, P);                                          \
+    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS * WM, lds)) / gy; \
+    gx = round_up(gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx), 8);  /* XCD-affine order: multiple of 8 */ \
+    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS * WM), lds, stream, P);                                  \
   } while (0)
   if (vec) GO(true); else GO(false);
 #undef GO
@@ -416,10 +433,8 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
   P.us_stride = G.us_stride; P.out_stride = G.out_stride; P.off_stat = G.off_stat; P.off_work = G.off_work;
   P.tiles_per_seq = ceil_div(P.Mlog, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  int gx = round_up(P.total_tiles < grid_cap ? P.total_tiles : grid_cap, 8);
-  dim3 grid(gx, G.gy);
   const size_t lds = G.lds;
-#define CASE(MTv, NTv) if (G.MT == MTv && G.NT == NTv) return launch3<T, MTv, NTv>(P, grid, lds, stream)
+#define CASE(MTv, NTv) if (G.MT == MTv && G.NT == NTv) return launch3<T, MTv, NTv>(P, grid_cap, G.gy, lds, stream)
   CASE(1, 1); CASE(2, 1); CASE(4, 1); CASE(1, 2); CASE(2, 2); CASE(4, 2);
 #undef CASE
   return ISTGCN_EINVAL;
@@ -462,7 +477,6 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
-  if (grid_cap < 8) grid_cap = 1024;
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }
