@@ -105,11 +105,13 @@ int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_
  *   running_mean / running_var in place (momentum, unbiased variance) exactly as nn.BatchNorm2d does
  *   (net/st_gcnold.py:165,174,192); training == 0 derives coef from the running statistics (eval mode).
  * istgcn_bn_bwd_coef: stats [rep][2][C] = (sum d, sum d*xhat) -> abc [3][C] with dx = abc0*d + abc1*x + abc2,
- *   dgamma = sum d*xhat, dbeta = sum d (autograd of BatchNorm2d); training == 0: dx = gamma*rstd*d. */
-int istgcn_bn_finalize(const double* stats, int stats_rep, double count, const float* gamma, const float* beta,
+ *   dgamma = sum d*xhat, dbeta = sum d (autograd of BatchNorm2d); training == 0: dx = gamma*rstd*d.
+ * clear != 0: the sums are zeroed as they are read, so one scratch buffer serves every producer in turn without a
+ *   memset launch between uses. */
+int istgcn_bn_finalize(double* stats, int stats_rep, int clear, double count, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, int training,
                        float* coef, int C, void* stream);
-int istgcn_bn_bwd_coef(const double* stats, int stats_rep, double count, const float* gamma, const float* coef,
+int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, double count, const float* gamma, const float* coef,
                        int training, float* abc, float* dgamma, float* dbeta, int C, void* stream);
 
 /* Tail of the st_gcn block, net/st_gcnold.py:174-175 + 201-203 (tcn.3 BatchNorm, tcn.4 Dropout, + residual, ReLU):

@@ -85,15 +85,18 @@ static inline DropCfg make_drop(float p, unsigned long long seed) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* stats, int rep, double count, const float* gamma, const float* beta,
-                                   float* rmean, float* rvar, float momentum, float eps, int training, float* coef,
-                                   int C) {
+__global__ void bn_finalize_kernel(double* stats, int rep, int clear, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
+                                   float* coef, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, rstd;
   if (training) {
     double s = 0, ss = 0;
-    for (int r = 0; r < rep; ++r) { s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c]; }
+    for (int r = 0; r < rep; ++r) {
+      s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c];
+      if (clear) { stats[(size_t)r * 2 * C + c] = 0.0; stats[(size_t)r * 2 * C + C + c] = 0.0; }   // ready for the next producer
+    }
     const double m = s / count;
     double var = ss / count - m * m;
     if (var < 0) var = 0;
@@ -116,12 +119,15 @@ __global__ void bn_finalize_kernel(const double* stats, int rep, double count, c
 }
 
 // dx = a*d + b*x + c ; a = g*rstd, b = -g*rstd^2*m2, c = -g*rstd*m1 + g*rstd^2*m2*mean   (m1 = sum d / M, m2 = sum d*xhat / M)
-__global__ void bn_bwd_coef_kernel(const double* stats, int rep, double count, const float* gamma, const float* coef,
-                                   int training, float* abc, float* dgamma, float* dbeta, int C) {
+__global__ void bn_bwd_coef_kernel(double* stats, int rep, int clear, double count, const float* gamma,
+                                   const float* coef, int training, float* abc, float* dgamma, float* dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0, sx = 0;
-  for (int r = 0; r < rep; ++r) { s += stats[(size_t)r * 2 * C + c]; sx += stats[(size_t)r * 2 * C + C + c]; }
+  for (int r = 0; r < rep; ++r) {
+    s += stats[(size_t)r * 2 * C + c]; sx += stats[(size_t)r * 2 * C + C + c];
+    if (clear) { stats[(size_t)r * 2 * C + c] = 0.0; stats[(size_t)r * 2 * C + C + c] = 0.0; }
+  }
   const float g = gamma ? gamma[c] : 1.f, mean = coef[2 * C + c], rstd = coef[3 * C + c];
   if (dgamma) dgamma[c] = (float)sx;
   if (dbeta) dbeta[c] = (float)s;
@@ -309,23 +315,23 @@ template <typename T> static inline int pick_vw(int C, bool need_div) {
 
 }  // namespace
 
-extern "C" int istgcn_bn_finalize(const double* stats, int stats_rep, double count, const float* gamma,
+extern "C" int istgcn_bn_finalize(double* stats, int stats_rep, int clear, double count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   int training, float* coef, int C, void* stream) {
   if (!coef || C < 1) return ISTGCN_EINVAL;
   if (training && (!stats || stats_rep < 1 || count <= 0)) return ISTGCN_EINVAL;
   if (!training && (!running_mean || !running_var)) return ISTGCN_EINVAL;
-  ISTGCN_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, count,
-                     gamma, beta, running_mean, running_var, momentum, eps, training, coef, C);
+  ISTGCN_LAUNCH(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, clear,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, training, coef, C);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
 
-extern "C" int istgcn_bn_bwd_coef(const double* stats, int stats_rep, double count, const float* gamma, const float* coef,
+extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, double count, const float* gamma, const float* coef,
                                   int training, float* abc, float* dgamma, float* dbeta, int C, void* stream) {
   if (!stats || !coef || !abc || C < 1 || stats_rep < 1 || count <= 0) return ISTGCN_EINVAL;
-  ISTGCN_LAUNCH(bn_bwd_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, count,
-                     gamma, coef, training, abc, dgamma, dbeta, C);
+  ISTGCN_LAUNCH(bn_bwd_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, stats_rep, clear,
+                     count, gamma, coef, training, abc, dgamma, dbeta, C);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

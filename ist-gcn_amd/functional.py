@@ -140,12 +140,13 @@ class STGCNBlockFn(torch.autograd.Function):
         dev = x.device
         A_eff = A_eff.contiguous()
         # 1. graph conv (+ BN1 batch sums)
-        st1 = ops.new_stats(cout, dev) if training else None
+        st1 = ops.stats_scratch(0, cout, dev) if training else None
         wp = ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt)
         g = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, stats=st1, nnz_cap=cfg.nnz_cap)
-        coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training)
+        coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training,
+                                clear=True)
         # 2. temporal conv (BN1+ReLU fused into the staging; BN2 batch sums from the epilogue)
-        st2 = ops.new_stats(cout, dev) if training else None
+        st2 = ops.stats_scratch(1, cout, dev) if training else None
         taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
         q = yb = None
         if cfg.tcn == 'conv':
@@ -160,17 +161,18 @@ class STGCNBlockFn(torch.autograd.Function):
             yb = ops.tconv(q, wt, w, taps, bias=bt, Tout=Tz, Mlog=Tz, in_mul=in_mul)
             we = ops.pack_tconv_weight(We.view(1, cout, w), V, [0], 1, dt)
             z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
-        coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training)
+        coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
+                                clear=True)
         # 3. residual branch
         r = coefr = None
         if cfg.residual == 'id':
             res, cr = x, None
         elif cfg.residual == 'conv':
-            strs = ops.new_stats(cout, dev) if training else None
+            strs = ops.stats_scratch(2, cout, dev) if training else None
             wr = ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
             r = ops.tconv(x, wr, cout, [0], bias=br, stats=strs, Tout=Tz, Mlog=Tz, in_mul=s)
             coefr = ops.bn_finalize(strs, NM * Tz * V, gr, betar, bufs['bnr'][0], bufs['bnr'][1], cfg.momentum,
-                                    cfg.eps, training)
+                                    cfg.eps, training, clear=True)
             res, cr = r, coefr[:2].contiguous()
         else:
             res, cr = None, None
@@ -194,41 +196,57 @@ class STGCNBlockFn(torch.autograd.Function):
         if dout.dtype != dt:
             dout = dout.to(dt)
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
-        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed)
-        abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training)
+        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True)
+        abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
         dz = ops.affine2(dres, z, abc2, p, seed)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
         taps, in_mul = ops.conv_taps_fwd(k, s)
         pre1 = coef1[:2].contiguous()
-        st1b = ops.new_stats(cout, x.device)
+        st1b = ops.stats_scratch(2, cout, x.device)
         dWs = dbs = dWe = dbe = None
+        need_A = ctx.needs_input_grad[5]
+        K = A_eff.shape[0]
+        # all fp32 gradient accumulators of this block out of ONE zero-filled allocation
+        cw = cout if cfg.tcn == 'conv' else cfg.width
+        shapes = [(len(taps), cw, cw), (cw,), (K, cout, cin)]
+        if ctx.has_b:
+            shapes.append((V, cout))
+        if need_A:
+            shapes.append((K, V, V))
+        if cfg.residual == 'conv':
+            shapes += [(1, cout, cin), (cout,)]
+        arena = ops.ZeroArena(shapes, x.device)
+        buf_t = (arena.take(), arena.take())
+        buf_g = (arena.take(), arena.take() if ctx.has_b else None)
+        buf_A = arena.take() if need_A else None
+        buf_r = (arena.take(), arena.take()) if cfg.residual == 'conv' else None
         if cfg.tcn == 'conv':
-            dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True)
+            dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True, out=buf_t)
             d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b)
         else:
             w = cfg.width
             dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
             dWe = dWe3.view(cout, w)
             dyb = _conv_bwd_data(dz, We.view(1, cout, w), 1, 1, Tz, w, V)
-            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul)
+            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t)
             dq = _conv_bwd_data(dyb, Wt, k, s, T, w, V)
             dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
             dWs = dWs3.view(w, cout)
             d1 = _conv_bwd_data(dq, Ws.view(1, w, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
-        abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training)
+        abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True)
         dg = ops.affine2(d1, g, abc1)
         # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in
-        need_A = ctx.needs_input_grad[5]
-        dWg, S = ops.gcn_wgrad(dg, x, A_eff, want_S=ctx.has_b, nnz_cap=cfg.nnz_cap)
+        dWg, S = ops.gcn_wgrad(dg, x, A_eff, want_S=ctx.has_b, nnz_cap=cfg.nnz_cap, out=buf_g)
         dWr = dbr = dgr = dbetar = None
         dx = dA = None
         if ctx.needs_input_grad[4] or need_A or cfg.residual == 'conv':
             addend = dres if cfg.residual == 'id' else None
-            dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cfg.nnz_cap)
+            dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cfg.nnz_cap,
+                                      dA_out=buf_A)
         if cfg.residual == 'conv':
-            abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training)
+            abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training, clear=True)
             dr = ops.affine2(dres, r, abcr)
-            dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s)
+            dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s, out=buf_r)
             dWr = dWr3.view(cout, cin)
             eye = torch.eye(V, device=x.device, dtype=torch.float32).view(1, V, V)
             wrt = ops.pack_gcn_weight(Wr.t().contiguous().view(cin, 1, cout), dt)

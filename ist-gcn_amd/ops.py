@@ -184,6 +184,23 @@ def conv_taps_bwd(k, stride, phase):
     return [(j, (phase + pad - j) // stride) for j in range(k) if (phase + pad - j) % stride == 0]
 
 
+class ZeroArena:
+    """One zero-filled fp32 allocation carved into the gradient buffers of a block's backward (one memset launch instead
+    of one per buffer).  `take(shape)` hands out consecutive 16-byte aligned views."""
+
+    def __init__(self, shapes, device):
+        self.sizes = [(int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
+        self.buf = torch.zeros(sum(self.sizes), dtype=torch.float32, device=device)
+        self.shapes, self.i, self.off = list(shapes), 0, 0
+
+    def take(self):
+        sh, n = self.shapes[self.i], self.sizes[self.i]
+        v = self.buf[self.off:self.off + int(torch.Size(sh).numel())].view(sh)
+        self.i += 1
+        self.off += n
+        return v
+
+
 _WGRAD_WS = {}
 WGRAD_WS_FLOATS = 16 << 20          # 64 MiB per device: per-workgroup partial sums of the weight-gradient kernels
 
@@ -197,15 +214,19 @@ def _wgrad_ws(dev):
     return ws
 
 
-def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=True, grid_cap=0):
+def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=True, grid_cap=0, out=None):
     """istgcn_tconv_wgrad -> (dWf [ntaps][Cout][Cin] fp32, dbias [Cout] fp32 or None)."""
     NM, Tz, V, Cout = dz.shape
     NM2, Tin, V2, Cin = g.shape
     assert (NM, V) == (NM2, V2) and dz.dtype == g.dtype
     if pre is not None:
         assert pre.shape == (2, Cin) and pre.dtype == torch.float32
-    dW = torch.zeros((len(tap_off), Cout, Cin), dtype=torch.float32, device=dz.device)
-    db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
+    if out is not None:                 # caller-provided ZERO-filled (dW [ntaps][Cout][Cin], db [Cout] or None)
+        dW, db = out
+        assert dW.shape == (len(tap_off), Cout, Cin) and dW.dtype == torch.float32 and dW.is_contiguous()
+    else:
+        dW = torch.zeros((len(tap_off), Cout, Cin), dtype=torch.float32, device=dz.device)
+        db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
     _check_dev(dz, g, pre, dW, db)
     _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
           V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap,
@@ -236,7 +257,7 @@ def pack_gcn_wb(w3, dtype):
     return w.to(dtype).contiguous()
 
 
-def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0):
+def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None):
     """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None)."""
     NM, T, V, Cout = dy.shape
     K, cout2, Cin = w3.shape
@@ -246,7 +267,8 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
     dA = None
     if want_dA:
         assert x is not None and x.shape == dx.shape and x.dtype == dy.dtype
-        dA = torch.zeros((K, V, V), dtype=torch.float32, device=dev)
+        dA = dA_out if dA_out is not None else torch.zeros((K, V, V), dtype=torch.float32, device=dev)
+        assert dA.shape == (K, V, V) and dA.dtype == torch.float32 and dA.is_contiguous()
     if addend is not None:
         assert addend.shape == dx.shape and addend.dtype == dy.dtype
     wb = pack_gcn_wb(w3, dy.dtype)
@@ -260,15 +282,19 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
     return dx, dA
 
 
-def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0):
+def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0, out=None):
     """istgcn_gcn_wgrad -> (dW [K][Cout][Cin] fp32, S [V][Cout] fp32 or None)."""
     NM, T, V, Cout = dy.shape
     Cin = x.shape[3]
     K = A.shape[0]
     assert x.shape[:3] == dy.shape[:3] and x.dtype == dy.dtype and A.shape == (K, V, V)
     dev = dy.device
-    dW = torch.zeros((K, Cout, Cin), dtype=torch.float32, device=dev)
-    S = torch.zeros((V, Cout), dtype=torch.float32, device=dev) if want_S else None
+    if out is not None:                 # caller-provided ZERO-filled (dW [K][Cout][Cin], S [V][Cout] or None)
+        dW, S = out
+        assert dW.shape == (K, Cout, Cin) and dW.dtype == torch.float32 and dW.is_contiguous()
+    else:
+        dW = torch.zeros((K, Cout, Cin), dtype=torch.float32, device=dev)
+        S = torch.zeros((V, Cout), dtype=torch.float32, device=dev) if want_S else None
     if nnz_cap is None:
         nnz_cap = K * V * V
     _check_dev(dy, x, A, dW, S)
@@ -285,25 +311,41 @@ def new_stats(C, device):
     return torch.zeros((STATS_REP, 2, C), dtype=torch.float64, device=device)
 
 
-def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training):
+_STATS_SCRATCH = {}
+
+
+def stats_scratch(slot, C, device):
+    """A persistent, always-zero-between-uses [STATS_REP][2][C] fp64 buffer: the kernel that produces batch sums adds
+    into it, `bn_finalize` / `bn_bwd_coef` (clear=True) read it and zero it again.  One per (device, stream, slot, C);
+    distinct `slot`s for sums that are alive at the same time.  Saves a memset launch per BatchNorm per pass."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, slot, C)
+    st = _STATS_SCRATCH.get(key)
+    if st is None:
+        st = _STATS_SCRATCH[key] = new_stats(C, device)
+    return st
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear=False):
     """-> coef [4][C] fp32: scale, shift, mean, rstd.  Training also updates the running statistics in place."""
     C = gamma.shape[0]
     coef = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
     _check_dev(stats, gamma, beta, running_mean, running_var, coef)
-    _call('istgcn_bn_finalize', _ptr(stats), 0 if stats is None else stats.shape[0], ctypes.c_double(float(count)),
+    _call('istgcn_bn_finalize', _ptr(stats), 0 if stats is None else stats.shape[0], int(bool(clear)),
+          ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum),
           ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma))
     return coef
 
 
-def bn_bwd_coef(stats, count, gamma, coef, training):
+def bn_bwd_coef(stats, count, gamma, coef, training, clear=False):
     """-> (abc [3][C], dgamma [C], dbeta [C]) from the two BatchNorm-backward sums."""
     C = gamma.shape[0]
     abc = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
     dg = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     db = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     _check_dev(stats, gamma, coef, abc, dg, db)
-    _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], ctypes.c_double(float(count)), _ptr(gamma), _ptr(coef),
+    _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], int(bool(clear)), ctypes.c_double(float(count)),
+          _ptr(gamma), _ptr(coef),
           int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma))
     return abc, dg, db
 
@@ -323,12 +365,17 @@ def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0):
     return out
 
 
-def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0):
-    """-> (dres = dout*[out>0], stats2, statsr or None)"""
+def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False):
+    """-> (dres = dout*[out>0], stats2, statsr or None); scratch=True: the sums go to `stats_scratch` slots 0 / 1
+    (consume them with bn_bwd_coef(clear=True))."""
     C = z.shape[-1]
     dres = torch.empty_like(z)
-    st2 = new_stats(C, z.device)
-    str_ = new_stats(C, z.device) if r is not None else None
+    if scratch:
+        st2 = stats_scratch(0, C, z.device)
+        str_ = stats_scratch(1, C, z.device) if r is not None else None
+    else:
+        st2 = new_stats(C, z.device)
+        str_ = new_stats(C, z.device) if r is not None else None
     assert dout.shape == z.shape == out.shape and dout.dtype == z.dtype
     _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
     _call('istgcn_block_out_bwd', _ptr(dout), _ptr(out), _ptr(z), _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres),
