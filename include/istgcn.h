@@ -99,6 +99,24 @@ int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_
                        int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
                        int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats, void* stream);
 
+/* Weight packers: fp32 parameter views (element strides given, read in place) -> the fragment orders above, zero padded
+ * and cast to `dtype`; one launch per weight.  The *_elems functions return the number of dst elements (or -1).
+ *   istgcn_pack_gcn:     Wr[c][k][i] at src + c*s_o + k*s_k + i*s_i  (nn.Conv2d(Cin, K*Cout, 1).weight viewed [K][Cout][Cin]:
+ *                        net/utils/tgcn.py:55-63) -> Wp of istgcn_gcn_fwd
+ *   istgcn_pack_tconv:   Wf[tap_sel[j]][o][i] at src + t*s_t + o*s_o + i*s_i for the ntaps packed taps
+ *                        (nn.Conv2d(C, C, (k,1)).weight [o][i][t][1]: s_o = Cin*k, s_i = k, s_t = 1; the data gradient
+ *                        swaps s_o / s_i and selects the taps of its output phase) -> Wp of istgcn_tconv
+ *   istgcn_pack_gcn_bwd: W3[k][c][i] at src + k*s_k + c*s_c + i*s_i -> Wb of istgcn_gcn_bwd_data */
+long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype);
+int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin, int Cout, int K,
+                    int dtype, void* stream);
+long long istgcn_pack_tconv_elems(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype);
+int istgcn_pack_tconv(const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel, void* dst, int V,
+                      int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, void* stream);
+long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype);
+int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin, int Cout, int K,
+                        int dtype, void* stream);
+
 /* BatchNorm2d bookkeeping (train-mode statistics are batch sums the MFMA kernels emit in their epilogues).
  * istgcn_bn_finalize: stats [rep][2][C] fp64 (sum, sum of squares) over `count` elements per channel ->
  *   coef [4][C] fp32 = scale (gamma*rstd), shift (beta - mean*scale), mean, rstd; training != 0 also updates

@@ -106,6 +106,8 @@ def load():
         _lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError('cannot load %s: %s' % (LIB_PATH, e))
+    for name in ('istgcn_pack_gcn_elems', 'istgcn_pack_tconv_elems', 'istgcn_pack_gcn_bwd_elems'):
+        getattr(_lib, name).restype = ctypes.c_longlong          # element counts; every other entry returns int
     return _lib
 
 
@@ -113,4 +115,4 @@ def declared_symbols():
     """Names of every `int istgcn_*(...)` entry point declared in include/istgcn.h."""
     import re
     txt = open(HEADER).read()
-    return sorted(set(re.findall(r'\bint\s+(istgcn_\w+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(?:int|long long)\s+(istgcn_\w+)\s*\(', txt)))

@@ -1,0 +1,180 @@
+// Weight packers: parameter tensors (fp32, any strides -- read in place from the nn.Conv2d weight) -> the fragment
+// orders the MFMA loops stream (zero padded, cast to the activation dtype), one launch per weight.  These replace the
+// pad / reshape / permute / cast chains of the host mirror (ops.pack_*_weight, kept as the executable specification
+// the tests compare against bit for bit): a training step repacks every weight after each optimiser update, and a
+// chain of 4-6 tiny launches per weight was a tenth of the bf16 step.
+//
+//   istgcn_pack_gcn      Wr[c][k][i]  -> [nch][MTtot][NKG][2][32][EPL]            (gcn_fwd.hip, see istgcn.h)
+//   istgcn_pack_tconv    Wf[j][o][i]  -> [nch][ntaps][NKG][MTtot][2][32][EPL]     (tconv.hip); the taps are picked
+//                        through `tap_sel` and o / i have independent strides, so the data-gradient weights
+//                        (transposed, per-phase tap subset) come from the same parameter without a copy
+//   istgcn_pack_gcn_bwd  W3[k][c][i]  -> [nchi][nchc][NKGc][MTK][2][32][EPL]      (gcn_bwd.hip)
+#include "common.hpp"
+
+extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp, int* MTtot,
+                                   int* EPL);
+extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype,
+                                     int* CC, int* nch, int* MTtot, int* EPL);
+extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc,
+                                       int* KKp, int* EPL);
+
+namespace {
+
+constexpr int MAX_TAPS = 16;
+
+struct PackGcn {
+  const float* src; void* dst;
+  long long s_o, s_k, s_i;     // element strides of Wr[c][k][i]
+  int Cin, Cout, K, CCeff, nch, NKG, MTtot;
+};
+
+// one thread per 16-byte output vector (h, r fixed, e = 0..EPL-1)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_gcn_kernel(const PackGcn P) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int total = P.nch * P.MTtot * P.NKG * 2 * 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int t = idx;
+  const int r = t % 32; t /= 32;
+  const int h = t % 2; t /= 2;
+  const int kg = t % P.NKG; t /= P.NKG;
+  const int mt = t % P.MTtot; const int ch = t / P.MTtot;
+  const int o = mt * 32 + r;
+  typename Elem<T>::frag v;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int kk = kg * 2 * EPL + h * EPL + e;
+    const int k = kk / P.CCeff, il = kk - k * P.CCeff, i = ch * P.CCeff + il;
+    const bool ok = o < P.Cout && k < P.K && i < P.Cin;
+    v[e] = Elem<T>::from_f(ok ? P.src[o * P.s_o + k * P.s_k + i * P.s_i] : 0.f);
+  }
+  *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
+}
+
+struct PackTconv {
+  const float* src; void* dst;
+  long long s_t, s_o, s_i;     // element strides of Wf[tap][o][i]
+  int Cin, Cout, ntaps, CC, nch, NKG, MTtot;
+  int tap_sel[MAX_TAPS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_tconv_kernel(const PackTconv P) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int total = P.nch * P.ntaps * P.NKG * P.MTtot * 2 * 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int t = idx;
+  const int r = t % 32; t /= 32;
+  const int h = t % 2; t /= 2;
+  const int mt = t % P.MTtot; t /= P.MTtot;
+  const int kg = t % P.NKG; t /= P.NKG;
+  const int j = t % P.ntaps; const int ch = t / P.ntaps;
+  const int o = mt * 32 + r;
+  const float* base = P.src + P.tap_sel[j] * P.s_t + o * P.s_o;
+  typename Elem<T>::frag v;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int i = ch * P.CC + kg * 2 * EPL + h * EPL + e;
+    v[e] = Elem<T>::from_f((o < P.Cout && i < P.Cin) ? base[i * P.s_i] : 0.f);
+  }
+  *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
+}
+
+struct PackGcnBwd {
+  const float* src; void* dst;
+  long long s_k, s_c, s_i;     // element strides of W3[k][c][i]
+  int Cin, Cout, K, CCi, nchi, CCc, nchc, NKGc, MTK;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_gcn_bwd_kernel(const PackGcnBwd P) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int total = P.nchi * P.nchc * P.NKGc * P.MTK * 2 * 32;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int t = idx;
+  const int r = t % 32; t /= 32;
+  const int h = t % 2; t /= 2;
+  const int m = t % P.MTK; t /= P.MTK;
+  const int kg = t % P.NKGc; t /= P.NKGc;
+  const int cch = t % P.nchc; const int ich = t / P.nchc;
+  const int kk = m * 32 + r;
+  const int k = kk / P.CCi, il = kk - k * P.CCi, i = ich * P.CCi + il;
+  const bool row_ok = k < P.K && i < P.Cin;
+  typename Elem<T>::frag v;
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int c = cch * P.CCc + kg * 2 * EPL + h * EPL + e;
+    v[e] = Elem<T>::from_f((row_ok && c < P.Cout) ? P.src[k * P.s_k + c * P.s_c + i * P.s_i] : 0.f);
+  }
+  *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
+}
+
+}  // namespace
+
+extern "C" long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype) {
+  int cce, nch, kkp, mttot, epl;
+  if (Cin < 1 || Cout < 1 || K < 1 || istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return -1;
+  return (long long)nch * mttot * kkp * 32;
+}
+
+extern "C" int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin,
+                               int Cout, int K, int dtype, void* stream) {
+  if (!src || !dst || Cin < 1 || Cout < 1 || K < 1) return ISTGCN_EINVAL;
+  int cce, nch, kkp, mttot, epl;
+  if (int rc = istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return rc;
+  PackGcn P{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot};
+  const int total = nch * mttot * P.NKG * 2 * 32;
+  if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else ISTGCN_LAUNCH(pack_gcn_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" long long istgcn_pack_tconv_elems(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul,
+                                             int dtype) {
+  int cc, nch, mttot, epl;
+  if (istgcn_tconv_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &cc, &nch, &mttot, &epl)) return -1;
+  return (long long)nch * ntaps * cc * mttot * 32;
+}
+
+extern "C" int istgcn_pack_tconv(const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,
+                                 void* dst, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul,
+                                 int dtype, void* stream) {
+  if (!src || !dst || !tap_sel || !tap_off) return ISTGCN_EINVAL;
+  int cc, nch, mttot, epl;
+  if (int rc = istgcn_tconv_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &cc, &nch, &mttot, &epl)) return rc;
+  PackTconv P{};
+  P.src = src; P.dst = dst; P.s_t = s_t; P.s_o = s_o; P.s_i = s_i;
+  P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps; P.CC = cc; P.nch = nch; P.NKG = cc / (2 * epl); P.MTtot = mttot;
+  for (int j = 0; j < ntaps; ++j) {
+    if (tap_sel[j] < 0) return ISTGCN_EINVAL;
+    P.tap_sel[j] = tap_sel[j];
+  }
+  const int total = nch * ntaps * P.NKG * mttot * 2 * 32;
+  if (dtype == 0) ISTGCN_LAUNCH(pack_tconv_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else ISTGCN_LAUNCH(pack_tconv_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype) {
+  int cci, nchi, ccc, nchc, kkp, epl;
+  if (Cin < 1 || Cout < 1 || istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
+  return (long long)nchi * nchc * ccc * kkp;
+}
+
+extern "C" int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin,
+                                   int Cout, int K, int dtype, void* stream) {
+  if (!src || !dst || Cin < 1 || Cout < 1) return ISTGCN_EINVAL;
+  int cci, nchi, ccc, nchc, kkp, epl;
+  if (int rc = istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return rc;
+  PackGcnBwd P{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32};
+  const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32;
+  if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else ISTGCN_LAUNCH(pack_gcn_bwd_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}

@@ -67,9 +67,9 @@ def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, sta
                 out.zero_()
                 filled = True
             continue
-        wt = torch.stack([w_taps[j].t() for j, _ in tl]).contiguous()          # [taps][Cin][Cout]
         offs = [dj for _, dj in tl]
-        wp = ops.pack_tconv_weight(wt, V, offs, 1, dz.dtype)
+        # transposed taps [k][Cin][Cout] as a view; the packer gathers this phase's taps straight from the parameter
+        wp = ops.pack_tconv_weight(w_taps.transpose(1, 2), V, offs, 1, dz.dtype, tap_sel=[j for j, _ in tl])
         ops.tconv(dz, wp, cin, offs, aux=aux, maux=maux, out=out, stats=stats, mode=0 if aux is None else 1,
                   Tout=T_in, Mlog=Mlog, in_mul=1, out_mul=stride, out_off=phase)
     return out
@@ -249,7 +249,7 @@ class STGCNBlockFn(torch.autograd.Function):
             dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s, out=buf_r)
             dWr = dWr3.view(cout, cin)
             eye = torch.eye(V, device=x.device, dtype=torch.float32).view(1, V, V)
-            wrt = ops.pack_gcn_weight(Wr.t().contiguous().view(cin, 1, cout), dt)
+            wrt = ops.pack_gcn_weight(Wr.t().unsqueeze(1), dt)                      # [cin][1][cout] view
             ops.gcn_forward(dr, eye, wrt, cin, addend=dx, out=dx, Tout=T, out_t_stride=s, nnz_cap=V)
         return (None, None, None, None, dx, dA, (S if ctx.has_b else None), dWg, dg1, db1, dWt, dbt, dg2, db2,
                 dWr, dbr, dgr, dbetar, dWs, dbs, dWe, dbe)

@@ -127,7 +127,8 @@ class STGCNBlock(nn.Module):
         bterm = Fn.fold_bias_term(conv.bias, A_eff, c) if conv.bias is not None else None
         if self.tcn_kind == 'single':
             bn1, tconv, bn2 = self.tcn[0], self.tcn[2], self.tcn[3]
-            Wt, bt, ks = tconv.weight[:, :, :, 0].permute(2, 0, 1).contiguous(), tconv.bias, self.tk
+            # [k][Cout][Cin] VIEW of the Conv2d weight: the packers read the parameter in place (no copy, no extra launch)
+            Wt, bt, ks = tconv.weight.view(c, c, self.tk).permute(2, 0, 1), tconv.bias, self.tk
             Ws = bs = We = be = None
             mode = 'conv'
         else:

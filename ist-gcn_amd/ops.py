@@ -80,8 +80,28 @@ def gcn_geometry(cin, cout, K, dt):
     return tuple(v.value for v in vals)  # CCeff, nch, KKp, MTtot, EPL
 
 
+def _src_ok(w):
+    if not w.is_cuda or w.dtype != torch.float32:
+        raise RuntimeError('istgcn: weight packers take fp32 tensors on the GPU (got %s on %s)' % (w.dtype, w.device))
+
+
 def pack_gcn_weight(wr, dtype):
-    """wr: [Cout][K][Cin] fp32 (Wr[c][k][i]) -> fragment-ordered tensor the MFMA loop streams (see istgcn.h)."""
+    """wr: [Cout][K][Cin] fp32 view (any strides: read in place) -> fragment-ordered tensor the MFMA loop streams
+    (istgcn_pack_gcn, one launch; layout in istgcn.h).  `pack_gcn_weight_ref` is the torch-op specification."""
+    cout, K, cin = wr.shape
+    if not wr.is_cuda:
+        return pack_gcn_weight_ref(wr, dtype)            # host tensors: the specification itself (tests, tooling)
+    _src_ok(wr)
+    n = _lib.load().istgcn_pack_gcn_elems(cin, cout, K, _DT[dtype])
+    out = torch.empty(int(n), dtype=dtype, device=wr.device)
+    so, sk, si = wr.stride()
+    _call('istgcn_pack_gcn', _ptr(wr), ctypes.c_longlong(so), ctypes.c_longlong(sk), ctypes.c_longlong(si), _ptr(out),
+          cin, cout, K, _DT[dtype], _stream(wr))
+    return out
+
+
+def pack_gcn_weight_ref(wr, dtype):
+    """Specification of istgcn_pack_gcn in torch ops: wr [Cout][K][Cin] -> [nch][MTtot][NKG][2][32][EPL]."""
     cout, K, cin = wr.shape
     cce, nch, kkp, mttot, epl = gcn_geometry(cin, cout, K, _DT[dtype])
     w = F.pad(wr, (0, nch * cce - cin))
@@ -136,8 +156,30 @@ def tconv_geometry(V, cin, cout, tap_off, in_mul, dt):
     return tuple(v.value for v in vals)  # CC, nch, MTtot, EPL
 
 
-def pack_tconv_weight(wf, V, tap_off, in_mul, dtype):
-    """wf: [ntaps][Cout][Cin] fp32 -> [nch][ntaps][NKG][MTtot][2][32][EPL] fragments (see istgcn.h)."""
+def pack_tconv_weight(wf, V, tap_off, in_mul, dtype, tap_sel=None):
+    """wf: [taps][Cout][Cin] fp32 view (any strides) -> [nch][ntaps][NKG][MTtot][2][32][EPL] fragments
+    (istgcn_pack_tconv, one launch).  tap_sel: which taps of wf feed the len(tap_off) packed taps (default: all, in
+    order) -- the data gradient packs a per-phase subset of the transposed view without materialising it."""
+    if tap_sel is None:
+        tap_sel = list(range(wf.shape[0]))
+    assert len(tap_sel) == len(tap_off) and max(tap_sel) < wf.shape[0]
+    _, cout, cin = wf.shape
+    if not wf.is_cuda:
+        return pack_tconv_weight_ref(wf[list(tap_sel)], V, tap_off, in_mul, dtype)
+    _src_ok(wf)
+    offs = _int_array(tap_off)
+    n = _lib.load().istgcn_pack_tconv_elems(V, cin, cout, len(tap_off), offs, in_mul, _DT[dtype])
+    if n < 0:
+        raise RuntimeError('istgcn_pack_tconv_elems: invalid geometry')
+    out = torch.empty(int(n), dtype=dtype, device=wf.device)
+    st, so, si = wf.stride()
+    _call('istgcn_pack_tconv', _ptr(wf), ctypes.c_longlong(st), ctypes.c_longlong(so), ctypes.c_longlong(si),
+          _int_array(tap_sel), _ptr(out), V, cin, cout, len(tap_off), offs, in_mul, _DT[dtype], _stream(wf))
+    return out
+
+
+def pack_tconv_weight_ref(wf, V, tap_off, in_mul, dtype):
+    """Specification of istgcn_pack_tconv in torch ops: wf [ntaps][Cout][Cin] -> [nch][ntaps][NKG][MTtot][2][32][EPL]."""
     ntaps, cout, cin = wf.shape
     cc, nch, mttot, epl = tconv_geometry(V, cin, cout, tap_off, in_mul, _DT[dtype])
     nkg = cc // (2 * epl)
@@ -245,7 +287,22 @@ def gcn_bwd_geometry(cin, cout, K, dt):
 
 
 def pack_gcn_wb(w3, dtype):
-    """w3: [K][Cout][Cin] fp32 -> fragments [nchi][nchc][NKGc][MTK][2][32][EPL] of the dxa product:
+    """w3: [K][Cout][Cin] fp32 view (any strides) -> fragments [nchi][nchc][NKGc][MTK][2][32][EPL] of the dxa product
+    (istgcn_pack_gcn_bwd, one launch)."""
+    K, cout, cin = w3.shape
+    if not w3.is_cuda:
+        return pack_gcn_wb_ref(w3, dtype)
+    _src_ok(w3)
+    n = _lib.load().istgcn_pack_gcn_bwd_elems(cin, cout, K, _DT[dtype])
+    out = torch.empty(int(n), dtype=dtype, device=w3.device)
+    sk, sc, si = w3.stride()
+    _call('istgcn_pack_gcn_bwd', _ptr(w3), ctypes.c_longlong(sk), ctypes.c_longlong(sc), ctypes.c_longlong(si),
+          _ptr(out), cin, cout, K, _DT[dtype], _stream(w3))
+    return out
+
+
+def pack_gcn_wb_ref(w3, dtype):
+    """Specification of istgcn_pack_gcn_bwd in torch ops: w3 [K][Cout][Cin] -> [nchi][nchc][NKGc][MTK][2][32][EPL]:
     row kk = k*CCi + (i - ich*CCi) (zero padded to KKp), contraction index c = cch*CCc + kg*2*EPL + h*EPL + e."""
     K, cout, cin = w3.shape
     cci, nchi, ccc, nchc, kkp, epl = gcn_bwd_geometry(cin, cout, K, _DT[dtype])

@@ -256,3 +256,37 @@ def test_extract_feature_shapes():
     assert out.shape == (2, nc, 8, 25, 2) and feat.shape == (2, 256, 8, 25, 2)
     # pooling the per-position scores reproduces forward (fcn is linear)
     assert rel_err(out.mean(dim=(2, 3, 4)), y) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_native_packers_match_specification(ops, dt):
+    """istgcn_pack_* (one launch, strided in-place reads) == the torch-op specification, bit for bit."""
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, K in ((3, 64, 3), (64, 64, 3), (64, 128, 3), (256, 256, 3), (40, 24, 2), (64, 64, 4), (16, 8, 1)):
+        w = torch.randn(K * cout, cin, 1, 1, generator=g).to(d)                       # Conv2d(Cin, K*Cout, 1).weight
+        W3 = w.view(K, cout, cin)
+        ref = ops.pack_gcn_weight_ref(W3.permute(1, 0, 2).contiguous().cpu(), dt)
+        got = ops.pack_gcn_weight(W3.permute(1, 0, 2), dt)                            # permuted view, read in place
+        assert torch.equal(got.cpu().view(ref.shape), ref)
+        refb = ops.pack_gcn_wb_ref(W3.cpu(), dt)
+        gotb = ops.pack_gcn_wb(W3, dt)
+        assert torch.equal(gotb.cpu().view(refb.shape), refb)
+    V = 25
+    for cin, cout, k, s in ((64, 64, 9, 1), (64, 128, 9, 2), (256, 256, 9, 1), (8, 8, 15, 1), (3, 64, 1, 2), (24, 40, 3, 1)):
+        w = torch.randn(cout, cin, k, 1, generator=g).to(d)                           # Conv2d(C, C, (k,1)).weight
+        wf = w.view(cout, cin, k).permute(2, 0, 1)                                    # [k][Cout][Cin] view
+        taps, in_mul = ops.conv_taps_fwd(k, s)
+        ref = ops.pack_tconv_weight_ref(wf.contiguous().cpu(), V, taps, in_mul, dt)
+        got = ops.pack_tconv_weight(wf, V, taps, in_mul, dt)
+        assert torch.equal(got.cpu().view(ref.shape), ref)
+        for phase in range(s):                                                        # data-gradient packs
+            tl = ops.conv_taps_bwd(k, s, phase)
+            if not tl:
+                continue
+            sel, offs = [j for j, _ in tl], [dj for _, dj in tl]
+            wt = torch.stack([wf[j].t() for j in sel]).contiguous().cpu()
+            ref = ops.pack_tconv_weight_ref(wt, V, offs, 1, dt)
+            got = ops.pack_tconv_weight(wf.transpose(1, 2), V, offs, 1, dt, tap_sel=sel)
+            assert torch.equal(got.cpu().view(ref.shape), ref)

@@ -67,7 +67,7 @@ def test_invalid_arguments_are_rejected_before_launch(lib):
     # NULL pointers / bad sizes -> ISTGCN_EINVAL (1), nothing touches a device
     assert lib.istgcn_gcn_fwd(None, None, None, None, None, None, None, 0, None, 1, 1, 1, 1, 25, 3, 8, 3, 1, 1, 10, 0, 0, None) == 1
     assert lib.istgcn_tconv(None, None, None, None, 0, None, None, None, None, 0, 0, 1, 1, 1, 1, 25, 8, 8, 1, None, 1, 1, 0, 0, 0, None) == 1
-    assert lib.istgcn_bn_finalize(None, 0, ctypes.c_double(1.0), None, None, None, None, ctypes.c_float(0.1), ctypes.c_float(1e-5), 1, None, 4, None) == 1
+    assert lib.istgcn_bn_finalize(None, 0, 0, ctypes.c_double(1.0), None, None, None, None, ctypes.c_float(0.1), ctypes.c_float(1e-5), 1, None, 4, None) == 1
     vals = [ctypes.c_int() for _ in range(5)]
     assert lib.istgcn_gcn_geometry(64, 64, 3, 7, *[ctypes.byref(v) for v in vals]) == 1
 
