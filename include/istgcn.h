@@ -117,6 +117,17 @@ long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype);
 int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin, int Cout, int K,
                         int dtype, void* stream);
 
+/* Parameter folds of the graph-conv unit (one launch each way; everything fp32):
+ *   A_eff = sum_j B_j (.) imp_j   (J = 1: A*importance, st_gcnold.py:86; J = 3: the Inception-GCN sum of
+ *           st_gcn_msgcn.py:116-117 or the elementwise powers of tgcn_multi3_fix_3A.py:86-89; B = [J][K][V][V])
+ *   bterm[w][c] = sum_k bias[k*C+c] * sum_v A_eff[k][v][w]   (Conv2d bias pushed through the einsum, tgcn.py:79-86)
+ * and their gradients: dimp_j = B_j (.) (dA + dcol broadcast over v), dbias (see csrc/fold.hip). K*V <= 512. */
+int istgcn_fold_fwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2, const float* bias,
+                    float* A_eff, float* bterm, int K, int V, int C, void* stream);
+int istgcn_fold_bwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2, const float* bias,
+                    const float* dA, const float* S, float* dimp0, float* dimp1, float* dimp2, float* dbias, int K, int V,
+                    int C, void* stream);
+
 /* BatchNorm2d bookkeeping (train-mode statistics are batch sums the MFMA kernels emit in their epilogues).
  * istgcn_bn_finalize: stats [rep][2][C] fp64 (sum, sum of squares) over `count` elements per channel ->
  *   coef [4][C] fp32 = scale (gamma*rstd), shift (beta - mean*scale), mean, rstd; training != 0 also updates

@@ -41,6 +41,27 @@ def fold_bias_term(bias, A_eff, cout):
     return torch.einsum('kc,kw->wc', bias.view(K, cout), A_eff.sum(1)).contiguous()
 
 
+class FoldFn(torch.autograd.Function):
+    """(A_eff, bterm) = fold(B, bias, *imps) in one launch (and one for the gradients): the fused form of
+    fold_adjacency + fold_bias_term above for learnable importances on the GPU."""
+
+    @staticmethod
+    def forward(ctx, B, bias, C, *imps):
+        imps = [i.contiguous() for i in imps]
+        A_eff, bterm = ops.fold_fwd(B, imps, bias, C)
+        ctx.save_for_backward(B, bias, *imps)
+        ctx.C = C
+        return A_eff, bterm
+
+    @staticmethod
+    def backward(ctx, dA, dbterm):
+        B, bias, *imps = ctx.saved_tensors
+        dA = dA.contiguous() if dA is not None else None
+        S = dbterm.contiguous() if dbterm is not None else None
+        dimps, dbias = ops.fold_bwd(B, imps, bias, dA, S, ctx.C)
+        return (None, dbias, None) + tuple(dimps)
+
+
 def fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
     """x1*m0 + x2*m1 + x3*m2 (st_gcn_multi3_fix_3A_mstcn.py:212-215; /3 in st_gcn_mstcn.py:245) with kernel sizes
     3/9/15 and paddings 1/4/7 is ONE 15-tap convolution: taps [15][Cout][Cin] and one bias."""

@@ -72,6 +72,9 @@ def _to_nctv(x):
     return x.permute(0, 3, 1, 2)          # logical (N,C,T,V), channels_last strides: no copy
 
 
+_UNSET = object()          # "argument not given" marker (None is a valid bias term)
+
+
 class STGCNBlock(nn.Module):
     KIND = None
 
@@ -117,14 +120,15 @@ class STGCNBlock(nn.Module):
         self._calls = 0
 
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
-    def run(self, x, A_eff, mst=None, nnz_cap=None):
+    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET):
         if not x.is_cuda:
             raise RuntimeError('istgcn_amd: the st_gcn block runs on MI355X only (tensor on %s); no CPU fallback'
                                % x.device)
         c, V = self.cout, x.shape[2]
         conv = self.gcn.the_conv()
         Wg3 = conv.weight.view(self.K, c, self.cin)
-        bterm = Fn.fold_bias_term(conv.bias, A_eff, c) if conv.bias is not None else None
+        if bterm is _UNSET:                  # (the model passes the fused fold's bias term; standalone blocks fold here)
+            bterm = Fn.fold_bias_term(conv.bias, A_eff, c) if conv.bias is not None else None
         if self.tcn_kind == 'single':
             bn1, tconv, bn2 = self.tcn[0], self.tcn[2], self.tcn[3]
             # [k][Cout][Cin] VIEW of the Conv2d weight: the packers read the parameter in place (no copy, no extra launch)
@@ -189,6 +193,12 @@ class STGCNBlock(nn.Module):
         return (_to_nctv(y),) + ret
 
 
+def _buffers_reloaded(module, incompatible_keys):
+    """load_state_dict may have replaced the adjacency buffers: drop everything derived from them."""
+    module._nnz_cap = None
+    module._fold_consts.clear()
+
+
 class STGCNModel(nn.Module):
     KIND = None
     BLOCK = None
@@ -228,7 +238,8 @@ class STGCNModel(nn.Module):
             self.mstcn_importance = nn.ParameterList([nn.Parameter(torch.ones(3)) for _ in blocks])
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._nnz_cap = None
-        self.register_load_state_dict_post_hook(lambda m, keys: setattr(m, '_nnz_cap', None))
+        self._fold_consts = {}               # device -> [J,K,V,V] constants of the fused importance fold
+        self.register_load_state_dict_post_hook(_buffers_reloaded)
 
     # the sparsity pattern bounds the kernels' in-LDS adjacency lists; recomputed if buffers are reloaded
     def _cap(self):
@@ -245,6 +256,29 @@ class STGCNModel(nn.Module):
             imps += [self.edge_importance2[i], self.edge_importance3[i]]
         return Fn.fold_adjacency(self.gcn_kind, self.A, imps, getattr(self, 'A2', None), getattr(self, 'A3', None))
 
+    def _fold_B(self, dev):
+        """[J,K,V,V] constants B_j with A_eff = sum_j B_j (.) importance_j (cached per device until buffers reload)."""
+        B = self._fold_consts.get(dev)
+        if B is None:
+            if self.gcn_kind == 'plain':
+                mats = [self.A]
+            elif self.gcn_kind == 'incep':
+                mats = [self.A, self.A2, self.A3]
+            else:
+                mats = [self.A, self.A * self.A, self.A * self.A * self.A]
+            B = self._fold_consts[dev] = torch.stack([m.to(dev) for m in mats]).contiguous()
+        return B
+
+    def _folded(self, i, blk):
+        """(A_eff, bterm-or-_UNSET) of block i: one fused launch when the importances are learnable parameters."""
+        imps = [self.edge_importance[i]]
+        if self.gcn_kind in ('incep', '3a'):
+            imps += [self.edge_importance2[i], self.edge_importance3[i]]
+        if all(isinstance(p, torch.Tensor) and p.is_cuda for p in imps):
+            conv = blk.gcn.the_conv()
+            return Fn.FoldFn.apply(self._fold_B(imps[0].device), conv.bias, blk.cout, *imps)
+        return self._a_eff(i), _UNSET
+
     def _trunk(self, x):
         if not x.is_cuda:
             raise RuntimeError('istgcn_amd.net: Model.forward needs the input on an MI355X (got %s); the HIP path has '
@@ -257,7 +291,8 @@ class STGCNModel(nn.Module):
         cap = self._cap()
         for i, blk in enumerate(self.st_gcn_networks):
             mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
-            x = blk.run(x, self._a_eff(i), mst, nnz_cap=cap)
+            A_eff, bterm = self._folded(i, blk)
+            x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm)
         return x
 
     def forward(self, x):

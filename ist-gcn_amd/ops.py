@@ -450,3 +450,34 @@ def affine2(d, x, abc, p_drop=0.0, seed=0):
           ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(d), _stream(d),
           work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter folds of the graph-conv unit (fold.hip)
+# ----------------------------------------------------------------------------------------------
+def fold_fwd(B, imps, bias, C):
+    """-> (A_eff [K,V,V], bterm [V,C] or None).  B: [J,K,V,V] constants, imps: J tensors [K,V,V], bias [K*C] or None."""
+    J, K, V, _ = B.shape
+    assert len(imps) == J and all(i.shape == (K, V, V) and i.dtype == torch.float32 for i in imps)
+    A_eff = torch.empty((K, V, V), dtype=torch.float32, device=B.device)
+    bterm = torch.empty((V, C), dtype=torch.float32, device=B.device) if bias is not None else None
+    _check_dev(B, bias, A_eff, bterm, *imps)
+    ip = [_ptr(i) for i in imps] + [_ptr(None)] * (3 - J)
+    _call('istgcn_fold_fwd', _ptr(B), J, ip[0], ip[1], ip[2], _ptr(bias), _ptr(A_eff), _ptr(bterm), K, V, int(C),
+          _stream(B))
+    return A_eff, bterm
+
+
+def fold_bwd(B, imps, bias, dA, S, C):
+    """-> ([dimp_j], dbias or None) from dA (grad of A_eff, or None) and S (grad of bterm, or None)."""
+    J, K, V, _ = B.shape
+    dimps = [torch.empty_like(i) for i in imps]
+    dbias = torch.empty_like(bias) if (bias is not None and S is not None) else None
+    if dbias is None and bias is not None:
+        dbias = torch.zeros_like(bias)
+    _check_dev(B, bias, dA, S, dbias, *imps, *dimps)
+    ip = [_ptr(i) for i in imps] + [_ptr(None)] * (3 - J)
+    dp = [_ptr(i) for i in dimps] + [_ptr(None)] * (3 - J)
+    _call('istgcn_fold_bwd', _ptr(B), J, ip[0], ip[1], ip[2], _ptr(bias), _ptr(dA), _ptr(S), dp[0], dp[1], dp[2],
+          _ptr(dbias if S is not None else None), K, V, int(C), _stream(B))
+    return dimps, dbias
