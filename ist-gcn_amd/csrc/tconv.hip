@@ -127,13 +127,30 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
     const int fin0 = P.in_mul * m0 + P.min_off;          // first staged input frame (may be < 0)
     const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
 
+    // accumulators start at the conv bias (rows of the D tile = output channels: 4 consecutive ones per register
+    // quad), so the epilogue has no bias pass
     f32x16 acc[MTW][NT];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+    for (int m = 0; m < MTW; ++m) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int g = 0; g < 4; ++g) {
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (P.bias) {
+          const int cg = cbase_blk + (wm * MTW + m) * 32 + 8 * g + 4 * (lane >> 5);
+          if (VEC && cg + 3 < P.Cout) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(P.bias + cg);
+            bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
+          } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+            for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) bv[jj] = P.bias[cg + jj];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[m][t][4 * g + jj] = bv[jj];
+      }
+    }
 
     // per-lane LDS row of its output rows at tap offset 0 (pad rows clamp to row 0: computed, never stored)
     int brow[NT];
@@ -214,17 +231,7 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-              const int cg = cbase_blk + ps * 64 + cl;
               float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
-              if (P.bias) {
-                if (VEC && cg + 3 < P.Cout) {
-                  const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + cg);
-                  v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
-                } else {
-#pragma unroll
-                  for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) v4[jj] += P.bias[cg + jj];
-                }
-              }
               store4(outs + sr * P.out_stride + cl, v4);
             }
           }
