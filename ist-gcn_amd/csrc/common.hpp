@@ -94,12 +94,24 @@ __device__ static inline void stage_block(const T* __restrict__ g, size_t gstrid
     const int q = tid & (Q - 1), r0 = tid >> lq, RS = nthreads >> lq;
     const bool qlive = q * EPL < c_lim;
     float scv[EPL], shv[EPL];
-    if (sc) {
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const bool in = VEC ? qlive : (q * EPL + e < c_lim);
-        scv[e] = in ? sc[q * EPL + e] : 0.f;
-        shv[e] = in ? sh[q * EPL + e] : 0.f;
+    for (int e = 0; e < EPL; ++e) { scv[e] = 0.f; shv[e] = 0.f; }
+    if (sc) {
+      if (VEC) {
+        if (qlive) {                         // whole 16-byte loads: one branch, not one per element
+#pragma unroll
+          for (int e4 = 0; e4 < EPL; e4 += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sc + q * EPL + e4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(sh + q * EPL + e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { scv[e4 + e] = a[e]; shv[e4 + e] = b[e]; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          if (q * EPL + e < c_lim) { scv[e] = sc[q * EPL + e]; shv[e] = sh[q * EPL + e]; }
+        }
       }
     }
     const T* src = g + (size_t)r0 * gstride + q * EPL;

@@ -58,7 +58,7 @@ struct TconvParams {
 // WM = waves along the channel axis: the workgroup has 4*WM waves; wave (wr = wave & 3, wm = wave >> 2) owns row slab wr
 // and the MT/WM output-channel tiles [wm*MTW, (wm+1)*MTW).  WM = 2 doubles the waves per CU at the same LDS footprint
 // (these kernels wait on memory and barriers more than half of their wave-cycles).
-template <typename T, int MT, int NT, bool VEC, int WM>
+template <typename T, int MT, int NT, bool VEC, int WM, int MODE>
 __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvParams P) {
   constexpr int NTH = NTHREADS * WM;
   constexpr int MTW = MT / WM;
@@ -243,13 +243,30 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
         const bool col_live = (ps * 64 + vq * EPL) < MT * 32 && cg < P.Cout;
         float s1[EPL], s2[EPL], msc[EPL], msh[EPL], mmu[EPL], mrs[EPL];
 #pragma unroll
-        for (int jj = 0; jj < EPL; ++jj) {
-          s1[jj] = 0.f; s2[jj] = 0.f;
-          const bool in = P.mode == 1 && col_live && cg + jj < P.Cout;
-          msc[jj] = in ? P.maux[cg + jj] : 0.f;
-          msh[jj] = in ? P.maux[P.Cout + cg + jj] : 0.f;
-          mmu[jj] = in ? P.maux[2 * P.Cout + cg + jj] : 0.f;
-          mrs[jj] = in ? P.maux[3 * P.Cout + cg + jj] : 0.f;
+        for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; msc[jj] = 0.f; msh[jj] = 0.f; mmu[jj] = 0.f; mrs[jj] = 0.f; }
+        if constexpr (MODE == 1) {
+          // producer's BatchNorm constants of this thread's channel vector: whole 16-byte loads, no per-element branches
+          if (col_live) {
+            if (VEC) {
+#pragma unroll
+              for (int j4 = 0; j4 < EPL; j4 += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(P.maux + cg + j4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(P.maux + P.Cout + cg + j4);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(P.maux + 2 * P.Cout + cg + j4);
+                const f32x4 d = *reinterpret_cast<const f32x4*>(P.maux + 3 * P.Cout + cg + j4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { msc[j4 + e] = a[e]; msh[j4 + e] = b[e]; mmu[j4 + e] = c[e]; mrs[j4 + e] = d[e]; }
+              }
+            } else {
+#pragma unroll
+              for (int jj = 0; jj < EPL; ++jj) {
+                if (cg + jj < P.Cout) {
+                  msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj];
+                  mmu[jj] = P.maux[2 * P.Cout + cg + jj]; mrs[jj] = P.maux[3 * P.Cout + cg + jj];
+                }
+              }
+            }
+          }
         }
         if (col_live) {
           // UB rows per batch: their LDS reads and (data gradient) aux loads are all issued before the first is used
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
               if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
               else g[u] = ((size_t)(n * P.Tout + (m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
               sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
-              if (P.mode == 1) {
+              if constexpr (MODE == 1) {
                 if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
                 else {
 #pragma unroll
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
               if (!ok[u]) continue;
-              if (P.mode == 1) {
+              if constexpr (MODE == 1) {
 #pragma unroll
                 for (int jj = 0; jj < EPL; ++jj) {
                   if (VEC || cg + jj < P.Cout) {
@@ -374,9 +391,9 @@ template <typename T, int MT, int NT>
 int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   constexpr int WM = 1;   // WM = 2 (8 waves) needs <= 128 VGPRs for two workgroups per CU; the staging/epilogue code does not fit yet
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
-#define GO(VV)                                                                                              \
+#define GO(VV, MD)                                                                                           \
   do {                                                                                                      \
-    auto kfn = tconv_kernel<T, MT, NT, VV, WM>;                                                                 \
+    auto kfn = tconv_kernel<T, MT, NT, VV, WM, MD>;                                                               \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
       hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -387,7 +404,8 @@ int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
     gx = round_up(gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx), 8);  /* XCD-affine order: multiple of 8 */ \
     ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS * WM), lds, stream, P);                                  \
   } while (0)
-  if (vec) GO(true); else GO(false);
+  if (P.mode == 1) { if (vec) GO(true, 1); else GO(false, 1); }
+  else { if (vec) GO(true, 0); else GO(false, 0); }
 #undef GO
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
