@@ -53,6 +53,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V, K = P.K, CCi = P.CCi, DS = P.ds_stride;
   const int Qi = CCi / EPL;
+  const bool cci_pow2 = (CCi & (CCi - 1)) == 0;
+  const int cci_lg = 31 - __builtin_clz(CCi);
 
   // ---- adjacency -> LDS (coalesced), then per-ROW compressed lists: row v -> entries (k, w, a) ----
   {
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
           for (int g = 0; g < 4; ++g) {
             const int kk = m * 32 + 8 * g + 4 * (lane >> 5);
             if (kk < K * CCi) {
-              const int k = kk / CCi, il = kk - k * CCi;
+              // (runtime integer division costs ~40 instructions; CCi is a power of two except for odd tiny Cin)
+              const int k = cci_pow2 ? (kk >> cci_lg) : kk / CCi, il = kk - k * CCi;
               float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
               store4(dxa + (k * TR + p) * CCi + il, v4);
             }
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
             const T* dr = dxa + r_ofs[en];
             float s = 0.f;
             for (int f = 0; f < nf; ++f) {
+#pragma unroll 4
               for (int q = 0; q < Qi; ++q) {
                 const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
                 const frag_t b = *reinterpret_cast<const frag_t*>(dr + (f * V) * CCi + q * EPL);

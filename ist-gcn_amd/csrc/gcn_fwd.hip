@@ -39,7 +39,7 @@ constexpr int TILE_ROWS = 128;
 constexpr int NTHREADS = 256;
 
 template <typename T, int MT, bool VEC_IN, bool VEC_OUT>
-__global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P) {
+__global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(const GcnFwdParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int KGS = E::KGS;
@@ -141,11 +141,32 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
     const int nf = min(P.F, P.Tlog - t0);
     const int rows = nf * V;
 
+    // accumulators start at the bias term bterm[w][c] of their (row, channel): loads issued here, behind the staging
     f32x16 acc[MT];
+    {
+      const int p = wave * 32 + (lane & 31);
+      const bool rowb = P.bterm && p < rows;
+      const float* brow = P.bterm + (rowb ? (int)row_w[p] : 0) * P.Cout + cbase_blk + 4 * (lane >> 5);
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          const int cg = cbase_blk + m * 32 + 8 * g + 4 * (lane >> 5);
+          if (rowb) {
+            if (VEC_OUT && cg + 3 < P.Cout) {
+              const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + m * 32 + 8 * g);
+              bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) bv[j] = brow[m * 32 + 8 * g + j];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[m][4 * g + j] = bv[j];
+        }
+      }
+    }
 
     for (int ch = 0; ch < P.nch; ++ch) {
       const int cb = ch * P.CCeff;
@@ -294,7 +315,6 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
     for (int ps = 0; ps < NPASS; ++ps) {
       {
         const int p = wave * 32 + (lane & 31);
-        const int w = row_w[p];
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
           const int m = 2 * ps + ml;
@@ -302,18 +322,7 @@ __global__ __launch_bounds__(NTHREADS) void gcn_fwd_kernel(const GcnFwdParams P)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-              const int cg = cbase_blk + ps * 64 + cl;
               float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-              if (P.bterm && p < rows) {
-                const float* bsrc = P.bterm + w * P.Cout + cg;
-                if (VEC_OUT && cg + 3 < P.Cout) {
-                  const f32x4 bv = *reinterpret_cast<const f32x4*>(bsrc);
-                  v4[0] += bv[0]; v4[1] += bv[1]; v4[2] += bv[2]; v4[3] += bv[3];
-                } else {
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) v4[j] += bsrc[j];
-                }
-              }
               store4(outs + p * P.out_stride + cl, v4);
             }
           }
@@ -427,7 +436,9 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   P.KKp = round_up(P.K * P.CCeff, E::KGS);
   P.NKG = P.KKp / E::KGS;
   if (P.KKp / EPL > 64) return ISTGCN_EINVAL;
-  int MT = P.Cout <= 32 ? 1 : P.Cout <= 64 ? 2 : P.Cout <= 128 ? 4 : 8;
+  // at most 4 channel tiles per workgroup: the 8-tile kernel needs > 256 VGPRs, i.e. ONE 4-wave workgroup per CU, and
+  // lost more to exposed latency than the second channel block costs in repeated aggregation
+  int MT = P.Cout <= 32 ? 1 : P.Cout <= 64 ? 2 : 4;
   int gy = ceil_div(P.Cout, MT * 32);
   P.MTtot = gy * MT;
   P.F = TILE_ROWS / P.V;
@@ -488,7 +499,7 @@ extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCe
   if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
   const int epl = dtype == 0 ? 4 : 8, cc = dtype == 0 ? 32 : 64, kgs = 2 * epl;
   int cce = Cin >= cc ? cc : round_up(Cin, epl);
-  int MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : Cout <= 128 ? 4 : 8;
+  int MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
   *CCeff = cce; *nch = ceil_div(Cin, cce); *KKp = round_up(K * cce, kgs);
   *MTtot = ceil_div(Cout, MT * 32) * MT; *EPL = epl;
   return ISTGCN_OK;
