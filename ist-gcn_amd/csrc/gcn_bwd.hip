@@ -43,15 +43,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   unsigned char* r_v = smem + P.off_rv;                                              // [cap] v of entry
   unsigned short* r_kw = reinterpret_cast<unsigned short*>(smem + P.off_rkw);        // [cap] k*V + w
   float* r_a = reinterpret_cast<float*>(smem + P.off_ra);                            // [cap]
-  int* r_ofs = reinterpret_cast<int*>(smem + P.off_dacc);                            // [cap] (k*TR + w)*CCi: dxa offset of entry
+  int* r_ofs = reinterpret_cast<int*>(smem + P.off_dacc);                            // [cap] (k*NCH*TR + w)*EPL: dxa offset of entry (chunk 0, frame 0)
   unsigned char* row_f = smem + P.off_rows;                                          // [TR]
   unsigned char* row_v = row_f + TR;                                                 // [TR]
   T* dys = reinterpret_cast<T*>(smem + P.off_dys);                                   // [TR][ds_stride]  (later: x chunk)
-  T* dxa = reinterpret_cast<T*>(smem + P.off_dxa);                                   // [K][TR][CCi] (+32 zero rows)
+  T* dxa = reinterpret_cast<T*>(smem + P.off_dxa);                                   // [K][NCH][TR][EPL] (+32 zero slots)
   T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                               // bf16: [K][2][64][8] fragments of A_k^T
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int V = P.V, K = P.K, CCi = P.CCi, DS = P.ds_stride;
+  // dxa lives CHUNK-MAJOR in LDS: [k][16-byte channel chunk][row][EPL].  Row-major 128-byte rows put the 32 lanes of an
+  // accumulator store (consecutive rows, same channels) on 4 banks -- a 16-way conflict that was 45 % of the bf16 kernel;
+  // here consecutive rows are consecutive 16-byte slots.  element (k, row, col) -> ((k*NCH + col/EPL)*TR + row)*EPL + col%EPL
+  const int NCH = CCi / EPL;
   const int Qi = CCi / EPL;
   const bool cci_pow2 = (CCi & (CCi - 1)) == 0;
   const int cci_lg = 31 - __builtin_clz(CCi);
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
           if (a != 0.f) {
             if (e < P.nnz_cap) {
               r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = a;
-              r_ofs[e] = (k * TR + w) * CCi;
+              r_ofs[e] = (k * NCH * TR + w) * EPL;
             }
             ++e;
           }
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
       }
       *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
     }
-    for (int idx = tid; idx < 32 * Qi; idx += NTHREADS) {
+    for (int idx = tid; idx < 32; idx += NTHREADS) {     // the last frame's k-range runs 32 - V rows past the last chunk
       frag_t z;
       zero_frag<T>(z);
-      *reinterpret_cast<frag_t*>(dxa + (size_t)K * TR * CCi + idx * EPL) = z;
+      *reinterpret_cast<frag_t*>(dxa + ((size_t)K * NCH * TR + idx) * EPL) = z;
     }
   }
   const int nnz = min(r_off[V], P.nnz_cap);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
               // (runtime integer division costs ~40 instructions; CCi is a power of two except for odd tiny Cin)
               const int k = cci_pow2 ? (kk >> cci_lg) : kk / CCi, il = kk - k * CCi;
               float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-              store4(dxa + (k * TR + p) * CCi + il, v4);
+              store4(dxa + ((k * NCH + il / EPL) * TR + p) * EPL + il % EPL, v4);
             }
           }
         }
@@ -219,9 +223,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
           for (int k = 0; k < K; ++k) {
 #pragma unroll
             for (int sstep = 0; sstep < 2; ++sstep) {
-              const T* r0 = dxa + (k * TR + f * V + 16 * sstep + 8 * h + q4) * CCi + ct * 32 + cblk + 4 * pp;
+              const int c0 = ct * 32 + cblk + 4 * pp;
+              const int cc = c0 < CCi ? c0 : 0;         // channels beyond the chunk: any finite data (results discarded)
+              const T* r0 = dxa + ((k * NCH + cc / EPL) * TR + f * V + 16 * sstep + 8 * h + q4) * EPL + cc % EPL;
               s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)r0);
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * CCi));
+              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * EPL));
               bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
               frag_t a;
               a[0] = l4[0]; a[1] = l4[1]; a[2] = l4[2]; a[3] = l4[3];
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
             float sum[EPL];
 #pragma unroll
             for (int e = 0; e < EPL; ++e) sum[e] = 0.f;
-            const T* dbase = dxa + (f * V) * CCi + q * EPL;
+            const T* dbase = dxa + (q * TR + f * V) * EPL;
             for (int en = e0; en < e1; ++en) {
               const float a = r_a[en];
               const frag_t dv = *reinterpret_cast<const frag_t*>(dbase + r_ofs[en]);
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
 #pragma unroll 4
               for (int q = 0; q < Qi; ++q) {
                 const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
-                const frag_t b = *reinterpret_cast<const frag_t*>(dr + (f * V) * CCi + q * EPL);
+                const frag_t b = *reinterpret_cast<const frag_t*>(dr + (q * TR + f * V) * EPL);
                 if constexpr (sizeof(T) == 2) {
                   // v_dot2c_f32_bf16: two bf16 products per lane-op, no conversions
                   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
