@@ -133,6 +133,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   const T* addg = reinterpret_cast<const T*>(P.addend);
   T* dxg = reinterpret_cast<T*>(P.dx);
 
+  // The GEMM's weight fragments of one (input chunk, output chunk) step live in REGISTERS: with an even tile count the
+  // four waves split the (k,i) rows in two halves and the positions in two 64-row halves, so a wave needs only
+  // NKGc * MTK/2 <= 12 fragments per step and every fragment feeds two MFMAs.  They are fetched at the top of each step,
+  // in front of the dy chunk (one memory round trip for both).  (Streaming them per k-group from L2, one fragment per
+  // MFMA, left the matrix cores waiting on L2 latency: ~30 % of the kernel.)
+  constexpr bool MSPLIT = (MTK % 2) == 0;
+  constexpr int MH = MSPLIT ? MTK / 2 : MTK;         // (k,i) tiles per wave
+  constexpr int NTW = MSPLIT ? 2 : 1;                // 32-row position tiles per wave
+  const int ph = MSPLIT ? (wave & 1) : wave, mh = MSPLIT ? (wave >> 1) : 0;
+  frag_t wr[4][MH];
+  auto load_weights = [&](int step) {
+    const T* wfrag = Wb + ((size_t)step * P.NKGc * MTK * 64 + lane) * EPL;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+      for (int m = 0; m < MH; ++m)
+        if (kg < P.NKGc) wr[kg][m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)kg * MTK + mh * MH + m) * 64 * EPL);
+  };
+
   for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
     const int n = tile / P.tiles_per_seq;
     const int t0 = (tile - n * P.tiles_per_seq) * P.F;
@@ -142,59 +161,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
 
     for (int ich = 0; ich < P.nchi; ++ich) {
       const int ib = ich * CCi;
-      f32x16 acc[MTK];
+      f32x16 acc[MH][NTW];
 #pragma unroll
-      for (int m = 0; m < MTK; ++m)
+      for (int m = 0; m < MH; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
       for (int cch = 0; cch < P.nchc; ++cch) {
         const int cb = cch * P.CCc;
-        stage_block<T, 8, VEC>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
+        // this step's weight fragments first (L2), the dy chunk right behind them: one memory round trip for both
+        load_weights(ich * P.nchc + cch);
+        stage_block<T, 4, VEC>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
                                nullptr, nullptr, 0, tid, NTHREADS);
         __syncthreads();
         {
-          const T* brow = dys + (wave * 32 + (lane & 31)) * DS + (lane >> 5) * EPL;
-          const T* wfrag = Wb + ((size_t)(ich * P.nchc + cch) * P.NKGc * MTK * 64 + lane) * EPL;
-          frag_t a0[MTK], a1[MTK], b0, b1;
-          auto load_step = [&](int kg, frag_t (&a)[MTK], frag_t& b) {
+          const T* brow = dys + (ph * 32 * NTW + (lane & 31)) * DS + (lane >> 5) * EPL;
 #pragma unroll
-            for (int m = 0; m < MTK; ++m)
-              a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)kg * MTK + m) * 64 * EPL);
-            b = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
-          };
-          load_step(0, a0, b0);
-          for (int kg = 0; kg < P.NKGc; kg += 2) {
-            load_step(min(kg + 1, P.NKGc - 1), a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int kg = 0; kg < 4; ++kg) {
+            if (kg < P.NKGc) {
+              frag_t bf[NTW];
 #pragma unroll
-            for (int m = 0; m < MTK; ++m) mma_kgroup(acc[m], a0[m], b0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_step(min(kg + 2, P.NKGc - 1), a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kg + 1 < P.NKGc) {
+              for (int t = 0; t < NTW; ++t) bf[t] = *reinterpret_cast<const frag_t*>(brow + t * 32 * DS + kg * KGS);
 #pragma unroll
-              for (int m = 0; m < MTK; ++m) mma_kgroup(acc[m], a1[m], b1);
+              for (int m = 0; m < MH; ++m)
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) mma_kgroup(acc[m][t], wr[kg][m], bf[t]);
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
         }
         __syncthreads();
       }
 
-      // ---- dxa chunk -> LDS [k][p][il]; x chunk -> the (now free) dy buffer for the adjacency gradient ----
+      // ---- dxa chunk -> LDS (chunk-major); x chunk -> the (now free) dy buffer for the adjacency gradient ----
       {
-        const int p = wave * 32 + (lane & 31);
 #pragma unroll
-        for (int m = 0; m < MTK; ++m) {
+        for (int t = 0; t < NTW; ++t) {
+          const int p = ph * 32 * NTW + t * 32 + (lane & 31);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int kk = m * 32 + 8 * g + 4 * (lane >> 5);
-            if (kk < K * CCi) {
-              // (runtime integer division costs ~40 instructions; CCi is a power of two except for odd tiny Cin)
-              const int k = cci_pow2 ? (kk >> cci_lg) : kk / CCi, il = kk - k * CCi;
-              float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-              store4(dxa + ((k * NCH + il / EPL) * TR + p) * EPL + il % EPL, v4);
+          for (int m = 0; m < MH; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int kk = (mh * MH + m) * 32 + 8 * g + 4 * (lane >> 5);
+              if (kk < K * CCi) {
+                // (runtime integer division costs ~40 instructions; CCi is a power of two except for odd tiny Cin)
+                const int k = cci_pow2 ? (kk >> cci_lg) : kk / CCi, il = kk - k * CCi;
+                float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
+                store4(dxa + ((k * NCH + il / EPL) * TR + p) * EPL + il % EPL, v4);
+              }
             }
           }
         }
