@@ -219,12 +219,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
                                nullptr, 0, tid, NTHREADS);
       __syncthreads();
 
+      auto dA_dots = [&]() {
+      // ---- adjacency gradient on the pattern: thread t owns entries t, t+256, ... and keeps their sums in registers
+      //      across tiles and chunks (flushed once per workgroup) ----
+      if (P.dA) {
+#pragma unroll
+        for (int pe = 0; pe < NPE; ++pe) {
+          const int en = tid + pe * NTHREADS;
+          if (en < nnz) {
+            const T* xr = dys + r_v[en] * DS;
+            const T* dr = dxa + r_ofs[en];
+            float s = 0.f;
+            for (int f = 0; f < nf; ++f) {
+#pragma unroll 4
+              for (int q = 0; q < Qi; ++q) {
+                const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
+                const frag_t b = *reinterpret_cast<const frag_t*>(dr + (q * TR + f * V) * EPL);
+                if constexpr (sizeof(T) == 2) {
+                  // v_dot2c_f32_bf16: two bf16 products per lane-op, no conversions
+                  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                  for (int e = 0; e < EPL; e += 2) {
+                    const bf16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
+                    s = __builtin_amdgcn_fdot2_f32_bf16(a2, b2, s, false);
+                  }
+                } else {
+#pragma unroll
+                  for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
+                }
+              }
+            }
+            dsum[pe] += s;
+          }
+        }
+      }
+      };
       bool agg_done = false;
       if constexpr (sizeof(T) == 2) if (mfma_agg) {
         // ---- bf16: transposed aggregation on the matrix cores.  Per (frame f, 32-channel tile ct):
         //      D[i][v] = sum_k sum_w dxa_k[(f,w)][i] * A_k[v][w]; dxa^T comes straight from the row-major images with
         //      ds_read_b64_tr_b16, the adjacency fragments from LDS; lane = joint v, 4 consecutive channels per quad. ----
         agg_done = true;
+        // the adjacency gradient first (it needs x in `dys`); then `dys` becomes the staging buffer of dx, so the
+        // global stores are whole 16-byte vectors of contiguous rows instead of 8-byte pieces of 25 different lines
+        dA_dots();
+        __syncthreads();
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         const int CT = (CCi + 31) >> 5;
         const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
@@ -252,28 +291,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
             }
           }
           if (v < V) {
-            const size_t grow = (pos0 + f * V + v) * P.Cin + ib;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int il = ct * 32 + 8 * g + 4 * (lane >> 5);
-              if (il < CCi && ib + il < P.Cin) {
+              if (il < CCi) {
                 float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-                if (VEC) {
-                  if (addg) {
-                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(addg + grow + il);
-                    v4[0] += (float)av[0]; v4[1] += (float)av[1]; v4[2] += (float)av[2]; v4[3] += (float)av[3];
-                  }
-                  bf16x4 o = {(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
-                  *reinterpret_cast<bf16x4*>(dxg + grow + il) = o;
-                } else {
+                store4(dys + (f * V + v) * DS + il, v4);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        {
+          // rows of the tile are contiguous in HBM: item -> (row, vector), UB rows per batch in flight
+          constexpr int UB = 4;
+          const int q = tid % Qi, r0 = tid / Qi, RS = NTHREADS / Qi;      // Qi divides 256 (CCi is a power of two here)
+          const int i0 = ib + q * EPL;
+          if ((NTHREADS % Qi) == 0 && i0 < P.Cin) {
+            for (int rb = r0; rb < rows; rb += RS * UB) {
+              frag_t sv[UB], av[UB];
+              bool ok[UB];
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    if (ib + il + e < P.Cin) {
-                      float fv = v4[e];
-                      if (addg) fv += E::to_f(addg[grow + il + e]);
-                      dxg[grow + il + e] = E::from_f(fv);
-                    }
+              for (int u = 0; u < UB; ++u) {
+                const int r = rb + u * RS;
+                ok[u] = r < rows;
+                const int rc = ok[u] ? r : rb;
+                sv[u] = *reinterpret_cast<const frag_t*>(dys + rc * DS + q * EPL);
+                if (addg) {
+                  const size_t g = (pos0 + rc) * P.Cin + i0;
+                  if (VEC) av[u] = *reinterpret_cast<const frag_t*>(addg + g);
+                  else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) av[u][e] = (i0 + e < P.Cin) ? addg[g + e] : E::from_f(0.f);
                   }
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < UB; ++u) {
+                if (!ok[u]) continue;
+                const size_t g = (pos0 + rb + u * RS) * P.Cin + i0;
+                frag_t o = sv[u];
+                if (addg) {
+#pragma unroll
+                  for (int e = 0; e < EPL; ++e) o[e] = E::from_f(E::to_f(sv[u][e]) + E::to_f(av[u][e]));
+                }
+                if (VEC) *reinterpret_cast<frag_t*>(dxg + g) = o;
+                else {
+#pragma unroll
+                  for (int e = 0; e < EPL; ++e) if (i0 + e < P.Cin) dxg[g + e] = o[e];
+                }
+              }
+            }
+          } else if ((NTHREADS % Qi) != 0) {
+            for (int it = tid; it < rows * Qi; it += NTHREADS) {        // odd chunk widths: plain item loop
+              const int r = it / Qi, qq = it - r * Qi;
+              const size_t g = (pos0 + r) * P.Cin + ib + qq * EPL;
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) {
+                if (ib + qq * EPL + e < P.Cin) {
+                  float fv = E::to_f(dys[r * DS + qq * EPL + e]);
+                  if (addg) fv += E::to_f(addg[g + e]);
+                  dxg[g + e] = E::from_f(fv);
                 }
               }
             }
@@ -326,39 +404,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         }
       }
       }
-      // ---- adjacency gradient on the pattern: thread t owns entries t, t+256, ... and keeps their sums in registers
-      //      across tiles and chunks (flushed once per workgroup) ----
-      if (P.dA) {
-#pragma unroll
-        for (int pe = 0; pe < NPE; ++pe) {
-          const int en = tid + pe * NTHREADS;
-          if (en < nnz) {
-            const T* xr = dys + r_v[en] * DS;
-            const T* dr = dxa + r_ofs[en];
-            float s = 0.f;
-            for (int f = 0; f < nf; ++f) {
-#pragma unroll 4
-              for (int q = 0; q < Qi; ++q) {
-                const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
-                const frag_t b = *reinterpret_cast<const frag_t*>(dr + (q * TR + f * V) * EPL);
-                if constexpr (sizeof(T) == 2) {
-                  // v_dot2c_f32_bf16: two bf16 products per lane-op, no conversions
-                  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                  for (int e = 0; e < EPL; e += 2) {
-                    const bf16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
-                    s = __builtin_amdgcn_fdot2_f32_bf16(a2, b2, s, false);
-                  }
-                } else {
-#pragma unroll
-                  for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
-                }
-              }
-            }
-            dsum[pe] += s;
-          }
-        }
-      }
+      if (!agg_done) dA_dots();
       __syncthreads();
     }
   }
