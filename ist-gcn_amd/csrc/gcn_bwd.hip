@@ -32,7 +32,7 @@ struct GbdParams {
   int off_rv, off_rkw, off_ra, off_dacc, off_rows, off_afrag, off_dys, off_dxa;
 };
 
-template <typename T, int MTK, bool VEC>
+template <typename T, int MTK, bool VEC, bool AGGM>
 __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
@@ -100,8 +100,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
     }
     __syncthreads();
   }
-  const bool mfma_agg = sizeof(T) == 2 && V <= 32;
-  if (mfma_agg) {
+  // AGGM (bf16 and V <= 32, chosen by the launcher): aggregation and adjacency gradient on the matrix cores
+  constexpr bool mfma_agg = AGGM;
+  // adjacency gradient as an MFMA product (wave k owns dA_k): measured SLOWER than the per-entry dot products (a chain
+  // of 20 dependent MFMAs on three waves vs 135 independent threads); kept for reference, off
+  constexpr bool DAM = false;
+  static_assert(!AGGM || sizeof(T) == 2, "MFMA aggregation is the bf16 path");
+  if constexpr (mfma_agg) {
     // B-operand fragments of A_k^T for the transposed aggregation on the matrix cores: lane (v = lane&31, h), k-step s,
     // element j holds A[k][v][w = 16s + 8h + j]; and 32 zero rows behind the last dxa image (the last frame's k-range)
     for (int idx = tid; idx < K * 2 * 64; idx += NTHREADS) {
@@ -123,9 +128,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   }
   const int nnz = min(r_off[V], P.nnz_cap);
   constexpr int NPE = 16;                    // entries per thread: 16 * 256 >= K*V*V (checked on the host)
-  float dsum[NPE];
+  float dsum[DAM ? 1 : NPE];
 #pragma unroll
-  for (int pe = 0; pe < NPE; ++pe) dsum[pe] = 0.f;
+  for (int pe = 0; pe < (DAM ? 1 : NPE); ++pe) dsum[pe] = 0.f;
+  // bf16: the adjacency gradient is a [V x C] x [C x V] product per (frame, k) -- wave k keeps the dense 32x32 tile
+  // dA_k[v][w] in 16 accumulator registers across the whole walk (instead of 16 per-entry sums) and the operands are
+  // plain 16-byte row reads of the x tile and of the chunk-major dxa image
+  f32x16 dAacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dAacc[r] = 0.f;
 
   const T* dyg = reinterpret_cast<const T*>(P.dy);
   const T* xg = reinterpret_cast<const T*>(P.x);
@@ -222,7 +233,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
       auto dA_dots = [&]() {
       // ---- adjacency gradient on the pattern: thread t owns entries t, t+256, ... and keeps their sums in registers
       //      across tiles and chunks (flushed once per workgroup) ----
-      if (P.dA) {
+      bool dots_done = false;
+      if constexpr (DAM) if (P.dA) {
+        dots_done = true;
+        if (wave < K) {
+          const int k = wave, rl = lane & 31, hq = lane >> 5;
+          const int nks = (Qi + 1) >> 1;
+          for (int f = 0; f < nf; ++f) {
+            const T* xrow = dys + (f * V + rl) * DS;
+            const T* drow = dxa + ((size_t)k * NCH * TR + f * V + rl) * EPL;
+            for (int ks = 0; ks < nks; ++ks) {
+              const int q = 2 * ks + hq;
+              frag_t a, b;
+              zero_frag<T>(a);
+              zero_frag<T>(b);
+              if (q < Qi) {
+                a = *reinterpret_cast<const frag_t*>(xrow + q * EPL);
+                b = *reinterpret_cast<const frag_t*>(drow + (size_t)q * TR * EPL);
+              }
+              dAacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, dAacc, 0, 0, 0);
+            }
+          }
+        }
+      }
+      if constexpr (!DAM) if (P.dA && !dots_done) {
 #pragma unroll
         for (int pe = 0; pe < NPE; ++pe) {
           const int en = tid + pe * NTHREADS;
@@ -255,7 +289,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
       }
       };
       bool agg_done = false;
-      if constexpr (sizeof(T) == 2) if (mfma_agg) {
+      if constexpr (AGGM) {
         // ---- bf16: transposed aggregation on the matrix cores.  Per (frame f, 32-channel tile ct):
         //      D[i][v] = sum_k sum_w dxa_k[(f,w)][i] * A_k[v][w]; dxa^T comes straight from the row-major images with
         //      ds_read_b64_tr_b16, the adjacency fragments from LDS; lane = joint v, 4 consecutive channels per quad. ----
@@ -358,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
           }
         }
       }
-      if (!agg_done) {
+      if constexpr (!AGGM) if (!agg_done) {
       // ---- (VALU path) dx[(f,v)][i] = sum over row v of A: a * dxa_k[(f,w)][i]  (+ addend), straight to HBM.
       //      Wave w owns joints v = w, w+4, ... (wave-uniform entry lists); lanes span (frame, channel vector). ----
       {
@@ -410,13 +444,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
   }
 
   if (P.dA) {
+    bool flushed = false;
+    if constexpr (DAM) {
+      flushed = true;
+      if (wave < K) {
+        const int w = lane & 31;
 #pragma unroll
-    for (int pe = 0; pe < NPE; ++pe) {
-      const int en = tid + pe * NTHREADS;
-      if (en < nnz) {
-        const int kw = r_kw[en];
-        const int k = kw / V, w = kw - k * V;
-        atomicAdd(P.dA + (k * V + r_v[en]) * V + w, dsum[pe]);
+        for (int r = 0; r < 16; ++r) {
+          const int v = mfma_row(r, lane);
+          if (v < V && w < V && P.A[(wave * V + v) * V + w] != 0.f)     // gradient on the sparsity pattern only
+            atomicAdd(P.dA + (wave * V + v) * V + w, dAacc[r]);
+        }
+      }
+    }
+    if constexpr (!DAM) if (!flushed) {
+#pragma unroll
+      for (int pe = 0; pe < NPE; ++pe) {
+        const int en = tid + pe * NTHREADS;
+        if (en < nnz) {
+          const int kw = r_kw[en];
+          const int k = kw / V, w = kw - k * V;
+          atomicAdd(P.dA + (k * V + r_v[en]) * V + w, dsum[pe]);
+        }
       }
     }
   }
@@ -438,9 +487,9 @@ inline void gbd_geom(int Cin, int Cout, int K, int dtype, GbdGeom* G) {
 template <typename T, int MTK>
 int launch_mtk(GbdParams& P, int grid_cap, size_t lds, hipStream_t stream) {
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
-#define GO(VV)                                                                                              \
+#define GO(VV, AG)                                                                                          \
   do {                                                                                                      \
-    auto kfn = gcn_bwd_kernel<T, MTK, VV>;                                                                  \
+    auto kfn = gcn_bwd_kernel<T, MTK, VV, AG>;                                                                \
     static bool attr_done = false;                                                                          \
     if (!attr_done) {                                                                                       \
       hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -451,7 +500,12 @@ int launch_mtk(GbdParams& P, int grid_cap, size_t lds, hipStream_t stream) {
     gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
     ISTGCN_LAUNCH(kfn, dim3(gx), dim3(NTHREADS), lds, stream, P);                                           \
   } while (0)
-  if (vec) GO(true); else GO(false);
+  if constexpr (sizeof(T) == 2) {
+    if (P.V <= 32) { if (vec) GO(true, true); else GO(false, true); }
+    else { if (vec) GO(true, false); else GO(false, false); }
+  } else {
+    if (vec) GO(true, false); else GO(false, false);
+  }
 #undef GO
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
