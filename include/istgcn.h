@@ -121,7 +121,7 @@ int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_c, long lon
  *   A_eff = sum_j B_j (.) imp_j   (J = 1: A*importance, st_gcnold.py:86; J = 3: the Inception-GCN sum of
  *           st_gcn_msgcn.py:116-117 or the elementwise powers of tgcn_multi3_fix_3A.py:86-89; B = [J][K][V][V])
  *   bterm[w][c] = sum_k bias[k*C+c] * sum_v A_eff[k][v][w]   (Conv2d bias pushed through the einsum, tgcn.py:79-86)
- * and their gradients: dimp_j = B_j (.) (dA + dcol broadcast over v), dbias (see csrc/fold.hip). K*V <= 512. */
+ * and their gradients: dimp_j = B_j (.) (dA + dcol broadcast over v), dbias (see csrc/fold.hip). K*V <= 512 and K*V*V <= 12288. */
 int istgcn_fold_fwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2, const float* bias,
                     float* A_eff, float* bterm, int K, int V, int C, void* stream);
 int istgcn_fold_bwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2, const float* bias,

@@ -274,7 +274,8 @@ class STGCNModel(nn.Module):
         imps = [self.edge_importance[i]]
         if self.gcn_kind in ('incep', '3a'):
             imps += [self.edge_importance2[i], self.edge_importance3[i]]
-        if all(isinstance(p, torch.Tensor) and p.is_cuda for p in imps):
+        K, V = self.A.shape[0], self.A.shape[1]
+        if all(isinstance(p, torch.Tensor) and p.is_cuda for p in imps) and K * V <= 512 and K * V * V <= 12288:
             conv = blk.gcn.the_conv()
             return Fn.FoldFn.apply(self._fold_B(imps[0].device), conv.bias, blk.cout, *imps)
         return self._a_eff(i), _UNSET
