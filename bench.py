@@ -36,8 +36,14 @@ MODELS = {
 }
 FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit GEMM)',
           'istgcn_tconv_wgrad': 'tconv_wgrad', 'istgcn_gcn_fwd': 'gcn_fwd (graph conv fwd + data-grad)',
-          'istgcn_gcn_wgrad': 'gcn_wgrad', 'istgcn_block_out_fwd': 'block_out_fwd', 'istgcn_block_out_bwd': 'block_out_bwd',
+          'istgcn_gcn_wgrad': 'gcn_wgrad', 'istgcn_gcn_bwd_data': 'gcn_bwd_data (graph conv data + adjacency gradient)', 'istgcn_block_out_fwd': 'block_out_fwd', 'istgcn_block_out_bwd': 'block_out_bwd',
           'istgcn_affine2': 'bn_bwd_apply'}
+
+
+PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'tconv_wgrad_kernel', 'istgcn_gcn_fwd': 'gcn_fwd_kernel',
+           'istgcn_gcn_bwd_data': 'gcn_bwd_kernel', 'istgcn_gcn_wgrad': 'tconv_wgrad_kernel',
+           'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
+           'istgcn_affine2': 'affine2_kernel'}
 
 
 def cpu_baseline(model_tag, T, seconds_budget=25.0):
@@ -152,7 +158,17 @@ def main():
     else:
         roof = {'bound': 'hbm', 'achieved': round(nbytes / secs / 1e9, 1), 'peak': PEAK['hbm'], 'unit': 'GB/s'}
     roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this
+    # command, corrected as MI355X_MICROARCH.md prescribes; profiles/r01_final_bf16_pmc_traffic.json) -- only for the
+    # configuration they were collected on
     roof['traffic'] = None
+    roof['algorithmic_bytes_per_launch'] = round(nbytes / n)
+    pmc_file = os.path.join(ROOT, 'profiles', 'r01_final_bf16_pmc_traffic.json')
+    if dt == torch.bfloat16 and args.model == 'st_gcn_msgcn' and B == 64 and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))['kernels'].get(PMC_KEY.get(dom, ''))
+        if pmc:
+            roof['traffic'] = pmc['hbm_bytes_avg']
+            roof['traffic_source'] = 'profiles/r01_final_bf16_pmc_traffic.json'
     roof['kernel'] = FAMILY.get(dom, dom)
     roof['launches'] = n
     roof['avg_launch_ms'] = round(secs / n * 1e3, 4)
