@@ -11,8 +11,11 @@ import torch.nn.functional as F
 def make_optimizer(model, optimizer='SGD', base_lr=0.1, nesterov=True, weight_decay=1e-4):
     """recognition.py:152-166"""
     if optimizer == 'SGD':
-        return torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, nesterov=nesterov,
-                               weight_decay=weight_decay)
+        params = list(model.parameters())
+        # same update rule, one multi-tensor kernel per step instead of ~11 (weight decay, momentum, nesterov, update)
+        fused = bool(params) and all(p.is_cuda for p in params)
+        return torch.optim.SGD(params, lr=base_lr, momentum=0.9, nesterov=nesterov, weight_decay=weight_decay,
+                               fused=fused)
     if optimizer == 'Adam':
         return torch.optim.Adam(model.parameters(), lr=base_lr, weight_decay=weight_decay)
     raise ValueError()
