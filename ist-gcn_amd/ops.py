@@ -51,11 +51,12 @@ def _check_dev(*ts):
 # appends (entry point, algorithmic flops, algorithmic bytes, start event, end event), the events recorded on the
 # stream the kernel was launched on.  None (default) = no events, no overhead.
 PROFILE = None
+PROFILE_ONLY = None     # if set: only launches of this entry point are timed (keeps the event overhead off the others)
 
 
 def _call(fn_name, *args, work=None):
     lib = _lib.load()
-    if PROFILE is not None and work is not None:
+    if PROFILE is not None and work is not None and (PROFILE_ONLY is None or PROFILE_ONLY == fn_name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, fn_name)(*args)
