@@ -26,24 +26,37 @@ __device__ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k
   out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
-// keep-mask scale factors (0 or 1/(1-p)) for VW consecutive elements starting at flat element index e0 (e0 % 4 == 0)
+// keep-mask scale factors (0 or 1/(1-p)) for VW consecutive elements starting at flat element index e0 (e0 % VW == 0,
+// VW in {4, 8}).  One Philox call yields EIGHT 16-bit uniform draws: element e uses draw e & 7 of block e >> 3 (the
+// probability is resolved to 2^-16; a 32-bit draw per element doubled the integer work of the bf16 kernels).
 template <int VW>
 __device__ static inline void drop_scales(float (&m)[VW], size_t e0, uint32_t thr, float inv_keep, uint32_t s0, uint32_t s1) {
 #pragma unroll
-  for (int b = 0; b < (VW + 3) / 4; ++b) {
+  for (int b = 0; b < (VW + 7) / 8; ++b) {
     uint32_t rnd[4];
-    const size_t blk = e0 / 4 + b;
+    const size_t blk = e0 / 8 + b;
     philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s0, s1, rnd);
+    const int j0 = VW >= 8 ? 0 : (int)(e0 & 7);            // 0, or 4 for the upper half of a block (VW == 4)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (4 * b + j < VW) m[4 * b + j] = rnd[j] >= thr ? inv_keep : 0.f;
+    for (int j = 0; j < (VW < 8 ? VW : 8); ++j) {
+      const int d = j0 + j;                                // draw index within the block
+      uint32_t w = rnd[0];
+      if ((d >> 1) == 1) w = rnd[1];
+      if ((d >> 1) == 2) w = rnd[2];
+      if ((d >> 1) == 3) w = rnd[3];
+      const uint32_t v = (d & 1) ? (w >> 16) : (w & 0xFFFFu);
+      if (8 * b + j < VW) m[8 * b + j] = v >= thr ? inv_keep : 0.f;
+    }
   }
 }
 __device__ static inline float drop_scale1(size_t e, uint32_t thr, float inv_keep, uint32_t s0, uint32_t s1) {
   uint32_t rnd[4];
-  const size_t blk = e / 4;
+  const size_t blk = e / 8;
   philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), s0, s1, rnd);
-  return rnd[e & 3] >= thr ? inv_keep : 0.f;
+  const int d = (int)(e & 7);
+  const uint32_t w = rnd[d >> 1];
+  const uint32_t v = (d & 1) ? (w >> 16) : (w & 0xFFFFu);
+  return v >= thr ? inv_keep : 0.f;
 }
 
 template <typename T, int VW>
@@ -76,8 +89,8 @@ static inline DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg d{};
   d.on = p > 0.f;
   if (d.on) {
-    double t = (double)p * 4294967296.0;
-    d.thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    double t = (double)p * 65536.0 + 0.5;                  // 16-bit draws: drop when draw < thr
+    d.thr = t >= 65536.0 ? 65536u : (uint32_t)t;
     d.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
     d.s0 = (uint32_t)seed; d.s1 = (uint32_t)(seed >> 32);
   }
