@@ -219,6 +219,37 @@ __device__ static inline void mfma_ring(int nit, LoadF load, MmaF mma) {
   }
 }
 
+// The same ring with the two operand streams split: `loadA` (weights, global/L2 -- independent of the LDS tile) can be
+// primed BEFORE the phase that produces the LDS operand (ring_prime_a), so the ring-fill latency (an L2 round trip
+// before the first MFMA -- most of a 12-step loop) overlaps that phase; `loadB` reads LDS.
+template <int D, int NA, int NB, typename FragT>
+struct MfmaRing {
+  FragT a[D][NA], b[D][NB];
+};
+
+template <int D, int NA, int NB, typename FragT, typename LoadA>
+__device__ static inline void ring_prime_a(MfmaRing<D, NA, NB, FragT>& R, int nit, LoadA loadA) {
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) loadA(min(d, nit - 1), R.a[d]);
+}
+
+template <int D, int NA, int NB, typename FragT, typename LoadA, typename LoadB, typename MmaF>
+__device__ static inline void ring_run(MfmaRing<D, NA, NB, FragT>& R, int nit, LoadA loadA, LoadB loadB, MmaF mma) {
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) loadB(min(d, nit - 1), R.b[d]);
+  for (int it0 = 0; it0 < nit; it0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int nx = min(it0 + d + D - 1, nit - 1);
+      loadA(nx, R.a[(d + D - 1) % D]);
+      loadB(nx, R.b[(d + D - 1) % D]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + d < nit) mma(R.a[d], R.b[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 __device__ static inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -192,6 +192,17 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
         }
       }
       __syncthreads();
+      // weight fragments of the first ring slots: fetched now, in flight during the aggregation (which touches only LDS).
+      // The contraction loop is 12 k-groups long; an L2 round trip in front of its first MFMA was most of its time.
+      constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MT <= 2 ? 4 : (MT <= 4 ? 3 : 2));
+      const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
+      auto load_a = [&](int kg, frag_t (&a)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
+      };
+      MfmaRing<DEPTH, MT, 1, frag_t> ring;
+      ring_prime_a(ring, P.NKG, load_a);
       bool agg_done = false;
       if constexpr (sizeof(T) == 2) if (V <= 32) {
         agg_done = true;
@@ -287,22 +298,15 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
         }
       }
       __syncthreads();
-      // ---- channel contraction on the matrix cores (weight fragments of k-group kg+1 in flight during kg) ----
+      // ---- channel contraction on the matrix cores (ring of weight fragments from L2 and xa fragments from LDS) ----
       {
         const T* brow = xa + (wave * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
-        const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-        auto load_step = [&](int kg, frag_t (&a)[MT], frag_t (&b)[1]) {
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
-          b[0] = *reinterpret_cast<const frag_t*>(brow + kg * KGS);
-        };
+        auto load_b = [&](int kg, frag_t (&b)[1]) { b[0] = *reinterpret_cast<const frag_t*>(brow + kg * KGS); };
         auto mma_step = [&](const frag_t (&a)[MT], const frag_t (&b)[1]) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a[m], b[0]);
         };
-        constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MT <= 2 ? 4 : (MT <= 4 ? 3 : 2));
-        mfma_ring<DEPTH, MT, 1, frag_t>(P.NKG, load_step, mma_step);
+        ring_run(ring, P.NKG, load_a, load_b, mma_step);
       }
       __syncthreads();   // xa / xs free again (next chunk or the epilogue's staging buffer)
     }
