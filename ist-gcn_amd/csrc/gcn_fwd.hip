@@ -64,6 +64,10 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
   const int wave = tid >> 6;
   const int V = P.V, K = P.K;
   const int KV = K * V;
+  constexpr bool MSPLIT = (MT % 2) == 0;
+  constexpr int MH = MSPLIT ? MT / 2 : MT;           // channel tiles per wave
+  constexpr int NTW = MSPLIT ? 2 : 1;                // 32-row tiles per wave
+  const int ph = MSPLIT ? (wave & 1) : wave, mh = MSPLIT ? (wave >> 1) : 0;
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
 
@@ -141,29 +145,34 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
     const int nf = min(P.F, P.Tlog - t0);
     const int rows = nf * V;
 
+    // Wave decomposition of the contraction: with an even number of channel tiles the four waves split 2 (64-row
+    // halves) x 2 (channel-tile halves), so a weight fragment feeds TWO MFMAs -- one fragment per MFMA asks the vector
+    // L1 for 128 B/clk per CU, twice what it delivers.  (Odd MT: one 32-row slab and all tiles per wave, as before.)
     // accumulators start at the bias term bterm[w][c] of their (row, channel): loads issued here, behind the staging
-    f32x16 acc[MT];
-    {
-      const int p = wave * 32 + (lane & 31);
+    f32x16 acc[MH][NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int p = ph * 32 * NTW + t * 32 + (lane & 31);
       const bool rowb = P.bterm && p < rows;
       const float* brow = P.bterm + (rowb ? (int)row_w[p] : 0) * P.Cout + cbase_blk + 4 * (lane >> 5);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MH; ++m) {
+        const int mg = mh * MH + m;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          const int cg = cbase_blk + m * 32 + 8 * g + 4 * (lane >> 5);
+          const int cg = cbase_blk + mg * 32 + 8 * g + 4 * (lane >> 5);
           if (rowb) {
             if (VEC_OUT && cg + 3 < P.Cout) {
-              const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + m * 32 + 8 * g);
+              const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + mg * 32 + 8 * g);
               bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
             } else {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) bv[j] = brow[m * 32 + 8 * g + j];
+              for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) bv[j] = brow[mg * 32 + 8 * g + j];
             }
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[m][4 * g + j] = bv[j];
+          for (int j = 0; j < 4; ++j) acc[m][t][4 * g + j] = bv[j];
         }
       }
     }
@@ -196,12 +205,12 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
       // The contraction loop is 12 k-groups long; an L2 round trip in front of its first MFMA was most of its time.
       constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MT <= 2 ? 4 : (MT <= 4 ? 3 : 2));
       const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-      auto load_a = [&](int kg, frag_t (&a)[MT]) {
+      auto load_a = [&](int kg, frag_t (&a)[MH]) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)m * P.NKG + kg) * 64 * EPL);
+        for (int m = 0; m < MH; ++m)
+          a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)(mh * MH + m) * P.NKG + kg) * 64 * EPL);
       };
-      MfmaRing<DEPTH, MT, 1, frag_t> ring;
+      MfmaRing<DEPTH, MH, NTW, frag_t> ring;
       ring_prime_a(ring, P.NKG, load_a);
       bool agg_done = false;
       if constexpr (sizeof(T) == 2) if (V <= 32) {
@@ -300,11 +309,16 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
       __syncthreads();
       // ---- channel contraction on the matrix cores (ring of weight fragments from L2 and xa fragments from LDS) ----
       {
-        const T* brow = xa + (wave * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
-        auto load_b = [&](int kg, frag_t (&b)[1]) { b[0] = *reinterpret_cast<const frag_t*>(brow + kg * KGS); };
-        auto mma_step = [&](const frag_t (&a)[MT], const frag_t (&b)[1]) {
+        const T* brow = xa + (ph * 32 * NTW + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
+        auto load_b = [&](int kg, frag_t (&b)[NTW]) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) mma_kgroup(acc[m], a[m], b[0]);
+          for (int t = 0; t < NTW; ++t) b[t] = *reinterpret_cast<const frag_t*>(brow + t * 32 * P.xa_stride + kg * KGS);
+        };
+        auto mma_step = [&](const frag_t (&a)[MH], const frag_t (&b)[NTW]) {
+#pragma unroll
+          for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
         };
         ring_run(ring, P.NKG, load_a, load_b, mma_step);
       }
@@ -318,16 +332,20 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       {
-        const int p = wave * 32 + (lane & 31);
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
-          const int m = 2 * ps + ml;
-          if (m < MT) {
+        for (int t = 0; t < NTW; ++t) {
+          const int p = ph * 32 * NTW + t * 32 + (lane & 31);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-              float v4[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-              store4(outs + p * P.out_stride + cl, v4);
+          for (int ml = 0; ml < 2; ++ml) {
+            const int mg = 2 * ps + ml;                    // channel tile of this pass; held by the waves with mh == mg / MH
+            const int m = mg % MH;
+            if (mg < MT && mg / MH == mh) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
+                float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
+                store4(outs + p * P.out_stride + cl, v4);
+              }
             }
           }
         }
