@@ -128,6 +128,18 @@ int istgcn_fold_bwd(const float* B, int J, const float* imp0, const float* imp1,
                     const float* dA, const float* S, float* dimp0, float* dimp1, float* dimp2, float* dbias, int K, int V,
                     int C, void* stream);
 
+/* The three-branch Inception-TCN folded into ONE 15-tap convolution (linear in the weights), and its gradient:
+ *   taps[j][o][i] = scale*(m0*W1[o][i][j-6] + m1*W2[o][i][j-3] + m2*W3[o][i][j]),  bias = scale*(m0*b1 + m1*b2 + m2*b3)
+ *   (net/st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215 with scale = 1; net/st_gcn_mstcn.py:189-209,242-245 with 1/3).
+ * W_s are the nn.Conv2d(C, C, (k,1)) weights [Co][Ci][k] for k = 3, 9, 15 (contiguous), mst [3] the branch importances.
+ * bwd: dW_s, db_s written; dmst [3] ACCUMULATED (caller zeroes). */
+int istgcn_tcn_fold_fwd(const float* w1, const float* w2, const float* w3, const float* b1, const float* b2, const float* b3,
+                        const float* mst, float scale, float* taps, float* bias, int Co, int Ci, void* stream);
+int istgcn_tcn_fold_bwd(const float* dtaps, const float* dbias, const float* w1, const float* w2, const float* w3,
+                        const float* b1, const float* b2, const float* b3, const float* mst, float scale, float* dw1,
+                        float* dw2, float* dw3, float* db1, float* db2, float* db3, float* dmst, int Co, int Ci,
+                        void* stream);
+
 /* BatchNorm2d bookkeeping (train-mode statistics are batch sums the MFMA kernels emit in their epilogues).
  * istgcn_bn_finalize: stats [rep][2][C] fp64 (sum, sum of squares) over `count` elements per channel ->
  *   coef [4][C] fp32 = scale (gamma*rstd), shift (beta - mean*scale), mean, rstd; training != 0 also updates

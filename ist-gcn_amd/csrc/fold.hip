@@ -117,6 +117,99 @@ __global__ __launch_bounds__(NT) void fold_bwd_kernel(const FoldParams P) {
   }
 }
 
+// ---- the three-branch Inception-TCN as ONE 15-tap convolution (linear in the weights):
+//      taps[j][o][i] = scale * (m0*W1[o][i][j-6] + m1*W2[o][i][j-3] + m2*W3[o][i][j])   (branches of 3 / 9 / 15 taps,
+//      paddings 1 / 4 / 7 -> tap offsets 6 / 3 / 0),  bias = scale * (m0*b1 + m1*b2 + m2*b3)
+//      net/st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215 (scale = 1), net/st_gcn_mstcn.py:189-209,242-245 (scale = 1/3)
+struct TcnFold {
+  const float *w1, *w2, *w3, *b1, *b2, *b3, *mst;     // W_s [Co][Ci][k_s] (k = 3, 9, 15), b_s [Co], mst [3]
+  float* taps;          // fwd out [15][Co][Ci]
+  float* bias;          // fwd out [Co]
+  const float* dtaps;   // bwd in [15][Co][Ci]
+  const float* dbias;   // bwd in [Co]
+  float *dw1, *dw2, *dw3, *db1, *db2, *db3, *dmst;    // bwd out (dmst [3] accumulated: caller zeroes)
+  float scale;
+  int Co, Ci;
+};
+
+// Both kernels: a block owns 256 consecutive (o,i) pairs.  The [o][i][k] parameter tensors are contiguous runs of 256*k
+// floats per block and move through LDS (coalesced global accesses; per-thread LDS strides 15 / 9 / 3 floats are odd:
+// conflict-free); the [j][o][i] taps are read / written directly (consecutive threads = consecutive addresses).
+__device__ static inline void tcn_stage_in(const float* __restrict__ g, float* l, int first, int count, int k) {
+  for (int i = threadIdx.x; i < count * k; i += 256) l[i] = g[(size_t)first * k + i];
+}
+__device__ static inline void tcn_stage_out(float* __restrict__ g, const float* l, int first, int count, int k) {
+  for (int i = threadIdx.x; i < count * k; i += 256) g[(size_t)first * k + i] = l[i];
+}
+
+__global__ __launch_bounds__(256) void tcn_fold_fwd_kernel(const TcnFold P) {
+  __shared__ float s3[256 * 15], s2[256 * 9], s1[256 * 3];
+  const int n = P.Co * P.Ci;
+  const int first = blockIdx.x * 256, count = min(256, n - first);
+  const int oi = first + threadIdx.x, l = threadIdx.x;
+  const float m0 = P.mst[0] * P.scale, m1 = P.mst[1] * P.scale, m2 = P.mst[2] * P.scale;
+  tcn_stage_in(P.w3, s3, first, count, 15);
+  tcn_stage_in(P.w2, s2, first, count, 9);
+  tcn_stage_in(P.w1, s1, first, count, 3);
+  __syncthreads();
+  if (oi < n) {
+    float t[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) t[j] = m2 * s3[l * 15 + j];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) t[j + 3] += m1 * s2[l * 9 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j + 6] += m0 * s1[l * 3 + j];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) P.taps[(size_t)j * n + oi] = t[j];
+  }
+  if (oi < P.Co) P.bias[oi] = m0 * P.b1[oi] + m1 * P.b2[oi] + m2 * P.b3[oi];
+}
+
+__global__ __launch_bounds__(256) void tcn_fold_bwd_kernel(const TcnFold P) {
+  __shared__ float s3[256 * 15], s2[256 * 9], s1[256 * 3];
+  __shared__ float red[3][4];
+  const int n = P.Co * P.Ci;
+  const int first = blockIdx.x * 256, count = min(256, n - first);
+  const int oi = first + threadIdx.x, l = threadIdx.x;
+  const float m0 = P.mst[0] * P.scale, m1 = P.mst[1] * P.scale, m2 = P.mst[2] * P.scale;
+  tcn_stage_in(P.w3, s3, first, count, 15);
+  tcn_stage_in(P.w2, s2, first, count, 9);
+  tcn_stage_in(P.w1, s1, first, count, 3);
+  __syncthreads();
+  float s0 = 0.f, sm1 = 0.f, sm2 = 0.f;
+  float d[15];
+#pragma unroll
+  for (int j = 0; j < 15; ++j) d[j] = oi < n ? P.dtaps[(size_t)j * n + oi] : 0.f;
+  if (oi < n) {
+    // importance gradients from the staged weights, then the slots are overwritten with the weight gradients
+#pragma unroll
+    for (int j = 0; j < 15; ++j) { sm2 += d[j] * s3[l * 15 + j]; s3[l * 15 + j] = m2 * d[j]; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { sm1 += d[j + 3] * s2[l * 9 + j]; s2[l * 9 + j] = m1 * d[j + 3]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { s0 += d[j + 6] * s1[l * 3 + j]; s1[l * 3 + j] = m0 * d[j + 6]; }
+  }
+  if (oi < P.Co) {
+    const float db = P.dbias[oi];
+    P.db1[oi] = m0 * db; P.db2[oi] = m1 * db; P.db3[oi] = m2 * db;
+    s0 += db * P.b1[oi]; sm1 += db * P.b2[oi]; sm2 += db * P.b3[oi];
+  }
+  __syncthreads();
+  tcn_stage_out(P.dw3, s3, first, count, 15);
+  tcn_stage_out(P.dw2, s2, first, count, 9);
+  tcn_stage_out(P.dw1, s1, first, count, 3);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s0 += __shfl_xor(s0, m); sm1 += __shfl_xor(sm1, m); sm2 += __shfl_xor(sm2, m); }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = sm1; red[2][wave] = sm2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float v = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    atomicAdd(P.dmst + threadIdx.x, v * P.scale);
+  }
+}
+
 }  // namespace
 
 extern "C" int istgcn_fold_fwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2,
@@ -142,6 +235,34 @@ extern "C" int istgcn_fold_bwd(const float* B, int J, const float* imp0, const f
   P.dimp[0] = dimp0; P.dimp[1] = dimp1; P.dimp[2] = dimp2; P.dbias = dbias;
   P.J = J; P.K = K; P.V = V; P.C = C;
   ISTGCN_LAUNCH(fold_bwd_kernel, dim3(1), dim3(NT), (size_t)K * V * V * sizeof(float), (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_tcn_fold_fwd(const float* w1, const float* w2, const float* w3, const float* b1, const float* b2,
+                                   const float* b3, const float* mst, float scale, float* taps, float* bias, int Co,
+                                   int Ci, void* stream) {
+  if (!w1 || !w2 || !w3 || !b1 || !b2 || !b3 || !mst || !taps || !bias || Co < 1 || Ci < 1) return ISTGCN_EINVAL;
+  TcnFold P{};
+  P.w1 = w1; P.w2 = w2; P.w3 = w3; P.b1 = b1; P.b2 = b2; P.b3 = b3; P.mst = mst; P.taps = taps; P.bias = bias;
+  P.scale = scale; P.Co = Co; P.Ci = Ci;
+  ISTGCN_LAUNCH(tcn_fold_fwd_kernel, dim3(ceil_div(Co * Ci, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_tcn_fold_bwd(const float* dtaps, const float* dbias, const float* w1, const float* w2,
+                                   const float* w3, const float* b1, const float* b2, const float* b3, const float* mst,
+                                   float scale, float* dw1, float* dw2, float* dw3, float* db1, float* db2, float* db3,
+                                   float* dmst, int Co, int Ci, void* stream) {
+  if (!dtaps || !dbias || !w1 || !w2 || !w3 || !b1 || !b2 || !b3 || !mst || !dw1 || !dw2 || !dw3 || !db1 || !db2 || !db3 ||
+      !dmst || Co < 1 || Ci < 1)
+    return ISTGCN_EINVAL;
+  TcnFold P{};
+  P.w1 = w1; P.w2 = w2; P.w3 = w3; P.b1 = b1; P.b2 = b2; P.b3 = b3; P.mst = mst; P.dtaps = dtaps; P.dbias = dbias;
+  P.dw1 = dw1; P.dw2 = dw2; P.dw3 = dw3; P.db1 = db1; P.db2 = db2; P.db3 = db3; P.dmst = dmst;
+  P.scale = scale; P.Co = Co; P.Ci = Ci;
+  ISTGCN_LAUNCH(tcn_fold_bwd_kernel, dim3(ceil_div(Co * Ci, 256)), dim3(256), 0, (hipStream_t)stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

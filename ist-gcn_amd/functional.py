@@ -73,6 +73,37 @@ def fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
     return taps.contiguous(), bias.contiguous()
 
 
+class TcnTapsFn(torch.autograd.Function):
+    """fold_tcn_taps as one launch each way (forward: taps + bias; backward: all six parameter gradients in their own
+    layouts + the branch-importance gradient) for GPU parameters."""
+
+    @staticmethod
+    def forward(ctx, w1, w2, w3, b1, b2, b3, mst, scale):
+        args = [t.contiguous() for t in (w1, w2, w3, b1, b2, b3, mst)]
+        ctx.save_for_backward(*args)
+        ctx.scale = float(scale)
+        return ops.tcn_fold_fwd(*args, ctx.scale)
+
+    @staticmethod
+    def backward(ctx, dtaps, dbias):
+        w1, w2, w3, b1, b2, b3, mst = ctx.saved_tensors
+        if dtaps is None:
+            dtaps = torch.zeros((15,) + tuple(w3.shape[:2]), dtype=torch.float32, device=w3.device)
+        if dbias is None:
+            dbias = torch.zeros_like(b3)
+        g = ops.tcn_fold_bwd(dtaps.contiguous(), dbias.contiguous(), w1, w2, w3, b1, b2, b3, mst, ctx.scale)
+        return g + (None,)
+
+
+def fold_tcn_taps_any(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
+    """The fused fold when everything is an fp32 GPU tensor with biases, else the torch-op specification."""
+    ts = (w1, w2, w3, b1, b2, b3, mst)
+    if all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in ts) and \
+            w1.shape[2:] == (3, 1) and w2.shape[2:] == (9, 1) and w3.shape[2:] == (15, 1):
+        return TcnTapsFn.apply(w1, w2, w3, b1, b2, b3, mst, scale)
+    return fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale)
+
+
 def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None):
     """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase."""
     NM, Tz = dz.shape[0], dz.shape[1]

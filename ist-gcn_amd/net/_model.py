@@ -139,7 +139,7 @@ class STGCNBlock(nn.Module):
             bn1, bn2 = self.tcn_start[0], self.tcn_end[0]
             if mst is None:
                 raise TypeError('this st_gcn variant needs mstcn_importance')
-            Wt, bt = Fn.fold_tcn_taps(self.tcn_1.weight, self.tcn_2.weight, self.tcn_3.weight, self.tcn_1.bias,
+            Wt, bt = Fn.fold_tcn_taps_any(self.tcn_1.weight, self.tcn_2.weight, self.tcn_3.weight, self.tcn_1.bias,
                                       self.tcn_2.bias, self.tcn_3.bias, mst,
                                       scale=(1.0 / 3.0) if self.tcn_kind == 'multi3' else 1.0)
             ks = 15

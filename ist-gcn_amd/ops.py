@@ -482,3 +482,25 @@ def fold_bwd(B, imps, bias, dA, S, C):
     _call('istgcn_fold_bwd', _ptr(B), J, ip[0], ip[1], ip[2], _ptr(bias), _ptr(dA), _ptr(S), dp[0], dp[1], dp[2],
           _ptr(dbias if S is not None else None), K, V, int(C), _stream(B))
     return dimps, dbias
+
+
+def tcn_fold_fwd(w1, w2, w3, b1, b2, b3, mst, scale):
+    """-> (taps [15,Co,Ci], bias [Co]): the 3/9/15-tap branches pre-summed into one 15-tap convolution."""
+    Co, Ci = w3.shape[0], w3.shape[1]
+    taps = torch.empty((15, Co, Ci), dtype=torch.float32, device=w3.device)
+    bias = torch.empty((Co,), dtype=torch.float32, device=w3.device)
+    _check_dev(w1, w2, w3, b1, b2, b3, mst, taps, bias)
+    _call('istgcn_tcn_fold_fwd', _ptr(w1), _ptr(w2), _ptr(w3), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(mst),
+          ctypes.c_float(scale), _ptr(taps), _ptr(bias), Co, Ci, _stream(w3))
+    return taps, bias
+
+
+def tcn_fold_bwd(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, scale):
+    """-> (dw1, dw2, dw3, db1, db2, db3, dmst) in the parameters' own layouts."""
+    Co, Ci = w3.shape[0], w3.shape[1]
+    outs = [torch.empty_like(t) for t in (w1, w2, w3, b1, b2, b3)]
+    dmst = torch.zeros_like(mst)
+    _check_dev(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, dmst, *outs)
+    _call('istgcn_tcn_fold_bwd', _ptr(dtaps), _ptr(dbias), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(b1), _ptr(b2), _ptr(b3),
+          _ptr(mst), ctypes.c_float(scale), *[_ptr(t) for t in outs], _ptr(dmst), Co, Ci, _stream(w3))
+    return (*outs, dmst)
