@@ -255,46 +255,6 @@ __device__ static inline void atomic_add_f64(double* p, double v) { unsafeAtomic
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same staging split in two, for software pipelining across a compute phase: tile_load issues the global loads
-// of an [R] x [Q vectors] block into registers (rows >= rows_live and channels >= c_lim read as zero), tile_commit
-// writes them to LDS later.  Item it = tid + u*nthreads -> (row it / Q, vector it % Q); U*nthreads >= R*Q.
-// ---------------------------------------------------------------------------------------------------------
-template <typename T, int U, bool VEC>
-__device__ static inline void tile_load(typename Elem<T>::frag (&v)[U], const T* __restrict__ g, size_t gstride,
-                                        int c_lim, int R, int rows_live, int Q, int tid, int nthreads) {
-  using E = Elem<T>;
-  constexpr int EPL = E::EPL;
-  const int tot = R * Q;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int it = tid + u * nthreads;
-    const int r = it / Q, q = it - r * Q;
-    zero_frag<T>(v[u]);
-    if (it < tot && r < rows_live && q * EPL < c_lim) {
-      const T* src = g + (size_t)r * gstride + q * EPL;
-      if (VEC) v[u] = *reinterpret_cast<const typename E::frag*>(src);
-      else {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) if (q * EPL + e < c_lim) v[u][e] = src[e];
-      }
-    }
-  }
-}
-
-template <typename T, int U>
-__device__ static inline void tile_commit(const typename Elem<T>::frag (&v)[U], T* lds, int lstride, int R, int Q,
-                                          int tid, int nthreads) {
-  constexpr int EPL = Elem<T>::EPL;
-  const int tot = R * Q;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int it = tid + u * nthreads;
-    const int r = it / Q, q = it - r * Q;
-    if (it < tot) *reinterpret_cast<typename Elem<T>::frag*>(lds + r * lstride + q * EPL) = v[u];
-  }
-}
-
 // hipGetLastError() is per-thread and sticky across *any* HIP call of the host process (PyTorch's allocator polls
 // events and leaves hipErrorNotReady behind): clear it before our launch so the check below sees only our own.
 #define ISTGCN_LAUNCH(...)            \
