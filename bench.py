@@ -94,12 +94,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    ndev = torch.cuda.device_count()
+    if local >= ndev and os.environ.get('ISTGCN_DIST_BACKEND', 'nccl') != 'nccl':
+        local = local % ndev              # rehearsal: several ranks share the one visible GPU
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # RCCL ('nccl' on ROCm) over xGMI; ISTGCN_DIST_BACKEND=gloo only to rehearse the multi-rank code path on one GPU
+        backend = os.environ.get('ISTGCN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import importlib
     import istgcn_amd  # noqa: F401
