@@ -1,0 +1,120 @@
+"""-m gpu: the hot-path kernels at BASELINE config-2 size (64 clips x 2 persons -> NM = 128, T = 300, V = 25, 64
+channels), checked through size-independent properties instead of the CPU oracle (which would need minutes here):
+
+* sequences are independent: any slice of the batch computed alone equals the same slice of the full launch, bit for
+  bit (exercises the persistent tile walk, the XCD-affine order and the halo / window logic at full depth);
+* linearity in the activations (graph conv) and additivity of the weight gradients over batch shards (exercises the
+  workspace / atomic flush of the position-contraction kernels with every workgroup resident);
+* BatchNorm batch sums emitted by the epilogues equal the sums of the stored output.
+"""
+import pytest
+import torch
+
+from gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+NM, T, V, C, K = 128, 300, 25, 64, 3
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from istgcn_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope='module')
+def graph_A():
+    from istgcn_amd.net.utils.graph import Graph
+    g = Graph('ntu-rgb+d', 'spatial_3')
+    return torch.tensor(g.A + g.A2 + g.A3, dtype=torch.float32)
+
+
+def _randn(*shape, seed, dt, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev(), dt)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gcn_forward_slices_and_linearity(ops, graph_A, dt):
+    d = dev()
+    A = graph_A.to(d)
+    cap = int((A != 0).sum())
+    x = _randn(NM, T, V, C, seed=1, dt=dt)
+    W3 = _randn(K, C, C, seed=2, dt=torch.float32, scale=C ** -0.5)
+    wp = ops.pack_gcn_weight(W3.permute(1, 0, 2), dt)
+    st = ops.new_stats(C, d)
+    y = ops.gcn_forward(x, A, wp, C, stats=st, nnz_cap=cap)
+    torch.cuda.synchronize()
+    # batch slices alone == slices of the full launch (bit-exact)
+    for lo, hi in ((0, 1), (37, 41), (NM - 3, NM)):
+        ys = ops.gcn_forward(x[lo:hi].contiguous(), A, wp, C, nnz_cap=cap)
+        assert torch.equal(ys, y[lo:hi]), 'sequence independence broken for [%d:%d)' % (lo, hi)
+    # BN sums of the epilogue == sums of what was stored (fp64 over the stored values)
+    yf = y.double()
+    s = st.sum(0)
+    tol = 1e-6 if dt == torch.float32 else 1e-5
+    assert ((s[0] - yf.sum((0, 1, 2))).abs().max() / yf.abs().sum((0, 1, 2)).max()) < tol
+    assert ((s[1] - (yf * yf).sum((0, 1, 2))).abs().max() / (yf * yf).sum((0, 1, 2)).max()) < tol
+    if dt == torch.float32:
+        # linearity in x (no bias term passed): f(2*x1 - 0.5*x2) == 2*f(x1) - 0.5*f(x2)
+        x2 = _randn(NM, T, V, C, seed=3, dt=dt)
+        y2 = ops.gcn_forward(x2, A, wp, C, nnz_cap=cap)
+        yl = ops.gcn_forward(2.0 * x - 0.5 * x2, A, wp, C, nnz_cap=cap)
+        ref = 2.0 * y - 0.5 * y2
+        assert ((yl - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_tconv_slices_full_size(ops, dt):
+    d = dev()
+    k = 9
+    taps, in_mul = ops.conv_taps_fwd(k, 1)
+    x = _randn(NM, T, V, C, seed=11, dt=dt)
+    Wc = _randn(C, C, k, 1, seed=12, dt=torch.float32, scale=(C * k) ** -0.5)
+    wp = ops.pack_tconv_weight(Wc.view(C, C, k).permute(2, 0, 1), V, taps, in_mul, dt)
+    bias = _randn(C, seed=13, dt=torch.float32, scale=0.1)
+    pre = torch.stack([0.5 + torch.rand(C, generator=torch.Generator().manual_seed(14)),
+                       0.3 * torch.randn(C, generator=torch.Generator().manual_seed(15))]).to(d)
+    st = ops.new_stats(C, d)
+    z = ops.tconv(x, wp, C, taps, bias=bias, pre=pre, pre_relu=True, stats=st, Tout=T, Mlog=T, in_mul=in_mul)
+    torch.cuda.synchronize()
+    for lo, hi in ((0, 2), (63, 65), (NM - 1, NM)):
+        zs = ops.tconv(x[lo:hi].contiguous(), wp, C, taps, bias=bias, pre=pre, pre_relu=True, Tout=T, Mlog=T,
+                       in_mul=in_mul)
+        assert torch.equal(zs, z[lo:hi]), 'sequence independence broken for [%d:%d)' % (lo, hi)
+    zf = z.double()
+    s = st.sum(0)
+    tol = 1e-6 if dt == torch.float32 else 1e-5
+    assert ((s[0] - zf.sum((0, 1, 2))).abs().max() / zf.abs().sum((0, 1, 2)).max()) < tol
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_weight_gradients_are_additive_over_batch_shards(ops, graph_A, dt):
+    d = dev()
+    A = graph_A.to(d)
+    cap = int((A != 0).sum())
+    k = 9
+    taps, in_mul = ops.conv_taps_fwd(k, 1)
+    dz = _randn(NM, T, V, C, seed=21, dt=dt, scale=0.1)
+    g = _randn(NM, T, V, C, seed=22, dt=dt)
+    pre = torch.stack([torch.ones(C), torch.zeros(C)]).to(d)
+    tol = 2e-5 if dt == torch.float32 else 2e-5          # both sides accumulate in fp32; only the order differs
+    h = NM // 2
+    dW, db = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    dWa, dba = ops.tconv_wgrad(dz[:h].contiguous(), g[:h].contiguous(), taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    dWb, dbb = ops.tconv_wgrad(dz[h:].contiguous(), g[h:].contiguous(), taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    assert ((dW - (dWa + dWb)).abs().max() / dW.abs().max()) < tol
+    assert ((db - (dba + dbb)).abs().max() / db.abs().max()) < tol
+    gW, S = ops.gcn_wgrad(dz, g, A, nnz_cap=cap)
+    gWa, Sa = ops.gcn_wgrad(dz[:h].contiguous(), g[:h].contiguous(), A, nnz_cap=cap)
+    gWb, Sb = ops.gcn_wgrad(dz[h:].contiguous(), g[h:].contiguous(), A, nnz_cap=cap)
+    assert ((gW - (gWa + gWb)).abs().max() / gW.abs().max()) < tol
+    assert ((S - (Sa + Sb)).abs().max() / S.abs().max()) < tol
+    # and the data gradient of the graph conv: slices independent, adjacency gradient additive
+    W3 = _randn(K, C, C, seed=23, dt=torch.float32, scale=C ** -0.5)
+    dx, dA = ops.gcn_bwd_data(dz, A, W3, x=g, want_dA=True, nnz_cap=cap)
+    dxa, dAa = ops.gcn_bwd_data(dz[:h].contiguous(), A, W3, x=g[:h].contiguous(), want_dA=True, nnz_cap=cap)
+    dxb, dAb = ops.gcn_bwd_data(dz[h:].contiguous(), A, W3, x=g[h:].contiguous(), want_dA=True, nnz_cap=cap)
+    assert torch.equal(dx[:h], dxa) and torch.equal(dx[h:], dxb)
+    assert ((dA - (dAa + dAb)).abs().max() / dA.abs().max()) < tol
