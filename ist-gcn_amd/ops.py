@@ -373,14 +373,25 @@ _STATS_SCRATCH = {}
 
 
 def stats_scratch(slot, C, device):
-    """A persistent, always-zero-between-uses [STATS_REP][2][C] fp64 buffer: the kernel that produces batch sums adds
-    into it, `bn_finalize` / `bn_bwd_coef` (clear=True) read it and zero it again.  One per (device, stream, slot, C);
-    distinct `slot`s for sums that are alive at the same time.  Saves a memset launch per BatchNorm per pass."""
+    """A persistent, zero-between-uses [STATS_REP][2][C] fp64 buffer: the kernel that produces batch sums adds into it,
+    `bn_finalize` / `bn_bwd_coef` (clear=True) read it and zero it again.  One per (device, stream, slot, C); distinct
+    `slot`s for sums that are alive at the same time.  Saves a memset launch per BatchNorm per pass.  If a previous
+    user never consumed its sums (an exception between producer and consumer), the buffer is re-zeroed here."""
     key = (device, torch.cuda.current_stream(device).cuda_stream, slot, C)
-    st = _STATS_SCRATCH.get(key)
-    if st is None:
-        st = _STATS_SCRATCH[key] = new_stats(C, device)
-    return st
+    ent = _STATS_SCRATCH.get(key)
+    if ent is None:
+        ent = _STATS_SCRATCH[key] = [new_stats(C, device), False]
+    elif ent[1]:
+        ent[0].zero_()
+    ent[1] = True                      # handed to a producer; bn_finalize / bn_bwd_coef(clear=True) mark it clean
+    return ent[0]
+
+
+def _scratch_consumed(stats):
+    for ent in _STATS_SCRATCH.values():
+        if ent[0] is stats:
+            ent[1] = False
+            return
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear=False):
@@ -392,6 +403,8 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
           ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum),
           ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma))
+    if clear and stats is not None:
+        _scratch_consumed(stats)
     return coef
 
 
@@ -405,6 +418,8 @@ def bn_bwd_coef(stats, count, gamma, coef, training, clear=False):
     _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], int(bool(clear)), ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(coef),
           int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma))
+    if clear:
+        _scratch_consumed(stats)
     return abc, dg, db
 
 

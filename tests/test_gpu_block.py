@@ -290,3 +290,57 @@ def test_native_packers_match_specification(ops, dt):
             ref = ops.pack_tconv_weight_ref(wt, V, offs, 1, dt)
             got = ops.pack_tconv_weight(wf.transpose(1, 2), V, offs, 1, dt, tap_sel=sel)
             assert torch.equal(got.cpu().view(ref.shape), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['plain', 'incep', '3a'])
+def test_fused_importance_fold_matches_torch_spec(kind):
+    """FoldFn (one launch each way) == fold_adjacency + fold_bias_term and their autograd."""
+    from istgcn_amd import functional as Fn
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    K, V, C = 3, 25, 64
+    A = (torch.rand(K, V, V, generator=g) < 0.15).float() * torch.rand(K, V, V, generator=g)
+    A2, A3 = A.roll(1, 1) * 0.5, A.roll(2, 2) * 0.25
+    mats = {'plain': [A], 'incep': [A, A2, A3], '3a': [A, A * A, A * A * A]}[kind]
+    B = torch.stack(mats).to(d).contiguous()
+    imps = [torch.rand(K, V, V, generator=g).to(d).requires_grad_() for _ in mats]
+    bias = torch.randn(K * C, generator=g).to(d).requires_grad_()
+    dA = torch.randn(K, V, V, generator=g).to(d)
+    dS = torch.randn(V, C, generator=g).to(d)
+    A_eff, bterm = Fn.FoldFn.apply(B, bias, C, *imps)
+    (A_eff * dA).sum().add((bterm * dS).sum()).backward()
+    got = [A_eff.detach(), bterm.detach(), bias.grad.clone()] + [i.grad.clone() for i in imps]
+    for t in imps + [bias]:
+        t.grad = None
+    ref_A = Fn.fold_adjacency(kind, A.to(d), imps, A2.to(d), A3.to(d))
+    ref_b = Fn.fold_bias_term(bias, ref_A, C)
+    (ref_A * dA).sum().add((ref_b * dS).sum()).backward()
+    ref = [ref_A.detach(), ref_b.detach(), bias.grad] + [i.grad for i in imps]
+    for a, b in zip(got, ref):
+        assert rel_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('co,ci,scale', [(64, 64, 1.0), (256, 256, 1.0 / 3.0), (11, 11, 1.0), (8, 16, 0.5)])
+def test_fused_tcn_tap_fold_matches_torch_spec(co, ci, scale):
+    """TcnTapsFn (one launch each way) == fold_tcn_taps and its autograd, all seven parameter gradients."""
+    from istgcn_amd import functional as Fn
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(4)
+    ws = [torch.randn(co, ci, k, 1, generator=g).to(d).requires_grad_() for k in (3, 9, 15)]
+    bs = [torch.randn(co, generator=g).to(d).requires_grad_() for _ in range(3)]
+    mst = (0.5 + torch.rand(3, generator=g)).to(d).requires_grad_()
+    dT = torch.randn(15, co, ci, generator=g).to(d)
+    dB = torch.randn(co, generator=g).to(d)
+    params = ws + bs + [mst]
+    taps, bias = Fn.TcnTapsFn.apply(*ws, *bs, mst, scale)
+    (taps * dT).sum().add((bias * dB).sum()).backward()
+    got = [taps.detach(), bias.detach()] + [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    rt, rb = Fn.fold_tcn_taps(*ws, *bs, mst, scale)
+    (rt * dT).sum().add((rb * dB).sum()).backward()
+    ref = [rt.detach(), rb.detach()] + [p.grad for p in params]
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and rel_err(a.cpu(), b.cpu()) < 5e-6
