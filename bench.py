@@ -6,8 +6,11 @@
 N=1 workload = BASELINE.json configs[1]: net/st_gcn_msgcn.py (Inception-GCN), NTU-RGB+D xsub shape
 (C=3, T=300, V=25, M=2, 60 classes), batch 64 clips per GPU, training step of processor/recognition.py:249-296
 (train mode, dropout 0.5, CrossEntropy, SGD-nesterov) on synthetic clips and random-init weights.
-N>1 (launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one process per GPU,
-the batch axis sharded (64 clips per GPU, weak scaling), one flat-bucket gradient all-reduce per step over RCCL.
+N>1: one process per GPU, the batch axis sharded (64 clips per GPU, weak scaling), one flat-bucket gradient all-reduce
+per step over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, or
+run directly (`python bench.py --gpus N`): with no WORLD_SIZE in the environment this process starts that launcher
+itself as a child (before anything touches the GPU), relays rank 0's JSON line and exits with the child's code.
+ISTGCN_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks sharing the visible GPU(s).
 
 One JSON line on rank 0, with
   roofline      the dominant kernel family of the step: algorithmic FLOPs (or bytes) of its launches / their summed
@@ -18,6 +21,8 @@ One JSON line on rank 0, with
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -72,25 +77,42 @@ def cpu_baseline(model_tag, T, seconds_budget=25.0):
                       'dropout 0.5, SGD step included' % (n, B, T, V)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` run directly: start N ranks through torch.distributed.run as a CHILD process (this
+    process has not touched the GPU), pass the command line through, relay the child's output, return its exit code."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('ISTGCN_BENCH_DTYPE', 'bf16'), choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default=os.environ.get('ISTGCN_BENCH_DTYPE', 'bf16'), choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--model', default='st_gcn_msgcn', choices=sorted(MODELS))
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
+    ap.add_argument('--loss-scale', type=float, default=None,
+                    help='static loss scale of the backward pass (default: 65536 for f16 storage, 1 otherwise)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (args.gpus, args.gpus))
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X (no CPU fallback for the product path)')
@@ -114,14 +136,18 @@ def main():
     from istgcn_amd import ops, harness, dp
     gargs, nc, V = MODELS[args.model]
     T = args.frames or (600 if args.model.endswith('deep') else 300)
-    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
+    half = dt != torch.float32
+    loss_scale = args.loss_scale if args.loss_scale else (65536.0 if dt == torch.float16 else 1.0)
     torch.manual_seed(0)
     model = importlib.import_module('istgcn_amd.net.' + args.model).Model(3, nc, gargs, True, dropout=0.5,
                                                                         compute_dtype=dt)
     model.apply(harness.weights_init)
     model.to(dev).train()
     sync = dp.FlatGradSync(model) if world > 1 else None
-    opt = harness.make_optimizer(model)
+    opt = harness.make_optimizer(model, loss_scale=loss_scale)
+    if sync is not None:
+        opt.attach_sync(sync)          # the all-reduce runs in place on the optimizer's flat gradient buffer
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
     x = torch.randn(B, 3, T, V, 2, generator=g).to(dev)
@@ -168,9 +194,9 @@ def main():
         rec[3] += nbytes
     dom = max(fam, key=lambda k: fam[k][1])
     n, secs, flops, nbytes = fam[dom]
-    ridge = (PEAK['mfma_bf16'] if dt == torch.bfloat16 else PEAK['mfma_f32']) * 1e12 / (PEAK['hbm'] * 1e9)
+    ridge = (PEAK['mfma_bf16'] if half else PEAK['mfma_f32']) * 1e12 / (PEAK['hbm'] * 1e9)
     if flops / max(nbytes, 1.0) >= ridge:
-        peak = PEAK['mfma_bf16'] if dt == torch.bfloat16 else PEAK['mfma_f32']
+        peak = PEAK['mfma_bf16'] if half else PEAK['mfma_f32']
         roof = {'bound': 'mfma', 'achieved': round(flops / secs / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s'}
     else:
         roof = {'bound': 'hbm', 'achieved': round(nbytes / secs / 1e9, 1), 'peak': PEAK['hbm'], 'unit': 'GB/s'}
@@ -206,11 +232,12 @@ def main():
             'value': round(B * world * args.steps / elapsed, 2), 'unit': 'clips/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if dt == torch.bfloat16 else 'f32', 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'net/%s.py NTU xsub shape (N,3,%d,%d,2), %d clips/GPU, train step (fwd+bwd+SGD-nesterov), '
                                    'dropout 0.5, random-init weights' % (args.model, T, V, B),
                        'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
-                       'storage': 'bf16 activations, fp32 accumulate/params, fp64 BN sums' if dt == torch.bfloat16 else 'fp32'},
+                       'storage': ('%s activations, fp32 accumulate/params, fp64 BN sums%s' % (
+                           args.dtype, ', static loss scale %g' % loss_scale if loss_scale != 1.0 else '')) if half else 'fp32'},
             'roofline': roof, 'final_loss': round(loss_val, 4),
         }
         if world == 1 and not args.no_cpu_baseline:

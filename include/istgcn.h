@@ -10,7 +10,9 @@
  *    freed or synchronised here; `stream` is a hipStream_t passed as void*.
  *  - activations are "NTVC": x[n][t][v][c], c innermost (== torch channels_last of the
  *    reference's (N*M, C, T, V) tensors); one n is one (clip, person) sequence.
- *  - dtype: 0 = float32, 1 = bfloat16 storage; accumulation is always fp32, BatchNorm sums fp64.
+ *  - dtype: 0 = float32, 1 = bfloat16, 2 = float16 storage of activations and activation gradients; accumulation is
+ *    always fp32, parameters / parameter gradients fp32, BatchNorm sums fp64.  (float16 = BASELINE config 5,
+ *    net/st_gcn_mstcn_1x1_deep.py; its 5-bit exponent needs a loss scale for the backward pass, see istgcn_sgd_step.)
  *  - return value: 0 ok, 1 invalid argument (nothing launched), 2 launch failure.
  *  - reentrant, no global mutable state: callable from any host thread (nn.DataParallel replicas).
  */
@@ -42,7 +44,8 @@ int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nc
  *   stats  NULL or [stats_rep][2][Cout] fp64, += per-channel sum(y), sum(y*y) (train-mode BatchNorm2d that
  *          follows: st_gcnold.py:165); caller zeroes it; replicas are summed by istgcn_bn_finalize
  *   status NULL or one int set to 1 if A has more non-zeros than nnz_cap (result then invalid)
- *   nnz_cap capacity of the in-LDS sparse column lists, >= nnz(A), <= K*V*V */
+ *   nnz_cap capacity of the in-LDS sparse column lists, >= nnz(A), <= K*V*V.  With fewer slots than non-zeros the
+ *          lists are TRUNCATED (wrong y, no fault): pass K*V*V unless the pattern is known, or check `status`. */
 int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* bterm, const void* addend,
                    void* y, double* stats, int stats_rep, int* status, int NM, int Tin, int Tout, int Tlog,
                    int V, int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int nnz_cap,
@@ -51,8 +54,11 @@ int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* b
 /* Backward of the graph-convolution unit (autograd of net/utils/tgcn.py:79-86 and the folded variants), two launches.
  *
  * istgcn_gcn_bwd_data: dx[n,t,v,i] = sum_k sum_w A[k][v][w] * dxa_k[n,t,w,i] (+ addend),  dxa_k = sum_c W[k][c][i] dy[..,c]
- *                      dA[k][v][w] += sum_{n,t,i} x[n,t,v,i] * dxa_k[n,t,w,i]   only where A[k][v][w] != 0 (the only
- *                      entries an importance gradient A (.) dA can see); dA may be NULL (then x may be NULL too).
+ *                      dA[k][v][w] += sum_{n,t,i} x[n,t,v,i] * dxa_k[n,t,w,i]   only where pattern[k][v][w] != 0
+ *                      (pattern [K][V][V] fp32: the constant adjacency B of A = B (.) importance -- the only entries an
+ *                      importance gradient B (.) dA can see, and unlike A itself it does not lose an entry when an
+ *                      importance value is exactly 0; NULL: the non-zeros of A; all-ones: a dense learnable A as autograd
+ *                      of tgcn.py:86 gives).  nnz(pattern) <= nnz_cap.  dA may be NULL (then x may be NULL too).
  *   dy [NM][T][V][Cout], x / addend / dx [NM][T][V][Cin] (addend NULL or the identity-residual gradient, may alias dx),
  *   Wb: fragments of W for the dxa product, element [ich][cch][kg][mt][h][r][e] =
  *       W[k][cch*CCc + kg*2*EPL + h*EPL + e][ich*CCi + il]  with  k*CCi + il = 32*mt + r  (zero padded);
@@ -62,9 +68,9 @@ int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* b
  * A [K][V][V] fp32, K <= 4.  dW / dA / S are fp32 and ACCUMULATED (the caller zeroes them). */
 int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc, int* KKp,
                             int* EPL);
-int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const void* Wb, const void* addend, void* dx,
-                        float* dA, int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap, int dtype,
-                        int grid_cap, void* stream);
+int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
+                        const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout, int K,
+                        int nnz_cap, int dtype, int grid_cap, void* stream);
 int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V, int Cin,
                      int Cout, int K, int nnz_cap, int dtype, int grid_cap, float* ws, long long ws_floats,
                      void* stream);
@@ -171,6 +177,15 @@ int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const
                          long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
                    unsigned long long seed, int dtype, void* stream);
+
+/* SGD with momentum / Nesterov / weight decay over ONE flat fp32 range = torch.optim.SGD as configured at
+ * processor/recognition.py:154-159 and stepped at :289, for all live parameters of the model in one launch:
+ *   g' = grad_scale*g + weight_decay*p;  m = momentum*m + g';  p -= lr*(nesterov ? g' + momentum*m : m)
+ * params / grads / momentum_buf: n floats each, 16-byte aligned (views of the host's three flat buffers; grads is the
+ * buffer the data-parallel all-reduce ran on).  grad_scale folds the 1/world of a SUM all-reduce and the 1/loss_scale
+ * of float16 training into the update.  momentum_buf starts at zero (first step: m = g', as torch initialises it). */
+int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
+                    float weight_decay, int nesterov, float grad_scale, void* stream);
 
 /* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);

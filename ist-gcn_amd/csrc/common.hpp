@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define ISTGCN_OK 0
 #define ISTGCN_EINVAL 1
@@ -15,14 +16,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
 // Element traits.  One "k-group" = the 16 bytes of contraction index one lane feeds to the
-// matrix core: 8 bf16 (one v_mfma_f32_32x32x16_bf16) or 4 f32 (four v_mfma_f32_32x32x2_f32,
+// matrix core: 8 bf16 / fp16 (one v_mfma_f32_32x32x16_{bf16,f16}) or 4 f32 (four v_mfma_f32_32x32x2_f32,
 // lane-half h contributing k = 4h+s to step s).  Both operands use the same slot -> k map,
-// so the contraction is exact whatever the order.
+// so the contraction is exact whatever the order.  dtype codes of the C ABI: 0 = f32, 1 = bf16, 2 = fp16;
+// the two 16-bit types share every tiling constant (geometry functions treat dtype != 0 alike).
 // ---------------------------------------------------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -38,9 +45,21 @@ template <> struct Elem<__bf16> {
   static constexpr int KGS = 16;
   static constexpr int CC = 64;
   typedef bf16x8 frag;
+  typedef bf16x4 frag4;
   __device__ static inline float to_f(__bf16 v) { return (float)v; }
   __device__ static inline __bf16 from_f(float v) { return (__bf16)v; }
 };
+template <> struct Elem<_Float16> {
+  static constexpr int EPL = 8;
+  static constexpr int KGS = 16;
+  static constexpr int CC = 64;
+  typedef f16x8 frag;
+  typedef f16x4 frag4;
+  __device__ static inline float to_f(_Float16 v) { return (float)v; }
+  __device__ static inline _Float16 from_f(float v) { return (_Float16)v; }
+};
+
+static inline bool istgcn_dtype_ok(int dtype) { return dtype >= 0 && dtype <= 2; }
 
 __device__ static inline void mma_kgroup(f32x16& acc, const f32x4& a, const f32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
@@ -50,6 +69,39 @@ __device__ static inline void mma_kgroup(f32x16& acc, const f32x4& a, const f32x
 }
 __device__ static inline void mma_kgroup(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ static inline void mma_kgroup(f32x16& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+
+// 16-bit element types: transposed LDS read (ds_read_b64_tr_b16, identical for both 16-bit formats) of the two 4-row
+// blocks a lane addresses -> one MFMA operand fragment; and an 8-element dot product on v_dot2 (no conversions).
+template <typename T>
+__device__ static inline typename Elem<T>::frag tr_pair(const T* lo_addr, const T* hi_addr) {
+  typedef typename Elem<T>::frag4 frag4;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_addr);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_addr);
+  frag4 l4 = __builtin_bit_cast(frag4, lo), h4 = __builtin_bit_cast(frag4, hi);
+  typename Elem<T>::frag o;
+  o[0] = l4[0]; o[1] = l4[1]; o[2] = l4[2]; o[3] = l4[3];
+  o[4] = h4[0]; o[5] = h4[1]; o[6] = h4[2]; o[7] = h4[3];
+  return o;
+}
+__device__ static inline float dot8(const bf16x8& a, const bf16x8& b, float s) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const bf16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
+    s = __builtin_amdgcn_fdot2_f32_bf16(a2, b2, s, false);
+  }
+  return s;
+}
+__device__ static inline float dot8(const f16x8& a, const f16x8& b, float s) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const f16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
+    s = __builtin_amdgcn_fdot2(a2, b2, s, false);
+  }
+  return s;
 }
 
 // D tile of a 32x32 MFMA: lane l holds column (l & 31); register r holds row
@@ -69,6 +121,10 @@ __device__ static inline void store4(float* dst, const float (&v)[4]) {
 __device__ static inline void store4(__bf16* dst, const float (&v)[4]) {
   bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   *reinterpret_cast<bf16x4*>(dst) = o;
+}
+__device__ static inline void store4(_Float16* dst, const float (&v)[4]) {
+  f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  *reinterpret_cast<f16x4*>(dst) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -267,20 +323,35 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // that many: every extra workgroup repeats the per-workgroup prologue (adjacency tables) / flush and waits for a slot
 // anyway.  Cached per (kernel, block size, LDS bytes); thread_local so DataParallel's per-device threads never race.
 inline int istgcn_resident_blocks(const void* kfn, int threads, size_t lds) {
-  struct Entry { const void* k; int threads; size_t lds; int blocks; };
+  struct Entry { const void* k; int threads; int dev; size_t lds; int blocks; };
   thread_local Entry cache[64];
   thread_local int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   for (int i = 0; i < n; ++i)
-    if (cache[i].k == kfn && cache[i].threads == threads && cache[i].lds == lds) return cache[i].blocks;
-  int dev = 0, cus = 0, occ = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-    cus = 256;
+    if (cache[i].k == kfn && cache[i].threads == threads && cache[i].lds == lds && cache[i].dev == dev)
+      return cache[i].blocks;
+  int cus = 0, occ = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, threads, lds) != hipSuccess || occ < 1) occ = 1;
   (void)hipGetLastError();
   const int blocks = occ * cus;
-  if (n < 64) cache[n++] = Entry{kfn, threads, lds, blocks};
+  if (n < 64) cache[n++] = Entry{kfn, threads, dev, lds, blocks};
   return blocks;
+}
+
+// Opt a kernel into > 64 KiB of dynamic LDS.  The attribute is per DEVICE (a single-process multi-GPU caller --
+// nn.DataParallel -- launches the same kernel on several devices from several threads), so the "done" flag is one bit
+// per device ordinal in an atomic mask owned by the call site.  Returns 0 or 2000 + hipError.
+inline int istgcn_lds_optin(const void* kfn, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return 2000 + (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
 }
 
 #define ISTGCN_CHECK_LAUNCH()                         \

@@ -23,6 +23,7 @@ struct GbdParams {
   const void* dy;        // [NM][T][V][Cout]
   const void* x;         // [NM][T][V][Cin] or null
   const float* A;        // [K][V][V]
+  const float* pat;      // [K][V][V] or null: entries != 0 are the sparsity pattern dA is computed on (null: A itself)
   const void* Wb;        // fragments, see istgcn.h
   const void* addend;    // [NM][T][V][Cin] or null (may alias dx)
   void* dx;              // [NM][T][V][Cin]
@@ -62,8 +63,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
 
   // ---- adjacency -> LDS (coalesced), then per-ROW compressed lists: row v -> entries (k, w, a) ----
   {
+    // lists are built on the PATTERN (entries whose gradient is wanted: the constant adjacency B of A_eff = B (.) imp,
+    // which stays fixed when an importance value passes through zero); the values come from A
     float* A_l = reinterpret_cast<float*>(dxa);
-    for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = P.A[i];
+    const float* patg = P.pat ? P.pat : P.A;
+    for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = patg[i];
     for (int r = tid; r < TR; r += NTHREADS) {
       int f = r / V;
       row_f[r] = (unsigned char)f;
@@ -88,10 +92,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
       int e = r_off[tid];
       for (int k = 0; k < K; ++k)
         for (int w = 0; w < V; ++w) {
-          const float a = A_l[(k * V + tid) * V + w];
-          if (a != 0.f) {
+          if (A_l[(k * V + tid) * V + w] != 0.f) {
             if (e < P.nnz_cap) {
-              r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = a;
+              r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = P.A[(k * V + tid) * V + w];
               r_ofs[e] = (k * NCH * TR + w) * EPL;
             }
             ++e;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
                 a = *reinterpret_cast<const frag_t*>(xrow + q * EPL);
                 b = *reinterpret_cast<const frag_t*>(drow + (size_t)q * TR * EPL);
               }
-              dAacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, dAacc, 0, 0, 0);
+              if constexpr (sizeof(T) == 2) mma_kgroup(dAacc, a, b);
             }
           }
         }
@@ -270,13 +273,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
                 const frag_t a = *reinterpret_cast<const frag_t*>(xr + (f * V) * DS + q * EPL);
                 const frag_t b = *reinterpret_cast<const frag_t*>(dr + (q * TR + f * V) * EPL);
                 if constexpr (sizeof(T) == 2) {
-                  // v_dot2c_f32_bf16: two bf16 products per lane-op, no conversions
-                  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                  for (int e = 0; e < EPL; e += 2) {
-                    const bf16x2 a2 = {a[e], a[e + 1]}, b2 = {b[e], b[e + 1]};
-                    s = __builtin_amdgcn_fdot2_f32_bf16(a2, b2, s, false);
-                  }
+                  s = dot8(a, b, s);           // v_dot2: two 16-bit products per lane-op, no conversions
                 } else {
 #pragma unroll
                   for (int e = 0; e < EPL; ++e) s += E::to_f(a[e]) * E::to_f(b[e]);
@@ -298,7 +295,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         // global stores are whole 16-byte vectors of contiguous rows instead of 8-byte pieces of 25 different lines
         dA_dots();
         __syncthreads();
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
         const int CT = (CCi + 31) >> 5;
         const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
         const int q4 = (lane & 15) >> 2, pp = lane & 3;
@@ -314,14 +310,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
               const int c0 = ct * 32 + cblk + 4 * pp;
               const int cc = c0 < CCi ? c0 : 0;         // channels beyond the chunk: any finite data (results discarded)
               const T* r0 = dxa + ((k * NCH + cc / EPL) * TR + f * V + 16 * sstep + 8 * h + q4) * EPL + cc % EPL;
-              s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)r0);
-              s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * EPL));
-              bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-              frag_t a;
-              a[0] = l4[0]; a[1] = l4[1]; a[2] = l4[2]; a[3] = l4[3];
-              a[4] = h4[0]; a[5] = h4[1]; a[6] = h4[2]; a[7] = h4[3];
+              const frag_t a = tr_pair<T>(r0, r0 + 4 * EPL);
               const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
-              d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, d, 0, 0, 0);
+              mma_kgroup(d, a, bfr);
             }
           }
           if (v < V) {
@@ -452,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int v = mfma_row(r, lane);
-          if (v < V && w < V && P.A[(wave * V + v) * V + w] != 0.f)     // gradient on the sparsity pattern only
+          if (v < V && w < V && (P.pat ? P.pat : P.A)[(wave * V + v) * V + w] != 0.f)     // gradient on the sparsity pattern only
             atomicAdd(P.dA + (wave * V + v) * V + w, dAacc[r]);
         }
       }
@@ -490,12 +481,8 @@ int launch_mtk(GbdParams& P, int grid_cap, size_t lds, hipStream_t stream) {
 #define GO(VV, AG)                                                                                          \
   do {                                                                                                      \
     auto kfn = gcn_bwd_kernel<T, MTK, VV, AG>;                                                                \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done) {                                                                                       \
-      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (ea_ != hipSuccess) return 2000 + (int)ea_;                                                        \
-      attr_done = true;                                                                                     \
-    }                                                                                                       \
+    static std::atomic<unsigned long long> optin{0};                                                        \
+    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
     int gx = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS, lds);             \
     gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
     ISTGCN_LAUNCH(kfn, dim3(gx), dim3(NTHREADS), lds, stream, P);                                           \
@@ -549,27 +536,28 @@ int launch_T(GbdParams& P, const GbdGeom& G, int grid_cap, hipStream_t stream) {
 
 extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc,
                                        int* KKp, int* EPL) {
-  if ((dtype != 0 && dtype != 1) || Cin < 1 || Cout < 1 || K < 1 || K > 4) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype) || Cin < 1 || Cout < 1 || K < 1 || K > 4) return ISTGCN_EINVAL;
   GbdGeom G;
   gbd_geom(Cin, Cout, K, dtype, &G);
   *CCi = G.CCi; *nchi = G.nchi; *CCc = G.CCc; *nchc = G.nchc; *KKp = G.KKp; *EPL = dtype == 0 ? 4 : 8;
   return ISTGCN_OK;
 }
 
-extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const void* Wb, const void* addend,
-                                   void* dx, float* dA, int NM, int T, int V, int Cin, int Cout, int K, int nnz_cap,
-                                   int dtype, int grid_cap, void* stream) {
+extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
+                                   const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
+                                   int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
   if (!dy || !A || !Wb || !dx) return ISTGCN_EINVAL;
   if (dA && !x) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
   if (nnz_cap < 1 || nnz_cap > K * V * V || (dA && nnz_cap > 16 * NTHREADS)) return ISTGCN_EINVAL;
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
   GbdParams P{};
-  P.dy = dy; P.x = x; P.A = A; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
+  P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;
   GbdGeom G;
   gbd_geom(Cin, Cout, K, dtype, &G);
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
+  if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }

@@ -219,7 +219,6 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
         //      A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows v beyond the frame
         //      multiply zero adjacency rows), A_k fragments from LDS; the VALU version of this pass cost ~2500
         //      instructions per wave and tile (conversions + addressing) against 24 MFMAs of real work. ----
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
         const int CT = (P.CCeff + 31) >> 5;
         const int npair = nf * CT;
         const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
@@ -238,11 +237,7 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
 #pragma unroll
           for (int sstep = 0; sstep < 2; ++sstep) {
             const T* r0 = xs + (f * V + 16 * sstep + 8 * h + q4) * P.xs_stride + ct * 32 + cblk + 4 * pp;
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)r0);
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(r0 + 4 * P.xs_stride));
-            bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-            a[sstep][0] = l4[0]; a[sstep][1] = l4[1]; a[sstep][2] = l4[2]; a[sstep][3] = l4[3];
-            a[sstep][4] = h4[0]; a[sstep][5] = h4[1]; a[sstep][6] = h4[2]; a[sstep][7] = h4[3];
+            a[sstep] = tr_pair<T>(r0, r0 + 4 * P.xs_stride);
           }
           const int w = lane & 31;
           for (int k = 0; k < K; ++k) {
@@ -251,8 +246,8 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
             const frag_t b0 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
             const frag_t b1 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
+            mma_kgroup(d, a[0], b0);
+            mma_kgroup(d, a[1], b1);
             if (w < V) {
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
@@ -430,12 +425,8 @@ int launch_mt(const GcnFwdParams& P, int grid_cap, int gy, size_t lds, hipStream
 #define GO(VI, VO)                                                                                          \
   do {                                                                                                      \
     auto kfn = gcn_fwd_kernel<T, MT, VI, VO>;                                                               \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done) {                                                                                       \
-      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
-      attr_done = true;                                                                                     \
-    }                                                                                                       \
+    static std::atomic<unsigned long long> optin{0};                                                        \
+    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
     int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS, lds)) / gy;      \
     gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
     ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS), lds, stream, P);                                       \
@@ -512,13 +503,14 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
   if (dtype == 1) return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
+  if (dtype == 2) return launch_T<_Float16>(P, grid_cap, (hipStream_t)stream);
   return ISTGCN_EINVAL;
 }
 
 // Geometry query so the host can size / order the fragment-packed weights exactly as the kernel reads them.
 extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp,
                                    int* MTtot, int* EPL) {
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   const int epl = dtype == 0 ? 4 : 8, cc = dtype == 0 ? 32 : 64, kgs = 2 * epl;
   int cce = Cin >= cc ? cc : round_up(Cin, epl);
   int MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;

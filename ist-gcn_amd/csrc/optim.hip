@@ -1,0 +1,58 @@
+// SGD (momentum, Nesterov, weight decay) over ONE flat fp32 range: the update of processor/recognition.py:154-159
+// (optim.SGD(lr, momentum=0.9, nesterov, weight_decay)) + :289 (optimizer.step()) for every live parameter of the model
+// in a single launch.  The host keeps parameters, gradients and momentum as views of three flat buffers (harness.FlatSGD);
+// the gradient buffer is the very buffer the data-parallel all-reduce runs on (dp.FlatGradSync), so a step is
+// all-reduce + this kernel.
+//
+//   g' = grad_scale * g + weight_decay * p          (grad_scale: 1/world for the all-reduce SUM, 1/loss_scale for fp16)
+//   m  = momentum * m + g'                          (m starts at zero: the first step gives m = g', as torch does)
+//   p -= lr * (nesterov ? g' + momentum * m : m)
+//
+// HBM-bound: 3 reads + 2 writes of 4 bytes per parameter (12.6 MB of parameters for config 2 -> ~63 MB per step).
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, long long n, float lr, float momentum,
+                                                       float wd, int nesterov, float gscale) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gscale * gv[j] + wd * pv[j];
+      mv[j] = momentum * mv[j] + gg;
+      pv[j] -= lr * (nesterov ? gg + momentum * mv[j] : mv[j]);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+  }
+  // tail (n not a multiple of 4)
+  const long long t = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) {
+    const float gg = gscale * g[t] + wd * p[t];
+    const float mm = momentum * m[t] + gg;
+    m[t] = mm;
+    p[t] -= lr * (nesterov ? gg + momentum * mm : mm);
+  }
+}
+
+}  // namespace
+
+extern "C" int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
+                               float momentum, float weight_decay, int nesterov, float grad_scale, void* stream) {
+  if (!params || !grads || !momentum_buf || n < 0) return ISTGCN_EINVAL;
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) return ISTGCN_EINVAL;   // 16-byte vectors
+  if (n == 0) return ISTGCN_OK;
+  long long blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  ISTGCN_LAUNCH(sgd_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr,
+                momentum, weight_decay, nesterov, grad_scale);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}

@@ -128,6 +128,7 @@ extern "C" int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, l
   PackGcn P{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot};
   const int total = nch * mttot * P.NKG * 2 * 32;
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
@@ -155,6 +156,7 @@ extern "C" int istgcn_pack_tconv(const float* src, long long s_t, long long s_o,
   }
   const int total = nch * ntaps * P.NKG * mttot * 2 * 32;
   if (dtype == 0) ISTGCN_LAUNCH(pack_tconv_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else if (dtype == 2) ISTGCN_LAUNCH(pack_tconv_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_tconv_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
@@ -174,6 +176,7 @@ extern "C" int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_
   PackGcnBwd P{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32};
   const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32;
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
+  else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_bwd_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;

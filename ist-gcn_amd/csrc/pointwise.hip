@@ -349,6 +349,13 @@ extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, doubl
   return ISTGCN_OK;
 }
 
+// dtype dispatch of the element-wise kernels: cast every activation pointer to the element type and launch
+#define EW_CASES(BODY)                                           \
+  do {                                                           \
+    if (dtype == 0) { typedef float ET; constexpr int VWB = 4; BODY; }        \
+    else if (dtype == 1) { typedef __bf16 ET; constexpr int VWB = 8; BODY; }  \
+    else { typedef _Float16 ET; constexpr int VWB = 8; BODY; }                \
+  } while (0)
 #define DISPATCH_VW(KERNEL, TYPE, VWBIG, grid, ...)                                                                   \
   do {                                                                                                            \
     if (vw == VWBIG) ISTGCN_LAUNCH((KERNEL<TYPE, VWBIG>), grid, dim3(NT), 0, (hipStream_t)stream, __VA_ARGS__); \
@@ -358,19 +365,14 @@ extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, doubl
 extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
                                     long long rows, int C, float p_drop, unsigned long long seed, int dtype,
                                     void* stream) {
-  if (!z || !coef2 || !out || rows < 0 || C < 1 || (dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f)
+  if (!z || !coef2 || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
   const DropCfg D = make_drop(p_drop, seed);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
-  if (dtype == 0) {
-    const float *zz = (const float*)z, *rr = (const float*)res; float* oo = (float*)out;
-    DISPATCH_VW(block_out_fwd_kernel, float, 4, grid, zz, coef2, rr, coefr, oo, (size_t)rows, C, D);
-  } else {
-    const __bf16 *zz = (const __bf16*)z, *rr = (const __bf16*)res; __bf16* oo = (__bf16*)out;
-    DISPATCH_VW(block_out_fwd_kernel, __bf16, 8, grid, zz, coef2, rr, coefr, oo, (size_t)rows, C, D);
-  }
+  EW_CASES(DISPATCH_VW(block_out_fwd_kernel, ET, VWB, grid, (const ET*)z, coef2, (const ET*)res, coefr, (ET*)out,
+                       (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
@@ -381,7 +383,7 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const voi
                                     void* stream) {
   if (!dout || !out || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
   if ((r != nullptr) != (coefr != nullptr) || (r && !statsr)) return ISTGCN_EINVAL;
-  if ((dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   int vw = dtype == 0 ? pick_vw<float>(C, true) : pick_vw<__bf16>(C, true);
   if (vw == 1 && (C > NT || NT % C != 0)) return ISTGCN_EINVAL;   // scalar map needs C | 256
@@ -390,30 +392,21 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const voi
   size_t g = ((size_t)rows + rpb - 1) / rpb;
   if (g > 1024) g = 1024;
   const dim3 grid((int)g);
-  if (dtype == 0) {
-    DISPATCH_VW(block_out_bwd_kernel, float, 4, grid, (const float*)dout, (const float*)out, (const float*)z, coef2,
-                  (const float*)r, coefr, (float*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D);
-  } else {
-    DISPATCH_VW(block_out_bwd_kernel, __bf16, 8, grid, (const __bf16*)dout, (const __bf16*)out, (const __bf16*)z, coef2,
-                  (const __bf16*)r, coefr, (__bf16*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D);
-  }
+  EW_CASES(DISPATCH_VW(block_out_bwd_kernel, ET, VWB, grid, (const ET*)dout, (const ET*)out, (const ET*)z, coef2,
+                       (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
 
 extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C,
                               float p_drop, unsigned long long seed, int dtype, void* stream) {
-  if (!d || !abc || !out || rows < 0 || C < 1 || (dtype != 0 && dtype != 1) || p_drop < 0.f || p_drop > 1.f)
+  if (!d || !abc || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
   const DropCfg D = make_drop(p_drop, seed);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
-  if (dtype == 0) {
-    DISPATCH_VW(affine2_kernel, float, 4, grid, (const float*)d, (const float*)x, abc, (float*)out, (size_t)rows, C, D);
-  } else {
-    DISPATCH_VW(affine2_kernel, __bf16, 8, grid, (const __bf16*)d, (const __bf16*)x, abc, (__bf16*)out, (size_t)rows, C, D);
-  }
+  EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

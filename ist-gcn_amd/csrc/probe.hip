@@ -24,7 +24,6 @@ __global__ void probe_tr16_kernel(const unsigned short* src, int nelem, const in
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   for (int i = threadIdx.x; i < nelem; i += 64) lds[i] = src[i];
   __syncthreads();
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
   const int off = lane_byte_off[threadIdx.x];
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)lds + off));
@@ -41,6 +40,9 @@ extern "C" int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dt
   else if (dtype == 1)
     ISTGCN_LAUNCH(probe_mfma_kernel<__bf16>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const __bf16*)A,
                        (const __bf16*)Bt, D);
+  else if (dtype == 2)
+    ISTGCN_LAUNCH(probe_mfma_kernel<_Float16>, dim3(1), dim3(64), 0, (hipStream_t)stream, (const _Float16*)A,
+                       (const _Float16*)Bt, D);
   else
     return ISTGCN_EINVAL;
   ISTGCN_CHECK_LAUNCH();

@@ -394,12 +394,8 @@ int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
 #define GO(VV, MD)                                                                                           \
   do {                                                                                                      \
     auto kfn = tconv_kernel<T, MT, NT, VV, WM, MD>;                                                               \
-    static bool attr_done = false;                                                                          \
-    if (!attr_done) {                                                                                       \
-      hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (ea_ != hipSuccess) return 2000 + (int)ea_; \
-      attr_done = true;                                                                                     \
-    }                                                                                                       \
+    static std::atomic<unsigned long long> optin{0};                                                        \
+    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
     int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS * WM, lds)) / gy; \
     gx = round_up(gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx), 8);  /* XCD-affine order: multiple of 8 */ \
     ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS * WM), lds, stream, P);                                  \
@@ -469,7 +465,7 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
 
 extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype,
                                      int* CC, int* nch, int* MTtot, int* EPL) {
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (!tap_off || ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1) return ISTGCN_EINVAL;
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
@@ -489,7 +485,7 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   if (mode == 1 && (!aux || !maux)) return ISTGCN_EINVAL;
   if (Mlog > 0 && (Mlog - 1) * out_mul + out_off >= Tout) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   for (int j = 2; j < ntaps; ++j)      // taps must be equally spaced (every forward / data-gradient phase of a conv is)
     if (tap_off[j] - tap_off[j - 1] != tap_off[1] - tap_off[0]) return ISTGCN_EINVAL;
   if (NM == 0 || Mlog == 0) return ISTGCN_OK;
@@ -503,6 +499,7 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
+  if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }
 

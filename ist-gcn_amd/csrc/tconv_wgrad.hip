@@ -56,29 +56,6 @@ struct TwgParams {
   long long ws_slice;
 };
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-static int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-  }
-  return cus;
-}
-
-__device__ static inline bf16x8 tr_pair(const __bf16* lo_addr, const __bf16* hi_addr) {
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo_addr);
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi_addr);
-  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-  bf16x8 o;
-  o[0] = l4[0]; o[1] = l4[1]; o[2] = l4[2]; o[3] = l4[3];
-  o[4] = h4[0]; o[5] = h4[1]; o[6] = h4[2]; o[7] = h4[3];
-  return o;
-}
-
 // sub-tiled staging: vector q of a row goes to sub-tile q / QV.  Split in two so the global loads of the NEXT tile can
 // be in flight (in registers) while the matrix cores work on the current one: item it = it0 + tid + u*nthreads.
 template <typename T, int U, bool VEC>
@@ -361,19 +338,19 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
           for (int unit = wave; unit < IT * nf * K; unit += NWG * TS) {     // (sub-tile, frame, partition) units
             const int k = unit % K, pr = unit / K;
             const int sub = pr / nf, f = pr - sub * nf;
-            bf16x8 a[2];
+            frag_t a[2];
 #pragma unroll
             for (int sstep = 0; sstep < 2; ++sstep) {
               const T* r0 = dzs + (sub * P.dz_rows + f * V + 16 * sstep + 8 * hh + q4) * CB + cblk + 4 * pp;
-              a[sstep] = tr_pair(r0, r0 + 4 * CB);
+              a[sstep] = tr_pair<T>(r0, r0 + 4 * CB);
             }
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
+            const frag_t b0 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
+            const frag_t b1 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b0, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b1, d, 0, 0, 0);
+            mma_kgroup(d, a[0], b0);
+            mma_kgroup(d, a[1], b1);
             if (w < V) {
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
@@ -544,18 +521,18 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
       const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
       const int q = (lane & 15) >> 2, pp = lane & 3;
       const int coff = cblk + 4 * pp;
-      bf16x8 a0, a1, b0[JTW], b1[JTW];
-      auto load_k = [&](int kk, bf16x8& a, bf16x8 (&b)[JTW]) {
+      frag_t a0, a1, b0[JTW], b1[JTW];
+      auto load_k = [&](int kk, frag_t& a, frag_t (&b)[JTW]) {
         const int pb = pbase + 16 * kk + 8 * h + q;          // this lane addresses rows pb and pb+4 of its 8 positions
-        a = tr_pair(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
+        a = tr_pair<T>(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
         const T* u0 = us_w + (AGG ? pb : (int)urow[pb]) * CB + coff;
         const T* u1 = us_w + (AGG ? pb + 4 : (int)urow[pb + 4]) * CB + coff;
 #pragma unroll
-        for (int j = 0; j < JTW; ++j) b[j] = tr_pair(u0 + toff[j], u1 + toff[j]);
+        for (int j = 0; j < JTW; ++j) b[j] = tr_pair<T>(u0 + toff[j], u1 + toff[j]);
       };
-      auto mma_k = [&](const bf16x8& a, const bf16x8 (&b)[JTW]) {
+      auto mma_k = [&](const frag_t& a, const frag_t (&b)[JTW]) {
 #pragma unroll
-        for (int j = 0; j < JTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < JTW; ++j) mma_kgroup(acc[j], a, b[j]);
       };
       if constexpr (NK == 1 || JTW > 4 || AGG) {
 #pragma unroll
@@ -735,26 +712,11 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (off > 160 * 1024 || P.urows > 65535) return ISTGCN_EINVAL;
   const int blocks = n_oblk * P.n_iblk;
   auto kfn = tconv_wgrad_kernel<T, JT, OT, IT, PS, AGG, TS, VEC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ea_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (ea_ != hipSuccess) return 2000 + (int)ea_;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
   // persistent grid: exactly the workgroups that are resident at once (every extra one pays a full flush of its
   // accumulators through atomics and waits for a slot anyway)
-  if (grid_cap < 1) {
-    static size_t occ_lds = ~(size_t)0;
-    static int occ = 1;
-    if (occ_lds != off) {
-      int o = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)kfn, 64 * OT * IT * PS * TS, off) != hipSuccess || o < 1)
-        o = 1;
-      occ = o;
-      occ_lds = off;
-    }
-    grid_cap = occ * device_cus();
-  }
+  if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, 64 * OT * IT * PS * TS, off);
   int gx = grid_cap / blocks;
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
@@ -762,7 +724,7 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   static const bool dbg = getenv("ISTGCN_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[istgcn] wgrad<%s JT=%d OT=%d IT=%d PS=%d TS=%d %s> Cin=%d Cout=%d taps=%d grid=(%d,%d) lds=%zu capf=%d Fin=%d\n",
-            esz == 2 ? "bf16" : "f32", JT, OT, IT, PS, TS, AGG ? "agg" : "conv", P.Cin, P.Cout, P.ntaps, gx, blocks, off,
+            esz == 2 ? "16bit" : "f32", JT, OT, IT, PS, TS, AGG ? "agg" : "conv", P.Cin, P.Cout, P.ntaps, gx, blocks, off,
             P.capf, P.Fin);
   const int n0 = P.ntaps * P.Cout * P.Cin, n1 = AGG ? P.V * P.Cout : P.Cout;
   float* aux_dst = AGG ? P.S : P.dbias;
@@ -846,7 +808,7 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   if (!dz || !g || !dW || !tap_off) return ISTGCN_EINVAL;
   if (ntaps < 1 || ntaps > 15 || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1 || NM < 0 || Tz < 0)
     return ISTGCN_EINVAL;
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || Tz == 0) return ISTGCN_OK;
   TwgParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;
@@ -856,6 +818,7 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
   for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
   for (int j = ntaps; j < MAX_TAPS; ++j) P.tap_off[j] = tap_off[0];    // padding taps: valid addresses, never flushed
   if (dtype == 0) return launch_T<float>(P, grid_cap, (hipStream_t)stream);
+  if (dtype == 2) return launch_T<_Float16>(P, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }
 
@@ -866,13 +829,14 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
   if (!dy || !x || !A || !dW) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
   if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
-  if (dtype != 0 && dtype != 1) return ISTGCN_EINVAL;
+  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
   TwgParams P{};
   P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
   P.NM = NM; P.Tin = T; P.Tz = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = K; P.in_mul = 1;
   P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;
   if (dtype == 0) return launch_agg_T<float>(P, grid_cap, (hipStream_t)stream);
+  if (dtype == 2) return launch_agg_T<_Float16>(P, grid_cap, (hipStream_t)stream);
   return launch_agg_T<__bf16>(P, grid_cap, (hipStream_t)stream);
 }
 

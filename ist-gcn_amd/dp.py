@@ -63,6 +63,13 @@ class FlatGradSync:
         self._flat.div_(self.world)
         torch._foreach_copy_([g for g, _, _ in views], [self._flat[o:o + n].view_as(g) for g, o, n in views])
 
+    def all_reduce_flat_(self, flat):
+        """SUM-all-reduce a caller-owned flat gradient buffer in place (harness.FlatSGD's `G`): the whole exchange step
+        of the data-parallel path, no packing.  The caller folds 1/world into its update."""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
     @property
     def bucket_bytes(self):
         return 0 if self._flat is None else self._flat.numel() * 4

@@ -108,16 +108,13 @@ def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, sta
     """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase."""
     NM, Tz = dz.shape[0], dz.shape[1]
     out = torch.empty((NM, T_in, V, cin), dtype=dz.dtype, device=dz.device)
-    filled = False
     for phase in range(stride):
         tl = ops.conv_taps_bwd(k, stride, phase)
         Mlog = (T_in - phase + stride - 1) // stride
         if Mlog <= 0:
             continue
-        if not tl:
-            if not filled:
-                out.zero_()
-                filled = True
+        if not tl:                       # no tap lands on this phase (k < stride): those frames get no gradient
+            out[:, phase::stride].zero_()
             continue
         offs = [dj for _, dj in tl]
         # transposed taps [k][Cin][Cout] as a view; the packer gathers this phase's taps straight from the parameter
@@ -132,16 +129,18 @@ def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, sta
 # --------------------------------------------------------------------------------------------------
 class GraphConvFn(torch.autograd.Function):
     """y = einsum('nkctv,kvw->nctw', conv1x1(x; W, b), A_eff) on NTVC tensors.
-    inputs: x [NM,T,V,Cin], A_eff [K,V,V], bterm [V,Cout] (or None), W3 [K,Cout,Cin]; nnz_cap int."""
+    inputs: x [NM,T,V,Cin], A_eff [K,V,V], bterm [V,Cout] (or None), W3 [K,Cout,Cin]; nnz_cap int; pattern [K,V,V]
+    fp32 or None = dense (every entry of A_eff gets its gradient, as autograd of net/utils/tgcn.py:86 gives)."""
 
     @staticmethod
-    def forward(ctx, x, A_eff, bterm, W3, nnz_cap):
+    def forward(ctx, x, A_eff, bterm, W3, nnz_cap, pattern=None):
         K, cout, cin = W3.shape
         A_eff = A_eff.contiguous()
         wp = ops.pack_gcn_weight(W3.permute(1, 0, 2), x.dtype)
         y = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, nnz_cap=nnz_cap)
         ctx.save_for_backward(x, A_eff, W3)
         ctx.nnz_cap = nnz_cap
+        ctx.pattern = pattern
         ctx.has_b = bterm is not None
         return y
 
@@ -154,8 +153,11 @@ class GraphConvFn(torch.autograd.Function):
         dW, S = ops.gcn_wgrad(dy, x, A_eff, want_S=ctx.has_b, nnz_cap=ctx.nnz_cap)
         dx = dA = None
         if ctx.needs_input_grad[0] or need_A:
-            dx, dA = ops.gcn_bwd_data(dy, A_eff, W3, x=x, want_dA=need_A, nnz_cap=ctx.nnz_cap)
-        return dx, dA, (S if ctx.has_b else None), dW, None
+            pat, cap = ctx.pattern, ctx.nnz_cap
+            if need_A and pat is None:
+                pat, cap = torch.ones_like(A_eff), A_eff.numel()
+            dx, dA = ops.gcn_bwd_data(dy, A_eff, W3, x=x, want_dA=need_A, nnz_cap=cap, pattern=pat)
+        return dx, dA, (S if ctx.has_b else None), dW, None, None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -165,7 +167,7 @@ class BlockCfg:
     """Static description of one block (shapes, variant, BatchNorm hyper-parameters)."""
 
     def __init__(self, cin, cout, K, V, stride, residual, tcn, ksize, p_drop, nnz_cap, width=None,
-                 momentum=0.1, eps=1e-5):
+                 momentum=0.1, eps=1e-5, pattern=None):
         self.cin, self.cout, self.K, self.V, self.stride = cin, cout, K, V, stride
         self.residual = residual          # 'none' | 'id' | 'conv'
         self.tcn = tcn                    # 'conv' (single or pre-summed multi-branch) | 'bneck'
@@ -173,6 +175,7 @@ class BlockCfg:
         self.p_drop, self.nnz_cap = p_drop, nnz_cap
         self.width = width                # bottleneck width int(sqrt(C))
         self.momentum, self.eps = momentum, eps
+        self.pattern = pattern            # [K,V,V] fp32 sparsity pattern of the adjacency gradient (None: dense)
 
 
 class STGCNBlockFn(torch.autograd.Function):
@@ -293,8 +296,11 @@ class STGCNBlockFn(torch.autograd.Function):
         dx = dA = None
         if ctx.needs_input_grad[4] or need_A or cfg.residual == 'conv':
             addend = dres if cfg.residual == 'id' else None
-            dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cfg.nnz_cap,
-                                      dA_out=buf_A)
+            pat, cap = cfg.pattern, cfg.nnz_cap
+            if need_A and pat is None:
+                pat, cap = torch.ones_like(A_eff), A_eff.numel()
+            dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cap, dA_out=buf_A,
+                                      pattern=pat)
         if cfg.residual == 'conv':
             abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training, clear=True)
             dr = ops.affine2(dres, r, abcr)

@@ -8,14 +8,128 @@ import torch
 import torch.nn.functional as F
 
 
-def make_optimizer(model, optimizer='SGD', base_lr=0.1, nesterov=True, weight_decay=1e-4):
-    """recognition.py:152-166"""
+class FlatSGD:
+    """torch.optim.SGD(lr, momentum, nesterov, weight_decay) of processor/recognition.py:154-159,289 on three FLAT fp32
+    buffers: every live parameter's `.data` is a view of `P`, its gradient lands in the matching view of `G`, its
+    momentum in `M`, and ONE launch of `istgcn_sgd_step` updates the whole model.  `G` is also the buffer the
+    data-parallel all-reduce runs on, in place (`attach_sync`): no pack / unpack copies, and the 1/world of the SUM as
+    well as the 1/loss_scale of float16 training are folded into the update kernel.
+
+    * live = parameters that have a gradient after the first backward.  Parameters whose gradient stays None (the
+      reference's dead `linear.*`, `gcn.branch.bn.*`) are skipped entirely -- no weight decay either -- exactly as
+      torch.optim.SGD skips `p.grad is None`.  A parameter that gets its first gradient later is updated by the same
+      rule with plain tensor ops (slow path, never taken by the shipped models).
+    * gradients that autograd delivered as tensors of their own are gathered into `G` by one multi-tensor copy; those
+      the engine wrote straight into their `G` view cost nothing.
+    * interface used by the reference's processor: `param_groups[i]['lr']`, `zero_grad()`, `step()`.
+    `update_fn(P, G, M, lr, momentum, weight_decay, nesterov, grad_scale)` defaults to the HIP kernel (GPU tensors only);
+    the CPU gloo test of the bucket logic passes a torch restatement."""
+
+    def __init__(self, params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, loss_scale=1.0, update_fn=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.param_groups = [dict(params=self.params, lr=lr, momentum=momentum, nesterov=nesterov,
+                                  weight_decay=weight_decay)]
+        self.loss_scale = float(loss_scale)
+        self.sync = None
+        self._update = update_fn
+        self.P = self.G = self.M = None
+        self._live, self._gviews, self._late = [], [], {}
+
+    def attach_sync(self, sync):
+        """dp.FlatGradSync: all-reduce `G` in place inside step()."""
+        self.sync = sync
+        return self
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def _build(self):
+        live = [p for p in self.params if p.grad is not None]
+        if not live:
+            raise RuntimeError('FlatSGD.step(): no parameter has a gradient')
+        dev = live[0].device
+        offs, total = [], 0
+        for p in live:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise RuntimeError('FlatSGD: parameters must be fp32 tensors on one device')
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4                      # every view 16-byte aligned
+        self.P = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            pviews = [self.P[o:o + p.numel()].view(p.shape) for p, o in zip(live, offs)]
+            torch._foreach_copy_(pviews, [p.data for p in live])
+            for p, v in zip(live, pviews):
+                p.data = v
+        self._gviews = [self.G[o:o + p.numel()].view(p.shape) for p, o in zip(live, offs)]
+        self._live = live
+        self._live_ids = {id(p) for p in live}
+
+    @property
+    def bucket_bytes(self):
+        return 0 if self.G is None else self.G.numel() * 4
+
+    @torch.no_grad()
+    def step(self):
+        if self.P is None:
+            self._build()
+        src, dst = [], []
+        for p, gv in zip(self._live, self._gviews):
+            g = p.grad
+            if g is None:
+                raise RuntimeError('FlatSGD: a parameter had a gradient on the first step and has none now')
+            if g.data_ptr() != gv.data_ptr():
+                src.append(g if g.dtype == torch.float32 else g.float())
+                dst.append(gv)
+                p.grad = gv
+        if src:
+            torch._foreach_copy_(dst, src)
+        scale = 1.0 / self.loss_scale
+        if self.sync is not None and self.sync.world > 1:
+            self.sync.all_reduce_flat_(self.G)                      # SUM, in place; the mean's 1/world goes into the update
+            scale /= self.sync.world
+        grp = self.param_groups[0]
+        upd = self._update
+        if upd is None:
+            from . import ops
+            upd = ops.sgd_step
+        upd(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale)
+        for p in self.params:                                        # slow path: first gradient after the layout was fixed
+            if p.grad is not None and id(p) not in self._live_ids:
+                g = p.grad.float() * scale
+                if self.sync is not None and self.sync.world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(g, group=self.sync.group)
+                g = g + grp['weight_decay'] * p.data
+                buf = self._late.get(id(p))
+                buf = g.clone() if buf is None else buf.mul_(grp['momentum']).add_(g)
+                self._late[id(p)] = buf
+                p.data.add_(g + grp['momentum'] * buf if grp['nesterov'] else buf, alpha=-grp['lr'])
+
+    def state_dict(self):
+        return {'momentum': None if self.M is None else self.M.clone(), 'param_groups': [
+            {k: v for k, v in g.items() if k != 'params'} for g in self.param_groups], 'loss_scale': self.loss_scale}
+
+    def load_state_dict(self, sd):
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+        self.loss_scale = sd.get('loss_scale', 1.0)
+        if sd.get('momentum') is not None:
+            if self.M is None:
+                raise RuntimeError('FlatSGD.load_state_dict: run one step first (the flat layout is fixed by it)')
+            self.M.copy_(sd['momentum'])
+
+
+def make_optimizer(model, optimizer='SGD', base_lr=0.1, nesterov=True, weight_decay=1e-4, loss_scale=1.0):
+    """recognition.py:152-166.  SGD on GPU parameters -> FlatSGD (one update launch, flat all-reduce bucket)."""
     if optimizer == 'SGD':
         params = list(model.parameters())
-        # same update rule, one multi-tensor kernel per step instead of ~11 (weight decay, momentum, nesterov, update)
-        fused = bool(params) and all(p.is_cuda for p in params)
-        return torch.optim.SGD(params, lr=base_lr, momentum=0.9, nesterov=nesterov, weight_decay=weight_decay,
-                               fused=fused)
+        if params and all(p.is_cuda for p in params):
+            return FlatSGD(params, lr=base_lr, momentum=0.9, nesterov=nesterov, weight_decay=weight_decay,
+                           loss_scale=loss_scale)
+        return torch.optim.SGD(params, lr=base_lr, momentum=0.9, nesterov=nesterov, weight_decay=weight_decay)
     if optimizer == 'Adam':
         return torch.optim.Adam(model.parameters(), lr=base_lr, weight_decay=weight_decay)
     raise ValueError()
@@ -37,9 +151,10 @@ def train_step(model, optimizer, data, label, grad_sync=None):
     output = model(data)
     loss = F.cross_entropy(output, label)
     optimizer.zero_grad()
-    loss.backward()
-    if grad_sync is not None:
-        grad_sync()
+    ls = getattr(optimizer, 'loss_scale', 1.0)
+    (loss * ls if ls != 1.0 else loss).backward()       # float16 storage: scaled backward, un-scaled inside the update
+    if grad_sync is not None and getattr(optimizer, 'sync', None) is not grad_sync:
+        grad_sync()                                       # (FlatSGD with attach_sync all-reduces its own flat buffer)
     optimizer.step()
     return loss.detach()
 

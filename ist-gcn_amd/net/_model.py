@@ -37,7 +37,30 @@ VARIANTS = {
 }
 
 _DTYPES = {'float32': torch.float32, 'fp32': torch.float32, 'bfloat16': torch.bfloat16, 'bf16': torch.bfloat16,
-           torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
+           'float16': torch.float16, 'fp16': torch.float16, 'half': torch.float16,
+           torch.float32: torch.float32, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16}
+
+
+def draw_seed():
+    """One 63-bit draw from torch's CPU generator (no device sync): reproducible under torch.manual_seed, different on
+    every call, safe from nn.DataParallel's replica threads (the generator locks).  Replaces id()/call counters, which
+    repeat on throw-away replicas and are not reproducible."""
+    return int(torch.empty((), dtype=torch.int64).random_()) & 0x7FFFFFFFFFFFFFFF
+
+
+def mix_seed(base, block_index, device):
+    """Philox key of one block's dropout for this forward: the per-forward draw, the block's position in the model, the
+    rank (ranks seeded alike must not drop the same elements of their different shards) and the device ordinal."""
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    di = device.index if device.index is not None else 0
+    x = (base ^ (0x9E3779B97F4A7C15 * (block_index + 1)) ^ (0xC2B2AE3D27D4EB4F * (rank + 1)) ^ (0x165667B19E3779F9 * (di + 1)))
+    x &= 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 33
+    x = (x * 0xFF51AFD7ED558CCD) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 33
+    return x & 0x7FFFFFFFFFFFFFFF
 
 
 class _ConvHolder(nn.Module):
@@ -117,10 +140,19 @@ class STGCNBlock(nn.Module):
             self.residual = nn.Sequential(nn.Conv2d(in_channels, c, kernel_size=1, stride=(stride, 1)),
                                           nn.BatchNorm2d(c))
         self.relu = nn.ReLU(inplace=True)
-        self._calls = 0
+        self.block_index = 0               # position in the Model (set by STGCNModel): part of the dropout key
+
+    def batchnorms(self):
+        if self.tcn_kind == 'single':
+            bns = (self.tcn[0], self.tcn[3])
+        else:
+            bns = (self.tcn_start[0], self.tcn_end[0])
+        return bns + ((self.residual[1],) if self.res_mode == 'conv' else ())
 
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
-    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET):
+    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True):
+        """pattern: [K,V,V] fp32 sparsity pattern of the adjacency gradient (None = dense); seed_base: the Model's
+        per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself."""
         if not x.is_cuda:
             raise RuntimeError('istgcn_amd: the st_gcn block runs on MI355X only (tensor on %s); no CPU fallback'
                                % x.device)
@@ -160,13 +192,14 @@ class STGCNBlock(nn.Module):
         if nnz_cap is None:
             nnz_cap = self.K * V * V
         cfg = Fn.BlockCfg(self.cin, c, self.K, V, self.stride, self.res_mode, mode, ks, self.p_drop, int(nnz_cap),
-                          width=getattr(self, 'width', None), momentum=mom if mom is not None else 0.1, eps=eps)
+                          width=getattr(self, 'width', None), momentum=mom if mom is not None else 0.1, eps=eps,
+                          pattern=pattern)
         training = self.training
-        if training:
-            for bn in (bn1, bn2) + ((self.residual[1],) if self.res_mode == 'conv' else ()):
-                bn.num_batches_tracked.add_(1)
-        self._calls += 1
-        seed = (torch.initial_seed() * 1000003 + id(self) % 65521 * 7919 + self._calls) & 0x7FFFFFFFFFFFFFFF
+        if training and bump:
+            torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms()], 1)
+        seed = 0
+        if training and self.p_drop > 0:
+            seed = mix_seed(draw_seed() if seed_base is None else seed_base, self.block_index, x.device)
         return Fn.STGCNBlockFn.apply(cfg, training, seed, bufs, x, A_eff, bterm, Wg3, bn1.weight, bn1.bias, Wt, bt,
                                      bn2.weight, bn2.bias, Wr, br, gr, betar, Ws, bs, We, be)
 
@@ -197,6 +230,7 @@ def _buffers_reloaded(module, incompatible_keys):
     """load_state_dict may have replaced the adjacency buffers: drop everything derived from them."""
     module._nnz_cap = None
     module._fold_consts.clear()
+    module._patterns.clear()
 
 
 class STGCNModel(nn.Module):
@@ -224,6 +258,7 @@ class STGCNModel(nn.Module):
                 blocks.append(self.BLOCK(cin, cout, kernel_size, 1, residual=False, **kwargs0))
             else:
                 blocks.append(self.BLOCK(cin, cout, kernel_size, stride, **kwargs))
+            blocks[-1].block_index = idx
             cin = cout
         self.st_gcn_networks = nn.ModuleList(blocks)
         n_imp = 3 if self.gcn_kind in ('incep', '3a') else 1
@@ -239,6 +274,7 @@ class STGCNModel(nn.Module):
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._nnz_cap = None
         self._fold_consts = {}               # device -> [J,K,V,V] constants of the fused importance fold
+        self._patterns = {}                  # device -> [K,V,V] fp32 union pattern of those constants
         self.register_load_state_dict_post_hook(_buffers_reloaded)
 
     # the sparsity pattern bounds the kernels' in-LDS adjacency lists; recomputed if buffers are reloaded
@@ -269,6 +305,14 @@ class STGCNModel(nn.Module):
             B = self._fold_consts[dev] = torch.stack([m.to(dev) for m in mats]).contiguous()
         return B
 
+    def _pattern(self, dev):
+        """[K,V,V] fp32, 1 where any constant adjacency of the fold is non-zero: the entries whose importance gradient
+        exists.  Fixed by the buffers, so an importance value that reaches exactly 0 keeps receiving its gradient."""
+        pat = self._patterns.get(dev)
+        if pat is None:
+            pat = self._patterns[dev] = (self._fold_B(dev) != 0).any(0).float().contiguous()
+        return pat
+
     def _folded(self, i, blk):
         """(A_eff, bterm-or-_UNSET) of block i: one fused launch when the importances are learnable parameters."""
         imps = [self.edge_importance[i]]
@@ -290,10 +334,16 @@ class STGCNModel(nn.Module):
         x = self.data_bn(x)
         x = x.view(N * M, V, C, T).permute(0, 3, 1, 2).contiguous().to(self.act_dtype)
         cap = self._cap()
+        pat = self._pattern(x.device)
+        seed_base = None
+        if self.training:
+            seed_base = draw_seed()
+            # every BatchNorm of the trunk advances its counter: ONE multi-tensor launch instead of 2-3 per block
+            torch._foreach_add_([bn.num_batches_tracked for blk in self.st_gcn_networks for bn in blk.batchnorms()], 1)
         for i, blk in enumerate(self.st_gcn_networks):
             mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
             A_eff, bterm = self._folded(i, blk)
-            x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm)
+            x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False)
         return x
 
     def forward(self, x):

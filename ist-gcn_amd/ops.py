@@ -4,14 +4,15 @@ pointers and the current HIP stream of the tensor's device to `libistgcn_hip.so`
 RuntimeError on a non-zero return.  Nothing here computes on the CPU; there is no fallback.
 """
 import ctypes
+import threading
 
 import torch
 import torch.nn.functional as F
 
 from . import _lib
 
-DT_F32, DT_BF16 = 0, 1
-_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}
 STATS_REP = 8          # replicated BatchNorm partial-sum rows (spreads the fp64 atomics)
 
 
@@ -19,7 +20,7 @@ def dtype_code(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError('istgcn: unsupported activation dtype %s (float32 / bfloat16 only)' % t.dtype)
+        raise TypeError('istgcn: unsupported activation dtype %s (float32 / bfloat16 / float16 only)' % t.dtype)
 
 
 def _ptr(t):
@@ -54,8 +55,14 @@ PROFILE = None
 PROFILE_ONLY = None     # if set: only launches of this entry point are timed (keeps the event overhead off the others)
 
 
-def _call(fn_name, *args, work=None):
+def _call(fn_name, *args, work=None, dev=None):
+    """dev: device of the tensors (from _check_dev).  The library launches on the CURRENT HIP device, so when the
+    tensors live elsewhere (a model moved with .to('cuda:1') while cuda:0 is current) the call runs under a device
+    guard; in the common case (same device) this costs one integer comparison."""
     lib = _lib.load()
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return _call(fn_name, *args, work=work)
     if PROFILE is not None and work is not None and (PROFILE_ONLY is None or PROFILE_ONLY == fn_name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -97,7 +104,7 @@ def pack_gcn_weight(wr, dtype):
     out = torch.empty(int(n), dtype=dtype, device=wr.device)
     so, sk, si = wr.stride()
     _call('istgcn_pack_gcn', _ptr(wr), ctypes.c_longlong(so), ctypes.c_longlong(sk), ctypes.c_longlong(si), _ptr(out),
-          cin, cout, K, _DT[dtype], _stream(wr))
+          cin, cout, K, _DT[dtype], _stream(wr), dev=wr.device)
     return out
 
 
@@ -113,9 +120,15 @@ def pack_gcn_weight_ref(wr, dtype):
     return w.to(dtype).contiguous()
 
 
+CHECK_NNZ = False        # debug / test switch: verify (with a host sync) that a reduced nnz_cap really covers nnz(A)
+
+
 def gcn_forward(x, A, wp, cout, bterm=None, addend=None, out=None, stats=None, Tout=None, Tlog=None,
                 in_t_stride=1, out_t_stride=1, nnz_cap=None, grid_cap=0):
-    """istgcn_gcn_fwd.  x: [NM,Tin,V,Cin]; A: [K,V,V] fp32; wp from pack_gcn_weight; returns y [NM,Tout,V,cout]."""
+    """istgcn_gcn_fwd.  x: [NM,Tin,V,Cin]; A: [K,V,V] fp32; wp from pack_gcn_weight; returns y [NM,Tout,V,cout].
+    nnz_cap (default K*V*V = cannot overflow) sizes the in-LDS column lists; a smaller cap is a promise that
+    nnz(A) <= cap (the Models derive it from their adjacency buffers' pattern).  With ops.CHECK_NNZ the kernel's
+    overflow flag is read back and a broken promise raises instead of silently truncating the lists."""
     NM, Tin, V, Cin = x.shape
     K = A.shape[0]
     assert A.shape == (K, V, V) and A.dtype == torch.float32
@@ -134,12 +147,15 @@ def gcn_forward(x, A, wp, cout, bterm=None, addend=None, out=None, stats=None, T
         assert stats.dtype == torch.float64 and stats.shape[-2:] == (2, cout)
     if nnz_cap is None:
         nnz_cap = K * V * V
-    _check_dev(x, A, wp, bterm, addend, out, stats)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device) if (CHECK_NNZ and nnz_cap < K * V * V) else None
+    dv = _check_dev(x, A, wp, bterm, addend, out, stats)
     _call('istgcn_gcn_fwd', _ptr(x), _ptr(A), _ptr(wp), _ptr(bterm), _ptr(addend), _ptr(out), _ptr(stats),
-          0 if stats is None else stats.shape[0], None, NM, Tin, Tout, Tlog, V, Cin, cout, K,
+          0 if stats is None else stats.shape[0], _ptr(status), NM, Tin, Tout, Tlog, V, Cin, cout, K,
           in_t_stride, out_t_stride, int(nnz_cap), dtype_code(x), grid_cap, _stream(x),
           work=(2.0 * NM * Tlog * V * cout * K * Cin + 2.0 * NM * Tlog * V * V * K * cout,      # 1x1 conv + dense einsum
-                float(NM * Tlog * V) * (Cin + cout * (2 if addend is not None else 1)) * _esz(x)))
+                float(NM * Tlog * V) * (Cin + cout * (2 if addend is not None else 1)) * _esz(x)), dev=dv)
+    if status is not None and int(status.item()) != 0:
+        raise RuntimeError('istgcn_gcn_fwd: the adjacency has more non-zeros than nnz_cap=%d (lists truncated)' % nnz_cap)
     return out
 
 
@@ -175,7 +191,7 @@ def pack_tconv_weight(wf, V, tap_off, in_mul, dtype, tap_sel=None):
     out = torch.empty(int(n), dtype=dtype, device=wf.device)
     st, so, si = wf.stride()
     _call('istgcn_pack_tconv', _ptr(wf), ctypes.c_longlong(st), ctypes.c_longlong(so), ctypes.c_longlong(si),
-          _int_array(tap_sel), _ptr(out), V, cin, cout, len(tap_off), offs, in_mul, _DT[dtype], _stream(wf))
+          _int_array(tap_sel), _ptr(out), V, cin, cout, len(tap_off), offs, in_mul, _DT[dtype], _stream(wf), dev=wf.device)
     return out
 
 
@@ -206,12 +222,12 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
         assert maux is not None and maux.shape == (4, cout) and maux.dtype == torch.float32
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.shape[-2:] == (2, cout)
-    _check_dev(x, wp, bias, pre, aux, maux, out, stats)
+    dv = _check_dev(x, wp, bias, pre, aux, maux, out, stats)
     _call('istgcn_tconv', _ptr(x), _ptr(wp), _ptr(bias), _ptr(pre), int(bool(pre_relu)), _ptr(aux), _ptr(maux),
           _ptr(out), _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, Cin, cout,
           len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), grid_cap, _stream(x),
           work=(2.0 * NM * Mlog * V * cout * Cin * len(tap_off),
-                float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if mode == 1 else 1)) * _esz(x)))
+                float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if mode == 1 else 1)) * _esz(x)), dev=dv)
     return out
 
 
@@ -249,7 +265,9 @@ WGRAD_WS_FLOATS = 16 << 20          # 64 MiB per device: per-workgroup partial s
 
 
 def _wgrad_ws(dev):
-    """Partial-sum workspace of the wgrad kernels: one per (device, stream), so launches that can overlap never share."""
+    """Partial-sum workspace of the wgrad kernels: one per (device, stream).  Launches on one stream are serialised (a
+    launch writes its slices and its reduce kernel consumes them before the next launch starts), so host threads
+    that share a stream may share it; launches that can overlap (different streams) never do."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _WGRAD_WS.get(key)
     if ws is None:
@@ -270,11 +288,11 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
     else:
         dW = torch.zeros((len(tap_off), Cout, Cin), dtype=torch.float32, device=dz.device)
         db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
-    _check_dev(dz, g, pre, dW, db)
+    dv = _check_dev(dz, g, pre, dW, db)
     _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
           V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap,
           _ptr(_wgrad_ws(dz.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dz),
-          work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)))
+          work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)), dev=dv)
     return dW, db
 
 
@@ -298,7 +316,7 @@ def pack_gcn_wb(w3, dtype):
     out = torch.empty(int(n), dtype=dtype, device=w3.device)
     sk, sc, si = w3.stride()
     _call('istgcn_pack_gcn_bwd', _ptr(w3), ctypes.c_longlong(sk), ctypes.c_longlong(sc), ctypes.c_longlong(si),
-          _ptr(out), cin, cout, K, _DT[dtype], _stream(w3))
+          _ptr(out), cin, cout, K, _DT[dtype], _stream(w3), dev=w3.device)
     return out
 
 
@@ -315,8 +333,10 @@ def pack_gcn_wb_ref(w3, dtype):
     return w.to(dtype).contiguous()
 
 
-def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None):
-    """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None)."""
+def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None):
+    """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None).  pattern [K,V,V] fp32 (non-zero = entry whose
+    gradient is wanted; None = the non-zeros of A): pass the constant adjacency of A = B * importance so that an
+    importance value of exactly 0 keeps its gradient, or ones for a dense learnable A (autograd of tgcn.py:86)."""
     NM, T, V, Cout = dy.shape
     K, cout2, Cin = w3.shape
     assert cout2 == Cout and A.shape == (K, V, V) and A.dtype == torch.float32
@@ -332,11 +352,13 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
     wb = pack_gcn_wb(w3, dy.dtype)
     if nnz_cap is None:
         nnz_cap = K * V * V
-    _check_dev(dy, x, A, wb, addend, dx, dA)
-    _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(wb), _ptr(addend), _ptr(dx),
+    if pattern is not None:
+        assert pattern.shape == (K, V, V) and pattern.dtype == torch.float32
+    dv = _check_dev(dy, x, A, pattern, wb, addend, dx, dA)
+    _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(pattern), _ptr(wb), _ptr(addend), _ptr(dx),
           _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
           work=(2.0 * NM * T * V * Cout * K * Cin + 2.0 * NM * T * V * V * K * Cin,
-                float(NM * T * V) * (Cout + Cin * (1 + (1 if want_dA else 0) + (1 if addend is not None else 0))) * _esz(dy)))
+                float(NM * T * V) * (Cout + Cin * (1 + (1 if want_dA else 0) + (1 if addend is not None else 0))) * _esz(dy)), dev=dv)
     return dx, dA
 
 
@@ -355,10 +377,10 @@ def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0, out=None):
         S = torch.zeros((V, Cout), dtype=torch.float32, device=dev) if want_S else None
     if nnz_cap is None:
         nnz_cap = K * V * V
-    _check_dev(dy, x, A, dW, S)
+    dv = _check_dev(dy, x, A, dW, S)
     _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(dW), _ptr(S), NM, T, V, Cin, Cout, K, int(nnz_cap),
           dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dev)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
-          work=(2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)))
+          work=(2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)), dev=dv)
     return dW, S
 
 
@@ -369,18 +391,25 @@ def new_stats(C, device):
     return torch.zeros((STATS_REP, 2, C), dtype=torch.float64, device=device)
 
 
-_STATS_SCRATCH = {}
+_STATS_SCRATCH = {}          # (device, stream, host thread, slot, C) -> [buffer, handed-out flag]
+_SCRATCH_BY_PTR = {}         # data_ptr -> the same entry (so the consumer finds it without scanning)
+_SCRATCH_LOCK = threading.Lock()
 
 
 def stats_scratch(slot, C, device):
     """A persistent, zero-between-uses [STATS_REP][2][C] fp64 buffer: the kernel that produces batch sums adds into it,
-    `bn_finalize` / `bn_bwd_coef` (clear=True) read it and zero it again.  One per (device, stream, slot, C); distinct
-    `slot`s for sums that are alive at the same time.  Saves a memset launch per BatchNorm per pass.  If a previous
-    user never consumed its sums (an exception between producer and consumer), the buffer is re-zeroed here."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, slot, C)
+    `bn_finalize` / `bn_bwd_coef` (clear=True) read it and zero it again.  One per (device, stream, host thread, slot,
+    C): distinct `slot`s for sums that are alive at the same time, and the thread in the key so that two modules driven
+    from two host threads onto one stream (or nn.DataParallel's replica threads) never add into each other's sums.
+    Saves a memset launch per BatchNorm per pass.  If a previous user never consumed its sums (an exception between
+    producer and consumer), the buffer is re-zeroed here."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), slot, C)
     ent = _STATS_SCRATCH.get(key)
     if ent is None:
-        ent = _STATS_SCRATCH[key] = [new_stats(C, device), False]
+        ent = [new_stats(C, device), False]
+        with _SCRATCH_LOCK:
+            _STATS_SCRATCH[key] = ent
+            _SCRATCH_BY_PTR[ent[0].data_ptr()] = ent
     elif ent[1]:
         ent[0].zero_()
     ent[1] = True                      # handed to a producer; bn_finalize / bn_bwd_coef(clear=True) mark it clean
@@ -388,21 +417,20 @@ def stats_scratch(slot, C, device):
 
 
 def _scratch_consumed(stats):
-    for ent in _STATS_SCRATCH.values():
-        if ent[0] is stats:
-            ent[1] = False
-            return
+    ent = _SCRATCH_BY_PTR.get(stats.data_ptr())
+    if ent is not None and ent[0] is stats:
+        ent[1] = False
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear=False):
     """-> coef [4][C] fp32: scale, shift, mean, rstd.  Training also updates the running statistics in place."""
     C = gamma.shape[0]
     coef = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
-    _check_dev(stats, gamma, beta, running_mean, running_var, coef)
+    dv = _check_dev(stats, gamma, beta, running_mean, running_var, coef)
     _call('istgcn_bn_finalize', _ptr(stats), 0 if stats is None else stats.shape[0], int(bool(clear)),
           ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum),
-          ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma))
+          ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma), dev=dv)
     if clear and stats is not None:
         _scratch_consumed(stats)
     return coef
@@ -414,10 +442,10 @@ def bn_bwd_coef(stats, count, gamma, coef, training, clear=False):
     abc = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
     dg = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     db = torch.empty((C,), dtype=torch.float32, device=gamma.device)
-    _check_dev(stats, gamma, coef, abc, dg, db)
+    dv = _check_dev(stats, gamma, coef, abc, dg, db)
     _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], int(bool(clear)), ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(coef),
-          int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma))
+          int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma), dev=dv)
     if clear:
         _scratch_consumed(stats)
     return abc, dg, db
@@ -429,12 +457,12 @@ def _rows(t):
 
 def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0):
     out = torch.empty_like(z)
-    _check_dev(z, coef2, res, coefr, out)
+    dv = _check_dev(z, coef2, res, coefr, out)
     if res is not None:
         assert res.shape == z.shape and res.dtype == z.dtype
     _call('istgcn_block_out_fwd', _ptr(z), _ptr(coef2), _ptr(res), _ptr(coefr), _ptr(out), ctypes.c_longlong(_rows(z)),
           z.shape[-1], ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
-          work=(3.0 * z.numel(), float(z.numel()) * (3 if res is not None else 2) * _esz(z)))
+          work=(3.0 * z.numel(), float(z.numel()) * (3 if res is not None else 2) * _esz(z)), dev=dv)
     return out
 
 
@@ -450,21 +478,21 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
         st2 = new_stats(C, z.device)
         str_ = new_stats(C, z.device) if r is not None else None
     assert dout.shape == z.shape == out.shape and dout.dtype == z.dtype
-    _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
+    dv = _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
     _call('istgcn_block_out_bwd', _ptr(dout), _ptr(out), _ptr(z), _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres),
           _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C, ctypes.c_float(p_drop),
           ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
-          work=(6.0 * z.numel(), float(z.numel()) * (5 if r is not None else 4) * _esz(z)))
+          work=(6.0 * z.numel(), float(z.numel()) * (5 if r is not None else 4) * _esz(z)), dev=dv)
     return dres, st2, str_
 
 
 def affine2(d, x, abc, p_drop=0.0, seed=0):
     """out = abc[0]*d*dropmask + abc[1]*x + abc[2]  (BatchNorm backward, elementwise part)."""
     out = torch.empty_like(d)
-    _check_dev(d, x, abc, out)
+    dv = _check_dev(d, x, abc, out)
     _call('istgcn_affine2', _ptr(d), _ptr(x), _ptr(abc), _ptr(out), ctypes.c_longlong(_rows(d)), d.shape[-1],
           ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(d), _stream(d),
-          work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)))
+          work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)), dev=dv)
     return out
 
 
@@ -477,10 +505,10 @@ def fold_fwd(B, imps, bias, C):
     assert len(imps) == J and all(i.shape == (K, V, V) and i.dtype == torch.float32 for i in imps)
     A_eff = torch.empty((K, V, V), dtype=torch.float32, device=B.device)
     bterm = torch.empty((V, C), dtype=torch.float32, device=B.device) if bias is not None else None
-    _check_dev(B, bias, A_eff, bterm, *imps)
+    dv = _check_dev(B, bias, A_eff, bterm, *imps)
     ip = [_ptr(i) for i in imps] + [_ptr(None)] * (3 - J)
     _call('istgcn_fold_fwd', _ptr(B), J, ip[0], ip[1], ip[2], _ptr(bias), _ptr(A_eff), _ptr(bterm), K, V, int(C),
-          _stream(B))
+          _stream(B), dev=dv)
     return A_eff, bterm
 
 
@@ -491,11 +519,11 @@ def fold_bwd(B, imps, bias, dA, S, C):
     dbias = torch.empty_like(bias) if (bias is not None and S is not None) else None
     if dbias is None and bias is not None:
         dbias = torch.zeros_like(bias)
-    _check_dev(B, bias, dA, S, dbias, *imps, *dimps)
+    dv = _check_dev(B, bias, dA, S, dbias, *imps, *dimps)
     ip = [_ptr(i) for i in imps] + [_ptr(None)] * (3 - J)
     dp = [_ptr(i) for i in dimps] + [_ptr(None)] * (3 - J)
     _call('istgcn_fold_bwd', _ptr(B), J, ip[0], ip[1], ip[2], _ptr(bias), _ptr(dA), _ptr(S), dp[0], dp[1], dp[2],
-          _ptr(dbias if S is not None else None), K, V, int(C), _stream(B))
+          _ptr(dbias if S is not None else None), K, V, int(C), _stream(B), dev=dv)
     return dimps, dbias
 
 
@@ -504,9 +532,9 @@ def tcn_fold_fwd(w1, w2, w3, b1, b2, b3, mst, scale):
     Co, Ci = w3.shape[0], w3.shape[1]
     taps = torch.empty((15, Co, Ci), dtype=torch.float32, device=w3.device)
     bias = torch.empty((Co,), dtype=torch.float32, device=w3.device)
-    _check_dev(w1, w2, w3, b1, b2, b3, mst, taps, bias)
+    dv = _check_dev(w1, w2, w3, b1, b2, b3, mst, taps, bias)
     _call('istgcn_tcn_fold_fwd', _ptr(w1), _ptr(w2), _ptr(w3), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(mst),
-          ctypes.c_float(scale), _ptr(taps), _ptr(bias), Co, Ci, _stream(w3))
+          ctypes.c_float(scale), _ptr(taps), _ptr(bias), Co, Ci, _stream(w3), dev=dv)
     return taps, bias
 
 
@@ -515,7 +543,21 @@ def tcn_fold_bwd(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, scale):
     Co, Ci = w3.shape[0], w3.shape[1]
     outs = [torch.empty_like(t) for t in (w1, w2, w3, b1, b2, b3)]
     dmst = torch.zeros_like(mst)
-    _check_dev(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, dmst, *outs)
+    dv = _check_dev(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, dmst, *outs)
     _call('istgcn_tcn_fold_bwd', _ptr(dtaps), _ptr(dbias), _ptr(w1), _ptr(w2), _ptr(w3), _ptr(b1), _ptr(b2), _ptr(b3),
-          _ptr(mst), ctypes.c_float(scale), *[_ptr(t) for t in outs], _ptr(dmst), Co, Ci, _stream(w3))
+          _ptr(mst), ctypes.c_float(scale), *[_ptr(t) for t in outs], _ptr(dmst), Co, Ci, _stream(w3), dev=dv)
     return (*outs, dmst)
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizer (optim.hip)
+# ----------------------------------------------------------------------------------------------
+def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0):
+    """istgcn_sgd_step over three flat fp32 buffers of equal length (in place on params / momentum_buf)."""
+    n = params.numel()
+    assert grads.numel() == n and momentum_buf.numel() == n
+    assert params.dtype == grads.dtype == momentum_buf.dtype == torch.float32
+    dv = _check_dev(params, grads, momentum_buf)
+    _call('istgcn_sgd_step', _ptr(params), _ptr(grads), _ptr(momentum_buf), ctypes.c_longlong(n), ctypes.c_float(lr),
+          ctypes.c_float(momentum), ctypes.c_float(weight_decay), int(bool(nesterov)), ctypes.c_float(grad_scale),
+          _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)

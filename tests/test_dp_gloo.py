@@ -78,3 +78,73 @@ def test_shard_batch_rejects_ragged():
     from istgcn_amd.dp import shard_batch
     with pytest.raises(ValueError):
         shard_batch(torch.zeros(7, 2), torch.zeros(7), 0, 2)
+
+
+def _torch_sgd_update(P, G, M, lr, momentum, wd, nesterov, gscale):
+    """torch restatement of istgcn_sgd_step (csrc/optim.hip) for the CPU test of FlatSGD's bucket logic."""
+    g = G * gscale + wd * P
+    M.mul_(momentum).add_(g)
+    P.add_(g + momentum * M if nesterov else M, alpha=-lr)
+
+
+def _worker_flat_sgd(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from istgcn_amd.dp import FlatGradSync, shard_batch
+    from istgcn_amd.harness import FlatSGD, train_step
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    m = Tiny()
+    sync = FlatGradSync(m)
+    opt = FlatSGD(m.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4,
+                  update_fn=_torch_sgd_update).attach_sync(sync)
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 6, generator=g), torch.randint(0, 4, (8,), generator=g)
+    xs, ys = shard_batch(X, Y, rank, world)
+
+    class Wrap(nn.Module):                     # harness.train_step feeds (N, ...) float data straight to the model
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            return self.inner(x)
+    w = Wrap(m)
+    for _ in range(3):
+        train_step(w, opt, xs, ys, sync)      # sync is the optimizer's own: all-reduced in place on its flat buffer
+    res = {k: v.detach().clone() for k, v in m.named_parameters()}
+    res['__bytes'] = opt.bucket_bytes
+    res['__is_view'] = all(p.data_ptr() >= opt.P.data_ptr() and p.data_ptr() < opt.P.data_ptr() + opt.P.numel() * 4
+                           for k, p in m.named_parameters() if not k.startswith('dead'))
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_sgd_allreduces_its_own_bucket_and_matches_full_batch_sgd():
+    """f1 (recognition.py:154-159,287-289): parameters / gradients / momentum as views of three flat buffers, the
+    all-reduce in place on the gradient buffer, 1/world folded into the update; two ranks with half the batch each must
+    follow the single-process full-batch torch.optim.SGD trajectory; dead parameters stay untouched."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_flat_sgd, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    torch.manual_seed(100)
+    ref = Tiny()
+    init_dead = {k: v.detach().clone() for k, v in ref.named_parameters() if k.startswith('dead')}
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 6, generator=g), torch.randint(0, 4, (8,), generator=g)
+    for _ in range(3):
+        opt.zero_grad()
+        nn.functional.cross_entropy(ref(X), Y).backward()
+        opt.step()
+    for k, p in ref.named_parameters():
+        assert torch.allclose(r0[k], p.detach(), atol=2e-6), k
+        assert torch.equal(r0[k], r1[k]), k
+    for k, v in init_dead.items():
+        assert torch.equal(r0[k], v)                                   # no gradient -> no update, no weight decay
+    assert r0['__is_view'] and r0['__bytes'] == 4 * sum((p.numel() + 3) // 4 * 4 for k, p in ref.named_parameters()
+                                                        if not k.startswith('dead'))

@@ -34,7 +34,7 @@ def ops():
 
 
 # ------------------------------------------------------------------------------------------------ pointwise
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 def test_bn_finalize_and_block_out(ops, dt):
     d = dev()
     g = torch.Generator().manual_seed(3)
@@ -42,8 +42,8 @@ def test_bn_finalize_and_block_out(ops, dt):
     z = torch.randn(rows, C, generator=g) * 2 + 0.5
     res = torch.randn(rows, C, generator=g)
     gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
-    if dt == torch.bfloat16:
-        z, res = z.bfloat16().float(), res.bfloat16().float()
+    if dt != torch.float32:
+        z, res = z.to(dt).float(), res.to(dt).float()
     rm, rv = torch.zeros(C), torch.ones(C)
     ref = F.batch_norm(z, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
     st = ops.new_stats(C, d)
@@ -98,16 +98,18 @@ def _block_args(kind, A, A2, A3, imps, mst):
     return (A, imps[0], imps[1], imps[2], mst)
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('kind', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn'])
 def test_blocks_golden(golden, kind, dt):
     g = golden('block_g3_%s.npz' % kind)
     mod = importlib.import_module('istgcn_amd.net.' + kind)
     d = dev()
     bases = sorted({'.'.join(k.split('.')[:2]) + '.' for k in g.files})
-    tol_f, tol_g = (3e-5, 2e-4) if dt == torch.float32 else (2e-2, 0.15)   # bf16: relative L2 (ReLU-mask flips on 576-position fixtures)
-    if dt == torch.bfloat16 and kind == 'st_gcn_mstcn_1x1':
-        tol_g = 0.4     # the fixture's bottleneck is int(sqrt(16)) = 4 channels wide: bf16 storage of a 4-channel tensor is all noise
+    # 16-bit storage: relative L2 (ReLU-mask flips on 576-position fixtures); float16 has 3 more mantissa bits than bfloat16
+    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (2e-2, 0.15), torch.float16: (5e-3, 0.05)}[dt]
+    if dt != torch.float32 and kind == 'st_gcn_mstcn_1x1':
+        # the fixture's bottleneck is int(sqrt(16)) = 4 channels wide: 16-bit storage of a 4-channel tensor is mostly noise
+        tol_g = 0.4 if dt == torch.bfloat16 else 0.1
 
     for b in bases:
         t = lambda k: torch.from_numpy(g[b + k])  # noqa: E731
@@ -122,7 +124,7 @@ def test_blocks_golden(golden, kind, dt):
         blk.to(d)
         imps = [t('imp%d' % j).to(d).requires_grad_(True) for j in (1, 2, 3)]
         mst = t('mst').to(d).requires_grad_(True)
-        xin = x.to(d, dt) if dt == torch.bfloat16 else x.to(d)
+        xin = x.to(d, dt)
         name = 'blk_%s_%s_%s' % (kind, b.strip('.').replace('.', '_'), str(dt)[6:])
         blk.eval()
         with torch.no_grad():
@@ -146,7 +148,7 @@ def test_blocks_golden(golden, kind, dt):
         for j in (1, 2, 3):
             if b + 'dimp%d' % j in g.files:
                 assert close(name + '_dimp%d' % j, imps[j - 1].grad, g[b + 'dimp%d' % j], tol_g, dt)
-        if b + 'dmst' in g.files and not (dt == torch.bfloat16 and kind == 'st_gcn_mstcn_1x1'):
+        if b + 'dmst' in g.files and not (dt != torch.float32 and kind == 'st_gcn_mstcn_1x1'):
             # (the bf16 bottleneck fixture has width int(sqrt(16)) = 4: its 3 importance gradients are sums of ~200
             #  strongly cancelling products of bf16-rounded terms; checked in fp32 only)
             assert close(name + '_dmst', mst.grad, g[b + 'dmst'], tol_g, dt)
@@ -259,7 +261,7 @@ def test_extract_feature_shapes():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 def test_native_packers_match_specification(ops, dt):
     """istgcn_pack_* (one launch, strided in-place reads) == the torch-op specification, bit for bit."""
     d = torch.device('cuda:0')
@@ -344,3 +346,216 @@ def test_fused_tcn_tap_fold_matches_torch_spec(co, ci, scale):
     ref = [rt.detach(), rb.detach()] + [p.grad for p in params]
     for a, b in zip(got, ref):
         assert a.shape == b.shape and rel_err(a.cpu(), b.cpu()) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ round-2 additions
+def test_flat_sgd_kernel_matches_torch_sgd():
+    """harness.FlatSGD (one istgcn_sgd_step launch over the flat buffers) against torch.optim.SGD (recognition.py:
+    154-159): three steps, a dead parameter (no gradient -> untouched, no weight decay), a late one (slow path)."""
+    from istgcn_amd import harness
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 3, 1, 1), (64,), (7, 5), (1,), (3, 25, 25), (33,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    opt_a = harness.FlatSGD(pa, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    opt_b = torch.optim.SGD(pb, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    dead, late = 3, 5
+    for step in range(4):
+        opt_a.zero_grad()
+        opt_b.zero_grad()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == dead or (i == late and step < 2):
+                continue
+            gr = torch.randn(a.shape, generator=g).to(d)
+            a.grad = gr.clone()
+            b.grad = gr.clone()
+        if step == 2:
+            for grp in list(opt_a.param_groups) + list(opt_b.param_groups):
+                grp['lr'] = 0.01                                    # recognition.py:168-176 adjust_lr
+        opt_a.step()
+        opt_b.step()
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            assert rel_err(a, b) < 2e-6, (step, i)
+    assert torch.equal(pa[dead].detach().cpu(), init[dead])           # never touched
+    assert opt_a.bucket_bytes == 4 * sum((p.numel() + 3) // 4 * 4 for i, p in enumerate(pa) if i not in (dead, late))
+    # loss scale: gradients scaled by S and un-scaled inside the kernel give the same update
+    pc = [torch.nn.Parameter(t.clone().to(d)) for t in init[:2]]
+    pd = [torch.nn.Parameter(t.clone().to(d)) for t in init[:2]]
+    oc, od = harness.FlatSGD(pc, loss_scale=1024.0), harness.FlatSGD(pd)
+    for c, dd in zip(pc, pd):
+        gr = torch.randn(c.shape, generator=g).to(d)
+        c.grad, dd.grad = gr * 1024.0, gr.clone()
+    oc.step()
+    od.step()
+    for c, dd in zip(pc, pd):
+        assert rel_err(c, dd) < 1e-6
+
+
+def test_dropout_seed_reproducible_and_fresh_per_forward():
+    """the dropout key comes from torch's CPU generator (reproducible under manual_seed, new on every
+    forward, also on throw-away nn.DataParallel-style replicas), not from id(self) / a per-object call counter."""
+    from torch.nn.parallel import replicate
+    m, nc = _model('st_gcnold', torch.float32, dropout=0.5)
+    m.train()
+    x = det_tensor('seed.x', (2, 3, 32, 25, 2)).to(dev())
+
+    def run(mod):
+        with torch.no_grad():
+            return mod(x).clone()
+    torch.manual_seed(7)
+    a1, a2 = run(m), run(m)
+    torch.manual_seed(7)
+    b1 = run(m)
+    assert not torch.equal(a1, a2)            # consecutive forwards: different masks
+    assert torch.equal(a1, b1)                # same seed: same masks
+    # replicas are rebuilt for every forward (DataParallel): their masks must still change from call to call
+    torch.manual_seed(9)
+    r1 = run(replicate(m, [0])[0])
+    r2 = run(replicate(m, [0])[0])
+    assert not torch.equal(r1, r2)
+
+
+def test_nnz_cap_overflow_is_detected(ops):
+    """a reduced nnz_cap smaller than nnz(A) truncates the in-LDS lists: with ops.CHECK_NNZ the kernel's status flag
+    turns that into an error instead of a silently wrong y."""
+    d = dev()
+    V, K, C = 25, 3, 16
+    A = torch.rand(K, V, V, device=d) + 0.1                    # dense: nnz = 1875
+    x = torch.randn(2, 8, V, C, device=d)
+    wp = ops.pack_gcn_weight(torch.randn(C, K, C, device=d), torch.float32)
+    ops.CHECK_NNZ = True
+    try:
+        ops.gcn_forward(x, A, wp, C, nnz_cap=K * V * V)        # full capacity: fine
+        with pytest.raises(RuntimeError):
+            ops.gcn_forward(x, A, wp, C, nnz_cap=100)
+    finally:
+        ops.CHECK_NNZ = False
+
+
+def test_adjacency_gradient_pattern_keeps_zero_importance_entries(ops):
+    """dA is taken on the constant adjacency pattern: an importance value that is exactly 0 still receives the gradient
+    autograd of tgcn.py:86 gives it (it used to be dropped because A_eff there is 0)."""
+    d = dev()
+    from istgcn_amd.net.utils.graph import Graph
+    B = torch.tensor(Graph('ntu-rgb+d', 'spatial').A, dtype=torch.float32)
+    K, V, _ = B.shape
+    g = torch.Generator().manual_seed(4)
+    imp = torch.rand(K, V, V, generator=g) + 0.5
+    nzidx = (B != 0).nonzero()
+    for i in nzidx[::7]:
+        imp[tuple(i)] = 0.0                                    # exact zeros ON the pattern
+    NM, T, C = 2, 6, 16
+    x = torch.randn(NM, T, V, C, generator=g)
+    dy = torch.randn(NM, T, V, C, generator=g)
+    W3 = torch.randn(K, C, C, generator=g) * C ** -0.5
+    A_eff = (B * imp).requires_grad_(True)
+    h = torch.einsum('kci,ntvi->nktvc', W3, x)
+    y = torch.einsum('nktvc,kvw->ntwc', h, A_eff)
+    y.backward(dy)
+    want = A_eff.grad * (B != 0)
+    pat = (B != 0).float().to(d)
+    cap = int(pat.sum())
+    _, dA = ops.gcn_bwd_data(dy.to(d), (B * imp).to(d), W3.to(d), x=x.to(d), want_dA=True, nnz_cap=cap, pattern=pat)
+    assert diag('dA_pattern', dA, want, 3e-5) < 3e-5
+    zero_on_pattern = ((B != 0) & (imp == 0))
+    assert zero_on_pattern.any() and float(want[zero_on_pattern].abs().max()) > 0
+    # dense pattern (learnable dense A through the unit drop-in): every entry, as autograd
+    _, dA2 = ops.gcn_bwd_data(dy.to(d), (B * imp).to(d), W3.to(d), x=x.to(d), want_dA=True, nnz_cap=K * V * V,
+                              pattern=torch.ones(K, V, V, device=d))
+    assert diag('dA_dense', dA2, A_eff.grad, 3e-5) < 3e-5
+
+
+def test_model_eval_logits_absolute_error(golden):
+    """north_star states the bar as an absolute 1e-3 on the logits; the G4 fixtures reach |logit| ~ 100-150, so the
+    relative gate above admits ~0.1 absolute.  Assert the absolute bound as well and record the measured figures."""
+    import os
+    from gpu_util import OUT
+    lines = []
+    for tag in ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1_deep']:
+        g = golden('model_g4_%s.npz' % tag)
+        m, nc = _model(tag, torch.float32)
+        m.eval()
+        x = det_tensor('g4.x.' + tag, tuple(int(s) for s in g['eval_shape'])).to(dev())
+        with torch.no_grad():
+            y = m(x).double().cpu()
+        ref = torch.from_numpy(g['eval_logits']).double()
+        err = float((y - ref).abs().max())
+        lines.append('%-28s max|logit| %8.3f  max abs err %.3e  rel %.3e' % (tag, float(ref.abs().max()), err,
+                                                                          err / float(ref.abs().max())))
+        assert err < 1e-3, lines[-1]
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'parity_abs_logits.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+
+
+@pytest.mark.parametrize('tag', ['st_gcn_mstcn_1x1_deep', 'st_gcn_msgcn'])
+def test_model_fp16_storage_close_to_fp32(golden, tag):
+    """BASELINE config 5 = net/st_gcn_mstcn_1x1_deep.py:253-269 in float16 at T=600: float16 activations (fp32
+    accumulation, fp64 statistics, static loss scale for the backward pass) against the reference's fp32 logits and the
+    fp32 HIP gradients.  float16 carries 3 more mantissa bits than bfloat16: logits within 5e-3 relative L2."""
+    g = golden('model_g4_%s.npz' % tag)
+    shp = tuple(int(s) for s in g['train_shape'])
+    LS = 4096.0
+    grads = {}
+    for dt in (torch.float32, torch.float16):
+        m, nc = _model(tag, dt)
+        x = det_tensor('g4.xt.' + tag, shp).to(dev())
+        lab = det_labels('g4.lab.' + tag, shp[0], nc).to(dev())
+        m.train()
+        logits = m(x)
+        loss = F.cross_entropy(logits, lab)
+        (loss * (LS if dt == torch.float16 else 1.0)).backward()
+        sc = 1.0 / LS if dt == torch.float16 else 1.0
+        grads[dt] = ([None if p.grad is None else p.grad.double().flatten() * sc for p in m.parameters()],
+                     logits.detach(), float(loss))
+    g32, g16 = grads[torch.float32], grads[torch.float16]
+    assert l2rel(g16[1], g['train_logits']) < 5e-3
+    assert abs(g16[2] - float(g['train_loss'])) < 1e-2
+    a = torch.cat([t for t in g32[0] if t is not None])
+    b = torch.cat([t for t in g16[0] if t is not None])
+    assert torch.isfinite(b).all()
+    assert float((a - b).norm() / a.norm()) < 0.08
+    # eval logits at the full clip shape (T=600 for the deep model)
+    m, nc = _model(tag, torch.float16)
+    m.eval()
+    x = det_tensor('g4.x.' + tag, tuple(int(s) for s in g['eval_shape'])).to(dev())
+    with torch.no_grad():
+        y = m(x)
+    assert l2rel(y, g['eval_logits']) < 5e-3
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_full_batch_step_16bit_vs_fp32_hip(dt):
+    """BASELINE config 2 at its real size -- st_gcn_msgcn, 64 clips (NM = 128), T=300 -- one training step in 16-bit
+    storage against the SAME step of the fp32 HIP path (itself pinned to the reference by the G4 tests): the only test
+    that runs the whole model with every workgroup of every kernel resident, apart from bench.py."""
+    from istgcn_amd import harness
+    gargs, nc = MODEL_CFG['st_gcn_msgcn']
+    mod = importlib.import_module('istgcn_amd.net.st_gcn_msgcn')
+    res = {}
+    for d_ in (torch.float32, dt):
+        torch.manual_seed(0)
+        m = mod.Model(3, nc, gargs, True, dropout=0, compute_dtype=d_)
+        m.apply(harness.weights_init)
+        m.to(dev()).train()
+        gen = torch.Generator().manual_seed(11)
+        x = torch.randn(64, 3, 300, 25, 2, generator=gen).to(dev())
+        y = torch.randint(0, nc, (64,), generator=gen).to(dev())
+        ls = 65536.0 if d_ == torch.float16 else 1.0
+        logits = m(x)
+        loss = F.cross_entropy(logits, y)
+        (loss * ls).backward()
+        res[d_] = (logits.detach().double().cpu(), float(loss),
+                   [None if p.grad is None else (p.grad.double() / ls).flatten().cpu() for p in m.parameters()])
+        del m, x, logits, loss
+        torch.cuda.empty_cache()
+    (l32, loss32, g32), (l16, loss16, g16) = res[torch.float32], res[dt]
+    tol_l, tol_g = (3e-2, 0.25) if dt == torch.bfloat16 else (5e-3, 0.08)
+    assert float((l16 - l32).norm() / l32.norm()) < tol_l
+    assert abs(loss16 - loss32) < 2e-2
+    a = torch.cat([t for t in g32 if t is not None])
+    b = torch.cat([t for t in g16 if t is not None])
+    assert torch.isfinite(b).all()
+    assert float((a - b).norm() / a.norm()) < tol_g

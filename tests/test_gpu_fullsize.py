@@ -1,5 +1,8 @@
-"""-m gpu: the hot-path kernels at BASELINE config-2 size (64 clips x 2 persons -> NM = 128, T = 300, V = 25, 64
-channels), checked through size-independent properties instead of the CPU oracle (which would need minutes here):
+"""-m gpu: the hot-path kernels at BASELINE full layer sizes -- config 2/4 (64 clips x 2 persons -> NM = 128, V = 25) at
+all three stages of the network (64 channels / T=300, 128 / T=150, 256 / T=75: different channel-tile counts, chunk
+counts, the multi-chunk dy path of gcn_bwd, workspace-vs-atomic weight-gradient flushes) and the config-5 layer
+(128 clips x 2 persons -> NM = 256, T = 600, 64 channels, float16) -- checked through size-independent properties
+instead of the CPU oracle (which would need minutes here):
 
 * sequences are independent: any slice of the batch computed alone equals the same slice of the full launch, bit for
   bit (exercises the persistent tile walk, the XCD-affine order and the halo / window logic at full depth);
@@ -14,7 +17,12 @@ from gpu_util import dev
 
 pytestmark = pytest.mark.gpu
 
-NM, T, V, C, K = 128, 300, 25, 64, 3
+V, K = 25, 3
+# (NM, T, C, dtypes): the three stages of configs 2/4 in every storage type, the config-5 layer in float16 only
+ALL = (torch.float32, torch.bfloat16, torch.float16)
+SHAPES = [(128, 300, 64, ALL), (128, 150, 128, ALL), (128, 75, 256, ALL), (256, 600, 64, (torch.float16,))]
+CASES = [pytest.param(nm, t, c, dt, id='nm%d_t%d_c%d_%s' % (nm, t, c, str(dt)[6:]))
+         for nm, t, c, dts in SHAPES for dt in dts]
 
 
 @pytest.fixture(scope='module')
@@ -35,8 +43,8 @@ def _randn(*shape, seed, dt, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(dev(), dt)
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
-def test_gcn_forward_slices_and_linearity(ops, graph_A, dt):
+@pytest.mark.parametrize('NM,T,C,dt', CASES)
+def test_gcn_forward_slices_and_linearity(ops, graph_A, NM, T, C, dt):
     d = dev()
     A = graph_A.to(d)
     cap = int((A != 0).sum())
@@ -65,8 +73,8 @@ def test_gcn_forward_slices_and_linearity(ops, graph_A, dt):
         assert ((yl - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
-def test_tconv_slices_full_size(ops, dt):
+@pytest.mark.parametrize('NM,T,C,dt', CASES)
+def test_tconv_slices_full_size(ops, NM, T, C, dt):
     d = dev()
     k = 9
     taps, in_mul = ops.conv_taps_fwd(k, 1)
@@ -89,8 +97,8 @@ def test_tconv_slices_full_size(ops, dt):
     assert ((s[0] - zf.sum((0, 1, 2))).abs().max() / zf.abs().sum((0, 1, 2)).max()) < tol
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
-def test_weight_gradients_are_additive_over_batch_shards(ops, graph_A, dt):
+@pytest.mark.parametrize('NM,T,C,dt', CASES)
+def test_weight_gradients_are_additive_over_batch_shards(ops, graph_A, NM, T, C, dt):
     d = dev()
     A = graph_A.to(d)
     cap = int((A != 0).sum())

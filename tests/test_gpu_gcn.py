@@ -10,7 +10,7 @@ from gpu_util import dev, to_ntvc, to_nctv, diag, OUT
 from oracle import stgcn_ref as R
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3}
 
 
 @pytest.fixture(scope='module')
@@ -19,7 +19,7 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 def test_probe_mfma_lane_maps(ops, dt):
     """A = exact small integers, asymmetric B: pins the A/B/D lane maps of common.hpp."""
     import ctypes
@@ -79,7 +79,7 @@ def _fold(unit, t):
     return {'multi3': Ai + Ai ** 2 + Ai ** 3, 'multi3fix': (Ai + Ai ** 2 + Ai ** 3) / 3, 'only3': Ai ** 3}[unit]
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('ci', range(4))
 @pytest.mark.parametrize('unit', ['tgcn', '3a', 'inc', 'incnew', 'multi3', 'multi3fix', 'only3'])
 def test_gcn_unit_golden(ops, golden, unit, ci, dt):
@@ -106,7 +106,7 @@ def test_gcn_unit_golden(ops, golden, unit, ci, dt):
     assert diag(name + '_dx', to_nctv(dx.float()), g[b + unit + '.dx'], TOL[dt]) < TOL[dt]
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [
     # NM, Cin, Cout, T, V, K, dense
     (3, 64, 64, 23, 25, 3, False), (2, 64, 128, 11, 25, 3, False), (2, 128, 256, 9, 25, 3, False),
@@ -124,8 +124,8 @@ def test_gcn_fwd_random_vs_oracle(ops, shape, dt):
     if not dense:
         A = A * (torch.rand(K, V, V, generator=g) < 0.12)
     add = torch.randn(NM, cout, T, V, generator=g)
-    if dt == torch.bfloat16:   # compare like with like: oracle sees the same rounded inputs
-        x, add = x.bfloat16().float(), add.bfloat16().float()
+    if dt != torch.float32:   # compare like with like: oracle sees the same rounded inputs
+        x, add = x.to(dt).float(), add.to(dt).float()
     ref = R.graph_einsum(torch.nn.functional.conv2d(x, W, bias), A) + add
     d = dev()
     wr = W.view(K, cout, cin).permute(1, 0, 2).contiguous().to(d)
@@ -174,7 +174,7 @@ def test_requires_gpu_no_fallback(ops):
         ops.gcn_forward(x, torch.zeros(1, 25, 25), torch.zeros(8), 8)
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('ci', range(4))
 @pytest.mark.parametrize('unit', ['tgcn', '3a', 'inc'])
 def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
@@ -195,8 +195,8 @@ def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
     cout, cin = W.shape[0] // K, W.shape[1]
     d = dev()
     xin, rin = x, r
-    if dt == torch.bfloat16:
-        xin, rin = x.bfloat16().float(), r.bfloat16().float()
+    if dt != torch.float32:
+        xin, rin = x.to(dt).float(), r.to(dt).float()
     w3 = W.view(K, cout, cin).contiguous().to(d)
     cap = int((Aeff != 0).sum())
     dyg, xg, Ag = to_ntvc(rin).to(d, dt), to_ntvc(xin).to(d, dt), Aeff.detach().to(d).contiguous()
@@ -220,7 +220,7 @@ def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
             assert diag(name + '_dimp%d' % j, imps[j - 1].grad, g[key], tol) < tol
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(3, 64, 64, 23, 25, 3, False), (2, 64, 128, 11, 25, 3, False), (2, 128, 256, 9, 25, 3, False),
                                    (2, 256, 256, 7, 18, 3, True), (1, 3, 64, 300, 25, 3, False), (2, 64, 64, 12, 25, 4, True),
                                    (2, 40, 24, 5, 15, 2, True)])
@@ -229,8 +229,8 @@ def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
     gen = torch.Generator().manual_seed(hash(shape) & 0xFFFF)
     x = torch.randn(NM, cin, T, V, generator=gen)
     dy = torch.randn(NM, cout, T, V, generator=gen)
-    if dt == torch.bfloat16:
-        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    if dt != torch.float32:
+        x, dy = x.to(dt).float(), dy.to(dt).float()
     W = (torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5).requires_grad_(True)
     A = torch.rand(K, V, V, generator=gen)
     if not dense:
@@ -242,8 +242,8 @@ def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
     cap = int((A != 0).sum())
     dyg, xg = to_ntvc(dy).to(d, dt), to_ntvc(x).to(d, dt)
     add = torch.randn(NM, cin, T, V, generator=gen)
-    if dt == torch.bfloat16:
-        add = add.bfloat16().float()
+    if dt != torch.float32:
+        add = add.to(dt).float()
     dW, S = ops.gcn_wgrad(dyg, xg, A.detach().to(d), nnz_cap=cap)
     dx2, dA = ops.gcn_bwd_data(dyg, A.detach().to(d), W.detach().view(K, cout, cin).to(d), x=xg,
                                addend=to_ntvc(add).to(d, dt), nnz_cap=cap)

@@ -7,7 +7,7 @@ from conftest import rel_err
 from gpu_util import dev, to_ntvc, to_nctv, diag
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float32: 3e-5, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 3e-5, torch.bfloat16: 2e-2, torch.float16: 5e-3}
 
 
 @pytest.fixture(scope='module')
@@ -32,19 +32,19 @@ def _mk(case, dt, seed=0):
     b = torch.randn(cout, generator=g) * 0.1
     sc = 0.5 + torch.rand(cin, generator=g)
     sh = torch.randn(cin, generator=g) * 0.3
-    if dt == torch.bfloat16:
-        x = x.bfloat16().float()
+    if dt != torch.float32:
+        x = x.to(dt).float()
     return x, W, b, sc, sh
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES)
 def test_tconv_forward(ops, case, dt):
     NM, cin, cout, T, V, k, s = case
     x, W, b, sc, sh = _mk(case, dt)
     u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    if dt == torch.bfloat16:
-        u = u.bfloat16().float()
+    if dt != torch.float32:
+        u = u.to(dt).float()
     ref = F.conv2d(u, W, b, stride=(s, 1), padding=((k - 1) // 2, 0))
     Tout = ref.shape[2]
     d = dev()
@@ -62,7 +62,7 @@ def test_tconv_forward(ops, case, dt):
     assert rel_err(s_[0], yf.sum((0, 1, 2))) < 1e-5 and rel_err(s_[1], (yf * yf).sum((0, 1, 2))) < 1e-5
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES)
 def test_tconv_data_gradient_with_mask(ops, case, dt):
     """du = conv^T(dz) per output phase, then the ReLU mask of the producer BN recomputed from `aux` and the two
@@ -74,8 +74,8 @@ def test_tconv_data_gradient_with_mask(ops, case, dt):
     dz = torch.randn(NM, cout, Tz, V, generator=g)
     mean = torch.randn(cin, generator=g) * 0.2
     rstd = 0.5 + torch.rand(cin, generator=g)
-    if dt == torch.bfloat16:
-        dz = dz.bfloat16().float()
+    if dt != torch.float32:
+        dz = dz.to(dt).float()
     u = x.clone().requires_grad_(True)
     F.conv2d(u, W, None, stride=(s, 1), padding=((k - 1) // 2, 0)).backward(dz)
     on = (x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) > 0
@@ -105,7 +105,7 @@ def test_tconv_data_gradient_with_mask(ops, case, dt):
     assert rel_err(s_[1], (of * xhat).sum((0, 1, 2))) < 1e-4
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('case', CASES)
 def test_tconv_weight_gradient(ops, case, dt):
     """dW[j][o][i] and dbias against autograd of relu(bn(x)) -> conv2d."""
@@ -113,14 +113,14 @@ def test_tconv_weight_gradient(ops, case, dt):
     x, W, b, sc, sh = _mk(case, dt, seed=2)
     g = torch.Generator().manual_seed(78)
     u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
-    if dt == torch.bfloat16:
-        u = u.bfloat16().float()
+    if dt != torch.float32:
+        u = u.to(dt).float()
     Wp = W.clone().requires_grad_(True)
     bp = b.clone().requires_grad_(True)
     z = F.conv2d(u, Wp, bp, stride=(s, 1), padding=((k - 1) // 2, 0))
     dz = torch.randn(z.shape, generator=g)
-    if dt == torch.bfloat16:
-        dz = dz.bfloat16().float()
+    if dt != torch.float32:
+        dz = dz.to(dt).float()
     z.backward(dz)
     d = dev()
     taps, in_mul = ops.conv_taps_fwd(k, s)
@@ -132,3 +132,22 @@ def test_tconv_weight_gradient(ops, case, dt):
     name = 'tconv_wgrad_%s_%s' % ('x'.join(map(str, case)), str(dt)[6:])
     assert diag(name, dW, ref, tol) < tol
     assert diag(name + '_db', db, bp.grad, tol) < tol
+
+
+@pytest.mark.parametrize('k,s', [(1, 2), (3, 4), (1, 1)])
+def test_conv_data_gradient_with_empty_phases(ops, k, s):
+    """k < stride: some output phases of the data gradient receive no tap.  Those frames must be zero and the OTHER
+    phases must keep what their launches wrote (a whole-tensor zero_() in a later phase wiped them once)."""
+    from istgcn_amd import functional as Fn
+    NM, C, T, V = 2, 16, 13, 25
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(C, C, k, 1, generator=g) * (C * k) ** -0.5
+    x = torch.randn(NM, C, T, V, generator=g).requires_grad_(True)
+    z = F.conv2d(x, W, None, stride=(s, 1), padding=((k - 1) // 2, 0))
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    d = dev()
+    taps = W[:, :, :, 0].permute(2, 0, 1).contiguous().to(d)       # [k][Cout][Cin]
+    dx = Fn._conv_bwd_data(to_ntvc(dz).to(d), taps, k, s, T, C, V)
+    assert diag('conv_bwd_empty_phase_k%d_s%d' % (k, s), to_nctv(dx), x.grad, 3e-5) < 3e-5
+    assert float(x.grad.abs().max()) > 0
