@@ -88,6 +88,10 @@ int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, f
  * mode 0: epi = + bias[o];            stats += sum(out), sum(out^2)
  * mode 1: epi = * [aux*maux[0]+maux[1] > 0] (ReLU mask of the producer BatchNorm, aux = its input, same shape as out);
  *                                     stats += sum(out), sum(out * (aux - maux[2]) * maux[3])   (BatchNorm backward)
+ * mode 2: epi = relu( . + bias[o] + res' ), res' = aux*maux[0] + maux[1] (aux NULL: 0; maux NULL: res' = aux); no stats.
+ *         Inference tail of the block, net/st_gcnold.py:174-175,201-203 with tcn.3's (eval-mode, hence affine) BatchNorm
+ *         folded into Wf / bias by the host and Dropout the identity: an eval-mode st_gcn block is istgcn_gcn_fwd +
+ *         this launch (+ the strided 1x1 residual conv where the block has one).
  * Wp: fragment-ordered weights, element (((((ch*ntaps + j)*NKG + kg)*MTtot + mt)*2 + h)*32 + r)*EPL + e holds
  *   Wf[j][32*mt + r][ch*CC + kg*2*EPL + h*EPL + e]; CC, nch, MTtot, EPL from istgcn_tconv_geometry, NKG = CC/(2*EPL). */
 int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int* CC,
@@ -177,6 +181,31 @@ int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const
                          long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
                    unsigned long long seed, int dtype, void* stream);
+
+/* Input stage: the feeder's augmentation (feeder/tools.py:31-101) and the data_bn prologue (net/st_gcnold.py:74-80) on
+ * the GPU.  raw [N][C][Traw][V][M] fp32 is the clip batch as the reference's DataLoader delivers it;
+ *   shift [N] int or NULL: source frame of output frame t is t + shift[n], frames outside [0, Traw) are zero
+ *         (auto_pading tools.py:31-41: shift 0, T > Traw; random_choose :44-57: crop shift = +begin, pad shift = -begin);
+ *   move  [N][T][6] fp64 or NULL: per (clip, frame) affine (m00, m01, tx, m10, m11, ty) applied to channels 0,1 AFTER
+ *         the shift: x' = m00*x + m01*y + tx, y' = m10*x + m11*y + ty, in double, rounded once to fp32
+ *         (random_move tools.py:60-101; the host draws the node values with the reference's generator calls and
+ *         interpolates them per frame, see ist-gcn_amd/feeder_gpu.py).
+ * istgcn_feeder_augment: out [N][C][T][V][M] fp32 = the augmented clips (what the reference's feeder would have yielded).
+ * istgcn_input_stats:    stats [rep][2][V*C] fp64 += per BatchNorm1d channel (v*C + c) sum / sum of squares of the
+ *                        augmented clips over (n, m, t)   (train-mode data_bn; finish with istgcn_bn_finalize, C' = V*C).
+ * istgcn_input_apply:    out [N*M][T][V][C] (dtype) = x*coef[0][v*C+c] + coef[1][v*C+c]: BatchNorm affine + the two
+ *                        permutes of st_gcnold.py:75-80 in one pass.
+ * istgcn_input_bwd:      stats += (sum dy, sum dy*xhat) per channel from dout [N*M][T][V][C] and coef [4][V*C]
+ *                        (scale, shift, mean, rstd); finish with istgcn_bn_bwd_coef -> d(data_bn.weight), d(data_bn.bias).
+ * C*V*M <= 1024. */
+int istgcn_feeder_augment(const float* raw, const int* shift, const double* move, float* out, int N, int C, int Traw,
+                          int T, int V, int M, void* stream);
+int istgcn_input_stats(const float* raw, const int* shift, const double* move, double* stats, int stats_rep, int N, int C,
+                       int Traw, int T, int V, int M, void* stream);
+int istgcn_input_apply(const float* raw, const int* shift, const double* move, const float* coef, void* out, int N, int C,
+                       int Traw, int T, int V, int M, int dtype, void* stream);
+int istgcn_input_bwd(const float* raw, const int* shift, const double* move, const void* dout, const float* coef,
+                     double* stats, int stats_rep, int N, int C, int Traw, int T, int V, int M, int dtype, void* stream);
 
 /* SGD with momentum / Nesterov / weight decay over ONE flat fp32 range = torch.optim.SGD as configured at
  * processor/recognition.py:154-159 and stepped at :289, for all live parameters of the model in one launch:

@@ -10,7 +10,9 @@
 //          is ONE 15-tap convolution whose taps the host pre-sums (linear in the weights).
 //   epi  = + bias, and per-channel sum / sum-of-squares for the train-mode BatchNorm2d that follows
 //          (st_gcnold.py:174), or -- for the data gradient -- the ReLU mask of the producer's BatchNorm+ReLU
-//          recomputed from `aux`, with the two BatchNorm-backward reductions.
+//          recomputed from `aux`, with the two BatchNorm-backward reductions; or -- inference, every BatchNorm
+//          folded into the weights by the host -- the block's tail relu(conv + residual) (st_gcnold.py:201-203)
+//          so that an eval-mode st_gcn block is two launches.
 // Forward: in_mul = stride, tap_off[j] = j - pad, out_mul = 1.  Data gradient: one launch per output phase
 // (t mod stride) with the taps that hit that phase, in_mul = 1, out_mul = stride, out_off = phase.
 //
@@ -244,6 +246,17 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
         float s1[EPL], s2[EPL], msc[EPL], msh[EPL], mmu[EPL], mrs[EPL];
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; msc[jj] = 0.f; msh[jj] = 0.f; mmu[jj] = 0.f; mrs[jj] = 0.f; }
+        if constexpr (MODE == 2) {
+          // residual affine (the folded BatchNorm of the strided 1x1 residual conv) or identity
+#pragma unroll
+          for (int jj = 0; jj < EPL; ++jj) msc[jj] = 1.f;
+          if (P.maux && col_live) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+              if (cg + jj < P.Cout) { msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj]; }
+            }
+          }
+        }
         if constexpr (MODE == 1) {
           // producer's BatchNorm constants of this thread's channel vector: whole 16-byte loads, no per-element branches
           if (col_live) {
@@ -283,11 +296,15 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
               if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
               else g[u] = ((size_t)(n * P.Tout + (m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
               sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
-              if constexpr (MODE == 1) {
-                if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
-                else {
+              if constexpr (MODE >= 1) {
+                if (MODE == 1 || auxg) {
+                  if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
+                  else {
 #pragma unroll
-                  for (int jj = 0; jj < EPL; ++jj) av[u][jj] = (cg + jj < P.Cout) ? auxg[g[u] + jj] : E::from_f(0.f);
+                    for (int jj = 0; jj < EPL; ++jj) av[u][jj] = (cg + jj < P.Cout) ? auxg[g[u] + jj] : E::from_f(0.f);
+                  }
+                } else {
+                  zero_frag<T>(av[u]);
                 }
               }
             }
@@ -304,6 +321,14 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
                     const float fv = E::to_f(o);
                     s1[jj] += fv;
                     s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
+                  }
+                }
+              } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) {
+                  if (VEC || cg + jj < P.Cout) {
+                    const float r = auxg ? E::to_f(av[u][jj]) * msc[jj] + msh[jj] : 0.f;
+                    sv[u][jj] = E::from_f(fmaxf(E::to_f(sv[u][jj]) + r, 0.f));
                   }
                 }
               } else {
@@ -401,6 +426,7 @@ int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
     ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS * WM), lds, stream, P);                                  \
   } while (0)
   if (P.mode == 1) { if (vec) GO(true, 1); else GO(false, 1); }
+  else if (P.mode == 2) { if (vec) GO(true, 2); else GO(false, 2); }
   else { if (vec) GO(true, 0); else GO(false, 0); }
 #undef GO
   ISTGCN_CHECK_LAUNCH();
@@ -481,7 +507,8 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
                             void* stream) {
   if (!in || !Wp || !out || !tap_off) return ISTGCN_EINVAL;
   if (ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1 || out_mul < 1) return ISTGCN_EINVAL;
-  if (NM < 0 || Mlog < 0 || out_off < 0 || (mode != 0 && mode != 1)) return ISTGCN_EINVAL;
+  if (NM < 0 || Mlog < 0 || out_off < 0 || mode < 0 || mode > 2) return ISTGCN_EINVAL;
+  if (mode == 2 && stats) return ISTGCN_EINVAL;
   if (mode == 1 && (!aux || !maux)) return ISTGCN_EINVAL;
   if (Mlog > 0 && (Mlog - 1) * out_mul + out_off >= Tout) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;

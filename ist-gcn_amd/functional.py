@@ -311,3 +311,108 @@ class STGCNBlockFn(torch.autograd.Function):
             ops.gcn_forward(dr, eye, wrt, cin, addend=dx, out=dx, Tout=T, out_t_stride=s, nnz_cap=V)
         return (None, None, None, None, dx, dA, (S if ctx.has_b else None), dWg, dg1, db1, dWt, dbt, dg2, db2,
                 dWr, dbr, dgr, dbetar, dWs, dbs, dWe, dbe)
+
+
+# --------------------------------------------------------------------------------------------------
+# input stage: (feeder augmentation +) data_bn + layout change
+# --------------------------------------------------------------------------------------------------
+class InputStageFn(torch.autograd.Function):
+    """x (N,C,T,V,M) fp32 -> data_bn (BatchNorm1d over the V*C channels v*C+c, net/st_gcnold.py:74-80) -> NTVC activation
+    [N*M, T', V, C] in `dtype`, optionally through the feeder's augmentation (feeder/tools.py:31-101: frame shift + zero
+    padding, per-frame affine of channels 0,1).  Two launches in training (batch sums, apply), one in eval; the backward
+    is one reduction for d(data_bn.weight), d(data_bn.bias) -- the clip itself needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, dtype, shift, move, T):
+        x = x.contiguous()
+        N, C, Traw, V, M = x.shape
+        T = Traw if T is None else T
+        st = None
+        if training:
+            st = ops.stats_scratch(3, V * C, x.device)
+            ops.input_stats(x, st, shift, move, T)
+        coef = ops.bn_finalize(st, N * M * T, gamma, beta, running_mean, running_var, momentum, eps, training, clear=True)
+        y = ops.input_apply(x, coef, dtype, shift, move, T)
+        ctx.save_for_backward(x, gamma, coef, shift, move)
+        ctx.training, ctx.T = training, T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, coef, shift, move = ctx.saved_tensors
+        N, C, Traw, V, M = x.shape
+        dgamma = dbeta = None
+        if gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            st = ops.stats_scratch(3, V * C, x.device)
+            ops.input_bwd(x, dy.contiguous(), coef, st, shift, move, ctx.T)
+            _, dgamma, dbeta = ops.bn_bwd_coef(st, N * M * ctx.T, gamma, coef, ctx.training, clear=True)
+        return (None, dgamma, dbeta) + (None,) * 9
+
+
+# --------------------------------------------------------------------------------------------------
+# inference path (SURVEY 8 f4): eval-mode BatchNorm is affine -> folded into the neighbouring weights, nothing saved
+# --------------------------------------------------------------------------------------------------
+def _bn_affine(bn):
+    """(scale, shift) of an eval-mode BatchNorm from its running statistics: y = x*scale + shift."""
+    gamma, beta, rm, rv, eps = bn
+    scale = (gamma if gamma is not None else 1.0) * torch.rsqrt(rv + eps)
+    shift = (beta if beta is not None else 0.0) - rm * scale
+    return scale, shift
+
+
+def build_infer_plan(cfg, dt, A_eff, bterm, Wg3, bn1, Wt, bt, bn2, Wr, br, bnr, Ws, bs, We, be):
+    """Constants of one st_gcn block for eval-mode inference (net/st_gcnold.py:197-203 under model.eval(), as
+    processor/recognition.py:347-348 and the demos processor/demo_offline.py:68-98 run it):
+      tcn.0 (BatchNorm after the graph conv)   -> the temporal conv's `pre` affine (+ReLU), as in training
+      tcn.3 (BatchNorm after the temporal conv) -> folded into the temporal conv's weights and bias
+      residual BatchNorm                        -> folded into the strided 1x1 residual conv's weights and bias
+      Dropout                                   -> identity
+    so the block is graph conv + ONE temporal-conv launch whose epilogue adds the residual and applies the ReLU.
+    bnX = (gamma, beta, running_mean, running_var, eps).  Returns a dict of packed weights (rebuilt only when a
+    parameter changes: net/_model.py caches it on the parameters' version counters)."""
+    V, s, cout, cin = cfg.V, cfg.stride, cfg.cout, cfg.cin
+    with torch.no_grad():
+        s1, h1 = _bn_affine(bn1)
+        s2, h2 = _bn_affine(bn2)
+        plan = {'A': A_eff.detach().contiguous(), 'bterm': None if bterm is None else bterm.detach().contiguous(),
+                'wg': ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt), 'pre1': torch.stack([s1, h1]).contiguous()}
+        taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
+        zero = torch.zeros((), dtype=torch.float32, device=s2.device)
+        if cfg.tcn == 'conv':
+            plan['wt'] = ops.pack_tconv_weight((Wt * s2.view(1, -1, 1)).contiguous(), V, taps, in_mul, dt)
+            plan['bt'] = ((bt if bt is not None else zero) * s2 + h2).contiguous()
+        else:
+            w = cfg.width
+            plan['ws'] = ops.pack_tconv_weight(Ws.view(1, w, cout), V, [0], 1, dt)
+            plan['bs'] = bs
+            plan['wt'] = ops.pack_tconv_weight(Wt.contiguous(), V, taps, in_mul, dt)
+            plan['bt'] = bt
+            plan['we'] = ops.pack_tconv_weight((We * s2.view(-1, 1)).contiguous().view(1, cout, w), V, [0], 1, dt)
+            plan['be'] = ((be if be is not None else zero) * s2 + h2).contiguous()
+        if cfg.residual == 'conv':
+            sr, hr = _bn_affine(bnr)
+            plan['wr'] = ops.pack_tconv_weight((Wr * sr.view(-1, 1)).contiguous().view(1, cout, cin), V, [0], s, dt)
+            plan['br'] = ((br if br is not None else zero) * sr + hr).contiguous()
+    return plan
+
+
+def run_infer_plan(cfg, plan, x):
+    """x [NM,T,V,cin] -> block output [NM,T/stride,V,cout]; 2 launches (3 with a residual conv, 4 with the bottleneck)."""
+    NM, T, V, _ = x.shape
+    cout, s = cfg.cout, cfg.stride
+    Tz = (T - 1) // s + 1
+    with torch.no_grad():
+        g = ops.gcn_forward(x, plan['A'], plan['wg'], cout, bterm=plan['bterm'], nnz_cap=cfg.nnz_cap)
+        res = None
+        if cfg.residual == 'id':
+            res = x
+        elif cfg.residual == 'conv':
+            res = ops.tconv(x, plan['wr'], cout, [0], bias=plan['br'], Tout=Tz, Mlog=Tz, in_mul=s)
+        taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
+        if cfg.tcn == 'conv':
+            return ops.tconv(g, plan['wt'], cout, taps, bias=plan['bt'], pre=plan['pre1'], pre_relu=True, aux=res,
+                             mode=2, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+        w = cfg.width
+        q = ops.tconv(g, plan['ws'], w, [0], bias=plan['bs'], pre=plan['pre1'], pre_relu=True, Tout=T, Mlog=T)
+        yb = ops.tconv(q, plan['wt'], w, taps, bias=plan['bt'], Tout=Tz, Mlog=Tz, in_mul=in_mul)
+        return ops.tconv(yb, plan['we'], cout, [0], bias=plan['be'], aux=res, mode=2, Tout=Tz, Mlog=Tz)

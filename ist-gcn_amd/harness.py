@@ -169,3 +169,76 @@ def weights_init(m):
     elif classname.find('BatchNorm') != -1:
         m.weight.data.normal_(1.0, 0.02)
         m.bias.data.fill_(0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# checkpoints and evaluation: counterparts of torchlight/torchlight/io.py:57-90,101-107 and of
+# processor/recognition.py:178-183,312-385, so accuracy parity can be shown with upstream `.pt` files both ways
+# ---------------------------------------------------------------------------------------------------------------
+def load_weights(model, weights, ignore_weights=None, log=None):
+    """torchlight IO.load_weights (io.py:57-90): `weights` is a path to a torch-saved state dict or the dict itself;
+    a leading `module.` (nn.DataParallel checkpoints) is stripped from every key, keys starting with any of
+    `ignore_weights` are dropped, and when the strict load fails the missing entries keep the model's own values."""
+    from collections import OrderedDict
+    if ignore_weights is None:
+        ignore_weights = []
+    if isinstance(ignore_weights, str):
+        ignore_weights = [ignore_weights]
+    if not isinstance(weights, dict):
+        weights = torch.load(weights, map_location='cpu')
+    weights = OrderedDict([[k.split('module.')[-1], v.cpu()] for k, v in weights.items()])
+    for i in ignore_weights:
+        for n in [w for w in weights if w.find(i) == 0]:
+            weights.pop(n)
+            if log:
+                log('Filter [{}] remove weights [{}].'.format(i, n))
+    try:
+        model.load_state_dict(weights)
+    except (KeyError, RuntimeError):
+        state = model.state_dict()
+        if log:
+            for d in set(state.keys()).difference(set(weights.keys())):
+                log('Can not find weights [{}].'.format(d))
+        state.update(weights)
+        model.load_state_dict(state)
+    return model
+
+
+def save_model(model, path):
+    """torchlight IO.save_model (io.py:101-107): CPU state dict with every `module.` removed from the keys -- a file the
+    reference's own load_weights (and therefore its processors and demos) reads back."""
+    from collections import OrderedDict
+    weights = OrderedDict([[''.join(k.split('module.')), v.cpu()] for k, v in model.state_dict().items()])
+    torch.save(weights, path)
+    return path
+
+
+def topk_accuracy(result, label, k):
+    """recognition.py:178-183 (argsort, hit if the label is among the k largest scores)."""
+    rank = np.asarray(result).argsort()
+    hit = [l in rank[i, -k:] for i, l in enumerate(np.asarray(label))]
+    return sum(hit) * 1.0 / len(hit)
+
+
+@torch.no_grad()
+def evaluate(model, batches, device=None, show_topk=(1, 5)):
+    """recognition.py:312-385 without the plotting: eval mode, no_grad forward per batch, mean CrossEntropy loss over
+    batches, top-k accuracy and the confusion matrix (rows = true class, columns = argmax) over all samples.
+    `batches` yields (data [N,C,T,V,M], label [N]).  Runs the Models' inference path (folded BatchNorms)."""
+    model.eval()
+    results, labels, losses = [], [], []
+    for data, label in batches:
+        data = data.float()
+        label = label.long()
+        if device is not None:
+            data, label = data.to(device, non_blocking=True), label.to(device)
+        out = model(data)
+        losses.append(float(F.cross_entropy(out, label)))
+        results.append(out.float().cpu().numpy())
+        labels.append(label.cpu().numpy())
+    result, lab = np.concatenate(results), np.concatenate(labels)
+    nc = result.shape[1]
+    conf = np.zeros((nc, nc), dtype=np.int64)
+    np.add.at(conf, (lab, result.argmax(1)), 1)
+    return {'mean_loss': float(np.mean(losses)), 'topk': {k: topk_accuracy(result, lab, k) for k in show_topk},
+            'confusion': conf, 'result': result, 'label': lab}

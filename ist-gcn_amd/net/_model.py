@@ -149,10 +149,50 @@ class STGCNBlock(nn.Module):
             bns = (self.tcn_start[0], self.tcn_end[0])
         return bns + ((self.residual[1],) if self.res_mode == 'conv' else ())
 
+    # ---- inference entry (eval mode, no autograd): folded BatchNorms, cached packed weights --------------
+    def infer(self, x, fold_fn, key_extra=(), mst=None, nnz_cap=None):
+        """x NTVC -> block output, eval-mode semantics, nothing saved for a backward pass.  `fold_fn()` -> (A_eff, bterm)
+        is only called when the cached plan is stale: the plan (folded + fragment-packed weights, Fn.build_infer_plan)
+        is keyed on the version counters of every tensor it was built from, so load_state_dict / an optimiser step /
+        `.to()` rebuild it and a steady-state eval pass launches only the block's 2-4 kernels."""
+        tensors = [t for t in list(self.parameters()) + list(self.buffers()) if t is not None] + list(key_extra)
+        if mst is not None:
+            tensors.append(mst)
+        key = (x.dtype, x.device, nnz_cap) + tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = self.__dict__.get('_infer_cache')
+        if cache is None or cache[0] != key:
+            A_eff, bterm = fold_fn()
+            cfg, args = self._gather(x, A_eff, mst, nnz_cap, bterm, None)
+            (A_e, bt_, Wg3, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar, Ws, bs, We, be), bns = args
+            bn = lambda m: (m.weight, m.bias, m.running_mean, m.running_var, m.eps)  # noqa: E731
+            plan = Fn.build_infer_plan(cfg, x.dtype, A_e, bt_, Wg3, bn(bns[0]), Wt, bt, bn(bns[1]), Wr, br,
+                                       bn(bns[2]) if len(bns) > 2 else None, Ws, bs, We, be)
+            cache = (key, cfg, plan)
+            self.__dict__['_infer_cache'] = cache
+        return Fn.run_infer_plan(cache[1], cache[2], x)
+
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
     def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True):
         """pattern: [K,V,V] fp32 sparsity pattern of the adjacency gradient (None = dense); seed_base: the Model's
         per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself."""
+        cfg, ((A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar, Ws, bs, We, be), bns) = \
+            self._gather(x, A_eff, mst, nnz_cap, bterm, pattern)
+        bn1, bn2 = bns[0], bns[1]
+        bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
+        if len(bns) > 2:
+            bufs['bnr'] = (bns[2].running_mean, bns[2].running_var)
+        training = self.training
+        if training and bump:
+            torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms()], 1)
+        seed = 0
+        if training and self.p_drop > 0:
+            seed = mix_seed(draw_seed() if seed_base is None else seed_base, self.block_index, x.device)
+        return Fn.STGCNBlockFn.apply(cfg, training, seed, bufs, x, A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2,
+                                     Wr, br, gr, betar, Ws, bs, We, be)
+
+    def _gather(self, x, A_eff, mst, nnz_cap, bterm, pattern):
+        """-> (BlockCfg, ((A_eff, bterm, Wg3, gamma1, beta1, Wt, bt, gamma2, beta2, Wr, br, gamma_r, beta_r, Ws, bs, We, be),
+        (bn1, bn2[, bn_residual]))): the block's parameters as the (views of) tensors the kernels take."""
         if not x.is_cuda:
             raise RuntimeError('istgcn_amd: the st_gcn block runs on MI355X only (tensor on %s); no CPU fallback'
                                % x.device)
@@ -182,26 +222,20 @@ class STGCNBlock(nn.Module):
             else:
                 Ws = bs = We = be = None
                 mode = 'conv'
-        bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
+        bns = (bn1, bn2)
         Wr = br = gr = betar = None
         mom, eps = bn1.momentum, bn1.eps
         if self.res_mode == 'conv':
             rc, rbn = self.residual[0], self.residual[1]
             Wr, br, gr, betar = rc.weight.view(c, self.cin), rc.bias, rbn.weight, rbn.bias
-            bufs['bnr'] = (rbn.running_mean, rbn.running_var)
+            bns = (bn1, bn2, rbn)
         if nnz_cap is None:
             nnz_cap = self.K * V * V
         cfg = Fn.BlockCfg(self.cin, c, self.K, V, self.stride, self.res_mode, mode, ks, self.p_drop, int(nnz_cap),
                           width=getattr(self, 'width', None), momentum=mom if mom is not None else 0.1, eps=eps,
                           pattern=pattern)
-        training = self.training
-        if training and bump:
-            torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms()], 1)
-        seed = 0
-        if training and self.p_drop > 0:
-            seed = mix_seed(draw_seed() if seed_base is None else seed_base, self.block_index, x.device)
-        return Fn.STGCNBlockFn.apply(cfg, training, seed, bufs, x, A_eff, bterm, Wg3, bn1.weight, bn1.bias, Wt, bt,
-                                     bn2.weight, bn2.bias, Wr, br, gr, betar, Ws, bs, We, be)
+        return cfg, ((A_eff, bterm, Wg3, bn1.weight, bn1.bias, Wt, bt, bn2.weight, bn2.bias, Wr, br, gr, betar,
+                      Ws, bs, We, be), bns)
 
     # ---- reference-signature forward on (N,C,T,V) tensors ------------------------------------------
     def forward(self, x, A, *rest):
@@ -242,6 +276,13 @@ class STGCNModel(nn.Module):
         var = VARIANTS[self.KIND]
         self.gcn_kind, self.tcn_kind = var['gcn'], var['tcn']
         self.act_dtype = _DTYPES[kwargs.pop('compute_dtype', 'float32')]
+        # optional GPU feeder stage: dict(window_size=, random_choose=, random_move=) = the options of
+        # feeder.Feeder (feeder/feeder.py:33-45), applied to the raw clips inside the data_bn prologue while training
+        ga = kwargs.pop('gpu_augment', None)
+        self.gpu_augment = None
+        if ga:
+            from ..feeder_gpu import GpuAugment
+            self.gpu_augment = GpuAugment(**ga)
         self.graph = Graph(**graph_args)
         if self.gcn_kind == 'incep':                                    # st_gcn_msgcn.py:36-39
             self.register_buffer('A2', torch.tensor(self.graph.A2, dtype=torch.float32, requires_grad=False))
@@ -324,24 +365,46 @@ class STGCNModel(nn.Module):
             return Fn.FoldFn.apply(self._fold_B(imps[0].device), conv.bias, blk.cout, *imps)
         return self._a_eff(i), _UNSET
 
+    def _folded_bias(self, i, blk):
+        """(A_eff, bterm) with the bias term resolved (for the inference plan)."""
+        A_eff, bterm = self._folded(i, blk)
+        if bterm is _UNSET:
+            conv = blk.gcn.the_conv()
+            bterm = Fn.fold_bias_term(conv.bias, A_eff, blk.cout) if conv.bias is not None else None
+        return A_eff, bterm
+
     def _trunk(self, x):
         if not x.is_cuda:
             raise RuntimeError('istgcn_amd.net: Model.forward needs the input on an MI355X (got %s); the HIP path has '
                                'no CPU fallback' % x.device)
         N, C, T, V, M = x.size()
-        # data_bn (st_gcnold.py:74-80): (N,C,T,V,M) -> BatchNorm1d over V*C channels -> NTVC
-        x = x.permute(0, 4, 3, 1, 2).contiguous().view(N * M, V * C, T)
-        x = self.data_bn(x)
-        x = x.view(N * M, V, C, T).permute(0, 3, 1, 2).contiguous().to(self.act_dtype)
+        # input stage (st_gcnold.py:74-80): (N,C,T,V,M) -> BatchNorm1d over the V*C channels -> NTVC activation, with the
+        # feeder's augmentation (feeder/tools.py:31-101) folded in when configured: csrc/input.hip, 2 launches
+        bn = self.data_bn
+        shift = move = Tw = None
+        if self.gpu_augment is not None and self.training:
+            shift, move, Tw = self.gpu_augment.draw(N, T)
+            shift = None if shift is None else shift.to(x.device, non_blocking=True)
+            move = None if move is None else move.to(x.device, non_blocking=True)
+        x = Fn.InputStageFn.apply(x.float(), bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                  bn.momentum if bn.momentum is not None else 0.1, bn.eps, self.act_dtype, shift, move, Tw)
         cap = self._cap()
         pat = self._pattern(x.device)
         seed_base = None
         if self.training:
             seed_base = draw_seed()
-            # every BatchNorm of the trunk advances its counter: ONE multi-tensor launch instead of 2-3 per block
-            torch._foreach_add_([bn.num_batches_tracked for blk in self.st_gcn_networks for bn in blk.batchnorms()], 1)
+            # every BatchNorm of the model advances its counter: ONE multi-tensor launch instead of 2-3 per block
+            torch._foreach_add_([bn.num_batches_tracked] + [b.num_batches_tracked for blk in self.st_gcn_networks
+                                                            for b in blk.batchnorms()], 1)
+        infer = (not self.training) and (not torch.is_grad_enabled())
         for i, blk in enumerate(self.st_gcn_networks):
             mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
+            if infer:                      # SURVEY 8 f4: folded BatchNorms, cached plans, 2-4 launches per block
+                imps = [getattr(self, n)[i] for n in ('edge_importance', 'edge_importance2', 'edge_importance3')
+                        if hasattr(self, n)]
+                x = blk.infer(x, lambda i=i, blk=blk: self._folded_bias(i, blk),
+                              key_extra=[t for t in imps if isinstance(t, torch.Tensor)] + [self.A], mst=mst, nnz_cap=cap)
+                continue
             A_eff, bterm = self._folded(i, blk)
             x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False)
         return x
@@ -350,8 +413,9 @@ class STGCNModel(nn.Module):
         N, M = x.size(0), x.size(4)
         y = self._trunk(x)                                           # (NM, T', V, 256)
         feat = y.float().mean(dim=(1, 2)).view(N, M, -1).mean(dim=1)   # global pooling, then persons
-        out = F.conv2d(feat.view(N, -1, 1, 1), self.fcn.weight, self.fcn.bias)
-        return out.view(N, -1)
+        # fcn is a 1x1 Conv2d on a 1x1 map (st_gcnold.py:92-94) = a matrix product (a plain GEMM instead of a convolution
+        # library's fallback kernels)
+        return F.linear(feat, self.fcn.weight.view(self.fcn.weight.shape[0], -1), self.fcn.bias)
 
     def extract_feature(self, x):
         N, M = x.size(0), x.size(4)

@@ -220,6 +220,10 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
     if mode == 1:
         assert aux is not None and aux.shape == out.shape and aux.dtype == x.dtype
         assert maux is not None and maux.shape == (4, cout) and maux.dtype == torch.float32
+    if mode == 2:
+        assert stats is None
+        assert aux is None or (aux.shape == out.shape and aux.dtype == x.dtype)
+        assert maux is None or (maux.shape[0] >= 2 and maux.shape[1] == cout and maux.dtype == torch.float32)
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.shape[-2:] == (2, cout)
     dv = _check_dev(x, wp, bias, pre, aux, maux, out, stats)
@@ -227,7 +231,7 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
           _ptr(out), _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, Cin, cout,
           len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), grid_cap, _stream(x),
           work=(2.0 * NM * Mlog * V * cout * Cin * len(tap_off),
-                float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if mode == 1 else 1)) * _esz(x)), dev=dv)
+                float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if (mode == 1 or aux is not None) else 1)) * _esz(x)), dev=dv)
     return out
 
 
@@ -561,3 +565,54 @@ def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, 
     _call('istgcn_sgd_step', _ptr(params), _ptr(grads), _ptr(momentum_buf), ctypes.c_longlong(n), ctypes.c_float(lr),
           ctypes.c_float(momentum), ctypes.c_float(weight_decay), int(bool(nesterov)), ctypes.c_float(grad_scale),
           _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)
+
+
+# ----------------------------------------------------------------------------------------------
+# input stage (input.hip): feeder augmentation + data_bn + layout change
+# ----------------------------------------------------------------------------------------------
+def _aug_args(raw, shift, move, T):
+    N, C, Traw, V, M = raw.shape
+    if T is None:
+        T = Traw
+    assert raw.dtype == torch.float32
+    if shift is not None:
+        assert shift.shape == (N,) and shift.dtype == torch.int32
+    if move is not None:
+        assert move.shape == (N, T, 6) and move.dtype == torch.float64
+    return N, C, Traw, V, M, T
+
+
+def feeder_augment(raw, shift=None, move=None, T=None):
+    """istgcn_feeder_augment -> (N, C, T, V, M) fp32 clips as feeder/tools.py would have produced them."""
+    N, C, Traw, V, M, T = _aug_args(raw, shift, move, T)
+    out = torch.empty((N, C, T, V, M), dtype=torch.float32, device=raw.device)
+    dv = _check_dev(raw, shift, move, out)
+    _call('istgcn_feeder_augment', _ptr(raw), _ptr(shift), _ptr(move), _ptr(out), N, C, Traw, T, V, M, _stream(raw), dev=dv)
+    return out
+
+
+def input_stats(raw, stats, shift=None, move=None, T=None):
+    N, C, Traw, V, M, T = _aug_args(raw, shift, move, T)
+    assert stats.dtype == torch.float64 and stats.shape[-2:] == (2, V * C)
+    dv = _check_dev(raw, shift, move, stats)
+    _call('istgcn_input_stats', _ptr(raw), _ptr(shift), _ptr(move), _ptr(stats), stats.shape[0], N, C, Traw, T, V, M,
+          _stream(raw), dev=dv)
+
+
+def input_apply(raw, coef, dtype, shift=None, move=None, T=None):
+    """-> [N*M, T, V, C] activation (dtype): BatchNorm1d affine coef [>=2][V*C] + the permutes of st_gcnold.py:75-80."""
+    N, C, Traw, V, M, T = _aug_args(raw, shift, move, T)
+    assert coef.dtype == torch.float32 and coef.shape[1] == V * C and coef.shape[0] >= 2
+    out = torch.empty((N * M, T, V, C), dtype=dtype, device=raw.device)
+    dv = _check_dev(raw, shift, move, coef, out)
+    _call('istgcn_input_apply', _ptr(raw), _ptr(shift), _ptr(move), _ptr(coef), _ptr(out), N, C, Traw, T, V, M,
+          _DT[dtype], _stream(raw), dev=dv)
+    return out
+
+
+def input_bwd(raw, dout, coef, stats, shift=None, move=None, T=None):
+    N, C, Traw, V, M, T = _aug_args(raw, shift, move, T)
+    assert dout.shape == (N * M, T, V, C) and coef.shape == (4, V * C)
+    dv = _check_dev(raw, shift, move, dout, coef, stats)
+    _call('istgcn_input_bwd', _ptr(raw), _ptr(shift), _ptr(move), _ptr(dout), _ptr(coef), _ptr(stats), stats.shape[0],
+          N, C, Traw, T, V, M, dtype_code(dout), _stream(raw), dev=dv)

@@ -281,8 +281,78 @@ def g45_models():
         json.dump(manifest, f, indent=0, sort_keys=True)
 
 
+# ----------------------------------------------------------------------------- G6 inference / extract_feature
+def g6_extract_feature():
+    """`extract_feature` (net/st_gcnold.py:98-120, caller processor/demo_offline.py:68-98) and the eval
+    logits of the same clip.  Only st_gcnold: the msgcn / mstcn variants' extract_feature is broken upstream
+    (st_gcn_msgcn.py:145-146 calls the block with too few arguments)."""
+    import importlib
+    tag = 'st_gcnold'
+    modname, gargs, nc, _ = MODELS[tag]
+    m = importlib.import_module(modname).Model(3, nc, gargs, True, dropout=0)
+    sd = det_fill_(m.state_dict())
+    m.load_state_dict(sd)
+    m.eval()
+    x = det_tensor('g6.x.' + tag, (1, 3, 32, 25, 2))
+    with torch.no_grad():
+        output, feature = m.extract_feature(x)
+        logits = m(x)
+    save('infer_g6_%s.npz' % tag, shape=np.asarray(x.shape), output=output, feature=feature, logits=logits)
+
+
+# ----------------------------------------------------------------------------- G7 feeder augmentation
+def g7_feeder_tools():
+    """feeder/tools.py:31-101 (`auto_pading`, `random_choose`, `random_move`) on seeded clips.  The random
+    draws are captured as explicit parameters by replaying the SAME generator calls the functions make, in the same
+    order (random.randint for the offsets; random.choice then four np.random.choice for random_move), after re-seeding."""
+    import random
+    from feeder import tools
+    out = {}
+    C, T, V, M = 3, 40, 25, 2
+    for case in range(4):
+        d = det_tensor('g7.x.%d' % case, (C, T, V, M)).numpy().astype(np.float32)
+        if case == 3:
+            d[:, 30:] = 0                                        # trailing empty frames, as real NTU clips have
+        out['c%d.x' % case] = d
+        # auto_pading, begin = 0 (feeder.py:83-84: window_size > 0 without random_choose)
+        out['c%d.pad64' % case] = tools.auto_pading(d.copy(), 64)
+        # random_choose: crop (T > size) and random pad (T < size)
+        for size in (24, 64):
+            random.seed(100 + case)
+            out['c%d.choose%d' % (case, size)] = tools.random_choose(d.copy(), size)
+            random.seed(100 + case)
+            out['c%d.choose%d.begin' % (case, size)] = np.asarray(
+                random.randint(0, T - size) if T > size else random.randint(0, size - T))
+        # random_move (default candidates, move_time 1)
+        random.seed(200 + case)
+        np.random.seed(200 + case)
+        out['c%d.move' % case] = tools.random_move(d.copy())
+        random.seed(200 + case)
+        np.random.seed(200 + case)
+        random.choice([1])
+        A = np.random.choice([-10., -5., 0., 5., 10.], 2)
+        S = np.random.choice([0.9, 1.0, 1.1], 2)
+        Tx = np.random.choice([-0.2, -0.1, 0.0, 0.1, 0.2], 2)
+        Ty = np.random.choice([-0.2, -0.1, 0.0, 0.1, 0.2], 2)
+        out['c%d.move.nodes' % case] = np.stack([A, S, Tx, Ty])          # [4][2] node values
+        # the training feeder's chain (feeder.py:81-86): random_choose then random_move
+        random.seed(300 + case)
+        np.random.seed(300 + case)
+        out['c%d.chain24' % case] = tools.random_move(tools.random_choose(d.copy(), 24))
+        random.seed(300 + case)
+        np.random.seed(300 + case)
+        out['c%d.chain24.begin' % case] = np.asarray(random.randint(0, T - 24))
+        random.choice([1])
+        A = np.random.choice([-10., -5., 0., 5., 10.], 2)
+        S = np.random.choice([0.9, 1.0, 1.1], 2)
+        Tx = np.random.choice([-0.2, -0.1, 0.0, 0.1, 0.2], 2)
+        Ty = np.random.choice([-0.2, -0.1, 0.0, 0.1, 0.2], 2)
+        out['c%d.chain24.nodes' % case] = np.stack([A, S, Tx, Ty])
+    save('feeder_g7.npz', **out)
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45']
+    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7']
     if 'g1' in what:
         g1_graph()
     if 'g2' in what:
@@ -291,3 +361,7 @@ if __name__ == '__main__':
         g3_blocks()
     if 'g45' in what:
         g45_models()
+    if 'g6' in what:
+        g6_extract_feature()
+    if 'g7' in what:
+        g7_feeder_tools()
