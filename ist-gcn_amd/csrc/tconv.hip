@@ -16,28 +16,33 @@
 // Forward: in_mul = stride, tap_off[j] = j - pad, out_mul = 1.  Data gradient: one launch per output phase
 // (t mod stride) with the taps that hit that phase, in_mul = 1, out_mul = stride, out_off = phase.
 //
-// A workgroup (4 waves) owns TR = 128*NT output rows (whole frames of one sequence) x up to 128 output
-// channels; the input rows it needs (with the tap halo) are staged per channel chunk into LDS once and then
-// re-read at a row offset per tap, so the activation is fetched from HBM/L2 once per chunk, not once per tap.
-// Tiles of one sequence are kept on one XCD (grid-stride order below) so halo re-reads hit that XCD's L2.
+// A workgroup owns TR = 128*NT output rows (whole frames of one sequence) x up to 128 output channels; the input rows
+// it needs (with the tap halo) are staged per channel chunk into LDS once and then re-read at a row offset per tap, so
+// the activation is fetched from HBM/L2 once per chunk, not once per tap.  Tiles of one sequence are kept on one XCD
+// (grid-stride order below) so halo re-reads hit that XCD's L2.
+//
+// Wave specialisation (round 2).  The workgroup has EIGHT waves in two roles, one workgroup per CU:
+//   waves 0-3  "compute": the MFMA loop over (taps x k-groups) of the staged chunk, weight fragments streamed from L2
+//              through a register ring; at the end of a tile they drop their accumulators into the LDS output image;
+//   waves 4-7  "memory": everything that touches HBM -- they keep the global loads of the chunk TWO items ahead in
+//              registers (they own no accumulators, so the registers are free), apply the BatchNorm affine + ReLU and
+//              write the chunk one item ahead into the other half of a double-buffered LDS tile, and they stream the
+//              previous tile's output image to HBM with the epilogue math (bias is already in the accumulators; BN sums /
+//              ReLU mask / residual) while the compute waves are already on the next tile.
+// The two roles meet at one barrier per (tile, chunk) item (+ the hand-over of the output image at a tile end), so the
+// matrix cores see back-to-back MFMA work whenever a chunk's matrix time exceeds its memory time (128/256-channel layers)
+// and the HBM stream never waits for arithmetic otherwise (64-channel layers).  In the single-role kernel this replaces
+// (round 1: two 4-wave workgroups per CU, each running stage -> barrier -> MFMA -> barrier -> epilogue in sequence) 40 %
+// of the time was un-overlapped staging and epilogue.
 #include "common.hpp"
+#include <cstdlib>
+#include <type_traits>
 
-#ifdef ISTGCN_STAMP
-// diagnostic build only: per-phase cycle sums (lane 0 of every wave), read back with istgcn_debug_stamps
-__device__ unsigned long long g_stamp[8];
-#define STAMP(i)                                                                                   \
-  do {                                                                                             \
-    unsigned long long t_ = __builtin_amdgcn_s_memtime();                                          \
-    if (lane == 0) st_acc[i] += t_ - st_prev;                                                      \
-    st_prev = __builtin_amdgcn_s_memtime();                                                        \
-  } while (0)
-#else
-#define STAMP(i)
-#endif
 
 namespace {
 
-constexpr int NTHREADS = 256;
+constexpr int NROLE = 256;           // threads per role (4 waves)
+constexpr int NTH = 2 * NROLE;       // compute waves 0-3, memory waves 4-7
 constexpr int MAX_TAPS = 16;
 
 struct TconvParams {
@@ -45,8 +50,8 @@ struct TconvParams {
   const void* Wp;
   const float* bias;     // [Cout] or null
   const float* pre;      // [2][Cin] scale, shift or null
-  const void* aux;       // epilogue mode 1: [NM][Tout][V][Cout]
-  const float* maux;     // epilogue mode 1: [4][Cout] scale, shift, mean, rstd
+  const void* aux;       // epilogue mode 1 / 2: [NM][Tout][V][Cout]
+  const float* maux;     // mode 1: [4][Cout] scale, shift, mean, rstd; mode 2: [2][Cout] scale, shift or null
   void* out;
   double* stats;         // [stats_rep][2][Cout] or null
   int NM, Tin, Tout, Mlog, V, Cin, Cout, ntaps;
@@ -54,35 +59,58 @@ struct TconvParams {
   int tap_off[MAX_TAPS];
   // derived on the host
   int F, tiles_per_seq, total_tiles, CC, nch, NKG, MTtot, min_off, Fin;
-  int us_stride, out_stride, off_stat, off_work;
+  int us_stride, out_stride, off_stat, off_u0, off_u1, off_o;
+  int cin_pad;           // nch * CC: length of the LDS copies of the `pre` rows
+  int abl;               // diagnostic ablation (ISTGCN_TCONV_ABL): 1 = no input loads, 2 = no MFMAs; results are then wrong
 };
 
-// WM = waves along the channel axis: the workgroup has 4*WM waves; wave (wr = wave & 3, wm = wave >> 2) owns row slab wr
-// and the MT/WM output-channel tiles [wm*MTW, (wm+1)*MTW).  WM = 2 doubles the waves per CU at the same LDS footprint
-// (these kernels wait on memory and barriers more than half of their wave-cycles).
-template <typename T, int MT, int NT, bool VEC, int WM, int MODE>
-__global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvParams P) {
-  constexpr int NTH = NTHREADS * WM;
-  constexpr int MTW = MT / WM;
-  static_assert(MT % WM == 0, "channel tiles must split evenly over the channel waves");
+struct Tile {
+  int n, m0, nf, rows, fin0, in_rows, r_lo, r_hi;
+  long long row0;        // first staged input row (frame fin0, may be negative) in rows of the NTVC tensor
+  bool valid;
+};
+
+__device__ static inline void lds_barrier() {
+  // LDS traffic of this wave retired, then the workgroup barrier.  NOT __syncthreads(): its fence drains vmcnt(0), which
+  // would wait for the memory waves' prefetch (two items of global loads deliberately left in flight across barriers).
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int UL = 8;     // 16-byte vectors of a staged chunk per memory-wave thread (rows x vectors <= UL * 256, checked on the host)
+
+template <typename T, int MT, int NT, bool VEC, int MODE, int WM>
+__global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int KGS = E::KGS;
   constexpr int TR = 128 * NT;
+  constexpr int OW = 256 / (int)sizeof(T);             // channels per epilogue pass (256-byte rows of the output image)
+  constexpr int NPASS = (MT * 32 + OW - 1) / OW;       // 1 for the 16-bit types, 2 for fp32 with 128 output channels
+  constexpr int MPP = OW / 32;                         // channel tiles per pass
+  // compute-wave layout: WM channel groups x 4/WM row groups.  WM = 2: a wave owns MT/2 channel tiles x 2*NT row tiles, so
+  // a weight fragment (vector L1 / L2) feeds 2*NT MFMAs instead of NT -- the L1 delivers 64 B/clk per CU, which one
+  // fragment per two MFMAs on all four SIMDs already saturates
+  static_assert(true && MT % WM == 0, "channel tiles split evenly over the channel groups");
+  constexpr int MTW = MT / WM, NTW = NT * WM;
   typedef typename E::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);          // [TR]
   unsigned short* row_v = row_f + TR;                                        // [TR]
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
-  int* tap_roff = reinterpret_cast<int*>(stat + 2 * MT * 32);                 // [MAX_TAPS] LDS row offset per tap
-  T* us = reinterpret_cast<T*>(smem + P.off_work);                           // [Fin*V][us_stride]
-  T* outs = us;                                                              // [TR][out_stride]
+  float* bias_l = stat + 2 * MT * 32;                                        // [MT*32] conv bias of this channel block
+  float* pre_l = bias_l + MT * 32;                                           // [2][cin_pad] BatchNorm affine of the input
+  // the two halves of the staged-chunk buffer, [Fin*V][us_stride] each.  Always formed as smem + offset: selecting between
+  // two POINTERS makes the compiler lose the LDS address space and emit flat loads, which count on vmcnt AND lgkmcnt, return
+  // out of order and force vmcnt(0) waits in front of every MFMA group (found in the ISA of the first wave-specialised build)
+  auto ubuf = [&](int half) __attribute__((always_inline)) { return reinterpret_cast<T*>(smem + (half ? P.off_u1 : P.off_u0)); };
+  T* outs = reinterpret_cast<T*>(smem + P.off_o);                            // [TR][out_stride]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = tid >> 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool is_compute = tid < NROLE;
+  const int ltid = tid & (NROLE - 1), wave = ltid >> 6;
   const int V = P.V;
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
-  const int Q = P.CC / EPL;
 
   for (int r = tid; r < TR; r += NTH) {
     int f = r / V;
@@ -90,310 +118,433 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
     row_v[r] = (unsigned short)(r - f * V);
   }
   for (int c = tid; c < 2 * MT * 32; c += NTH) stat[c] = 0.f;
-  if (tid < P.ntaps) tap_roff[tid] = (P.tap_off[tid] - P.min_off) * V;
-  __syncthreads();
+  // per-channel constants into LDS once: read from there they cost LDS latency and -- unlike a global load -- no wait on
+  // the vector-memory counter, behind which the waves' prefetched loads are queued
+  for (int c = tid; c < MT * 32; c += NTH) bias_l[c] = (P.bias && cbase_blk + c < P.Cout) ? P.bias[cbase_blk + c] : 0.f;
+  for (int c = tid; c < 2 * P.cin_pad; c += NTH) {
+    const int h = c / P.cin_pad, i = c - h * P.cin_pad;
+    pre_l[c] = (P.pre && i < P.Cin) ? P.pre[h * P.Cin + i] : (h == 0 ? 1.f : 0.f);
+  }
 
   const T* ing = reinterpret_cast<const T*>(P.in);
   const T* Wp = reinterpret_cast<const T*>(P.Wp);
   const T* auxg = reinterpret_cast<const T*>(P.aux);
   T* outg = reinterpret_cast<T*>(P.out);
 
-  // XCD-affine persistent order: XCD x (= blockIdx.x % 8 under round-robin dispatch; speed only) walks the
-  // contiguous tile range [x*chunk, (x+1)*chunk), its workgroups taking neighbouring tiles at each step.
+  // XCD-affine persistent order: XCD x (= blockIdx.x % 8 under round-robin dispatch; speed only) walks the contiguous
+  // tile range [x*chunk, (x+1)*chunk), its workgroups taking neighbouring tiles at each step.  The k-th tile of this
+  // workgroup is tile0 + k*G8; an ITEM is one (tile, input-channel chunk) pair, item = k*nch + ch.
   const int G8 = gridDim.x >> 3;
   const int chunk = (P.total_tiles + 7) >> 3;
-  const int xcd = blockIdx.x & 7;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int slot_end = min(chunk, P.total_tiles - xcd * chunk);
+  const int ntile_w = slot0 < slot_end ? (slot_end - slot0 + G8 - 1) / G8 : 0;
+  const int nch = P.nch;
+  const int total_items = ntile_w * nch;
+  auto tile_of = [&](int k) __attribute__((always_inline)) {
+    Tile t;
+    t.valid = k < ntile_w;
+    const int tile = xcd * chunk + slot0 + (t.valid ? k : 0) * G8;
+    t.n = tile / P.tiles_per_seq;
+    t.m0 = (tile - t.n * P.tiles_per_seq) * P.F;
+    t.nf = min(P.F, P.Mlog - t.m0);
+    t.rows = t.nf * V;
+    t.fin0 = P.in_mul * t.m0 + P.min_off;                              // first staged input frame (may be < 0)
+    t.in_rows = (P.in_mul * (t.nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
+    t.r_lo = t.fin0 < 0 ? -t.fin0 * V : 0;
+    t.r_hi = min(t.in_rows, (P.Tin - t.fin0) * V);
+    t.row0 = (long long)(t.n * P.Tin + t.fin0) * V;
+    return t;
+  };
+  lds_barrier();
 
-  // BatchNorm partial sums: a thread always copies out the same channel vector.  Where registers allow (small
-  // accumulator footprints) the sums stay in registers for the whole grid-stride walk and are reduced across lanes once
-  // per workgroup; the register-heavy instantiations reduce per tile instead.
-  constexpr bool REG_STATS = MTW * NT < 8;
-  constexpr int NPASS_ = (MT + 1) / 2;
-  float st1[REG_STATS ? NPASS_ : 1][EPL], st2[REG_STATS ? NPASS_ : 1][EPL];
+  if (is_compute) {
+    // =========================================== compute waves ===========================================
+    // One wave per SIMD issues all the MFMAs, so nothing may stall it: the weight fragments come from L2 (500-900 cycles)
+    // through a register ring DA steps deep that runs CONTINUOUSLY over the items of the workgroup -- the fragment
+    // sequence of a tile is periodic (it does not depend on the staged data), so the ring keeps prefetching across the
+    // item barriers and tile ends; the activation fragments (LDS, ~100 cycles) are read one step ahead inside an item.
+    // (Round 1 re-primed a 3-4 deep ring per chunk: with two workgroups per CU the other workgroup covered the bubbles
+    // and the too-shallow ring; with one wave per SIMD they were the kernel.)
+    // Shape of the loop, chosen so that the compiler's own s_waitcnt bookkeeping stays exact (a data-dependent number of
+    // loads on any path degrades every wait to vmcnt(0) = one exposed L2 round trip per step): an item is padded to
+    // nitp = a multiple of DA steps, every (padded) step issues exactly MTW ring loads -- ghost steps and steps past the
+    // last item read fragment 0 -- and only the MFMAs are predicated.  With nitp a multiple of DA the ring slot of a step
+    // is its position in the unrolled chunk, and the first steps of the next item are already in flight when an item ends.
+    constexpr int DA = 6;                                   // weight ring: 5 steps ahead
+    constexpr int DB = NTW >= 8 ? 2 : 3;                    // activation ring: DB-1 steps ahead (divides DA: static slots)
+    constexpr int PD = DB - 1;
+    f32x16 acc[MTW][NTW];
+    int brow[NTW];                                          // element offset of the lane's fragment at tap offset 0
+    const int wr = wave / WM, wm = wave % WM;               // row group, channel group of this wave
+    const int hoff = (lane >> 5) * EPL;
+    const int nit = P.ntaps * P.NKG;                       // steps per item; NKG is a power of two
+    const int nitp = (nit + DA - 1) / DA * DA;
+    const int lkg = 31 - __builtin_clz(P.NKG);
+    const int roff0 = (P.tap_off[0] - P.min_off) * V;
+    const int rstep = P.ntaps > 1 ? (P.tap_off[1] - P.tap_off[0]) * V : 0;
+    const int period = nch * nit;
+    const size_t astride = (size_t)P.MTtot * 64 * EPL;      // elements between the fragments of consecutive steps
+    const T* abase = Wp + ((size_t)(mt0 + wm * MTW) * 64 + lane) * EPL;
+    // fragments live in the rings as four raw dwords: loop-carried arrays of 8 x 16-bit vectors get scalarised and re-packed
+    // element by element (20 v_perm_b32 per step in the first build); they become MFMA operands by a bit cast
+    u32x4 a[DA][MTW], b[DB][NTW];
+    // running positions (a handful of scalar adds / selects per step; recomputing tap, k-group and offsets from the step
+    // number cost ~20 scalar instructions per 4-8 MFMAs, and the 64-channel layers are instruction-issue bound)
+    size_t aoff = 0;                                        // element offset of the next real ring fragment (wraps at alimit)
+    const size_t alimit = (size_t)period * astride;
+    int ppos = 0;                                           // padded step (mod nitp) the next ring load is for
+    auto load_a = [&](u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
+      // branch-free: a ghost step (padding of an item to a multiple of DA steps) reads fragment 0 and does not advance
+      const bool real = ppos < nit;
+      const size_t off = real ? aoff : 0;
 #pragma unroll
-  for (int ps = 0; ps < (REG_STATS ? NPASS_ : 1); ++ps)
+      for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + off + (size_t)m * 64 * EPL);
+      const size_t an = aoff + (real ? astride : 0);
+      aoff = an == alimit ? 0 : an;
+      ppos = ppos + 1 == nitp ? 0 : ppos + 1;
+    };
+    const T* us = ubuf(0);
+    // activation fragments of the NEXT not yet loaded step of the current item: running (k-group, offset) pair; past the
+    // item's last step it stays there (the slot is reloaded with the same fragment and never used)
+    const int tapstep = rstep * P.us_stride - (P.NKG - 1) * KGS;
+    int sb = 0, kgb = 0, soffb = 0;                         // step, its k-group, its element offset in the tile
+    auto load_b = [&](u32x4 (&dst)[NTW]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] = 0.f; st2[ps][jj] = 0.f; }
-
-#ifdef ISTGCN_STAMP
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
-#endif
-  for (int slot = blockIdx.x >> 3; slot < chunk; slot += G8) {
-    const int tile = xcd * chunk + slot;
-    if (tile >= P.total_tiles) break;
-    STAMP(0);
-    const int n = tile / P.tiles_per_seq;
-    const int m0 = (tile - n * P.tiles_per_seq) * P.F;
-    const int nf = min(P.F, P.Mlog - m0);
-    const int rows = nf * V;
-    const int fin0 = P.in_mul * m0 + P.min_off;          // first staged input frame (may be < 0)
-    const int in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
-
-    // accumulators start at the conv bias (rows of the D tile = output channels: 4 consecutive ones per register
-    // quad), so the epilogue has no bias pass
-    f32x16 acc[MTW][NT];
+      for (int tt = 0; tt < NTW; ++tt) dst[tt] = *reinterpret_cast<const u32x4*>(us + brow[tt] + soffb);
+      const bool adv = sb + 1 < nit;
+      const bool wrap = kgb + 1 == P.NKG;
+      soffb += adv ? (wrap ? tapstep : KGS) : 0;
+      kgb = adv ? (wrap ? 0 : kgb + 1) : kgb;
+      sb += adv ? 1 : 0;
+    };
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) {
+    for (int d = 0; d < DA - 1; ++d) load_a(a[d]);         // in flight while the first chunk is being staged
+    lds_barrier();                                          // item 0 staged (the memory waves' prologue)
+    int ch = 0, k = 0;
+    for (int it = 0; it < total_items; ++it) {
+      if (ch == 0) {
+        // tile start: accumulators = conv bias (rows of the D tile = output channels: 4 consecutive per register quad),
+        // and the per-lane LDS row of each output row at tap offset 0 (pad rows clamp to row 0: computed, never stored)
+        const Tile t = tile_of(k);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (P.bias) {
-          const int cg = cbase_blk + (wm * MTW + m) * 32 + 8 * g + 4 * (lane >> 5);
-          if (VEC && cg + 3 < P.Cout) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(P.bias + cg);
-            bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
-          } else {
+        for (int m = 0; m < MTW; ++m) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) if (cg + jj < P.Cout) bv[jj] = P.bias[cg + jj];
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + (wm * MTW + m) * 32 + 8 * q4 + 4 * (lane >> 5));
+#pragma unroll
+            for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) acc[m][tt][4 * q4 + jj] = b4[jj];
           }
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int p = wr * (32 * NTW) + tt * 32 + (lane & 31);
+          brow[tt] = (p < t.rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0) * P.us_stride + hoff;
+        }
+      }
+      sb = 0; kgb = 0; soffb = roff0 * P.us_stride;         // taps are an arithmetic progression (checked on the host)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[m][t][4 * g + jj] = bv[jj];
+      for (int d = 0; d < PD; ++d) load_b(b[d]);
+      // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations two steps ahead),
+      // which are independent of each other: sched_group_barrier asks for them to be INTERLEAVED -- one MFMA, then a few
+      // of the other instructions in the 32-cycle shadow of that MFMA -- instead of a clump of ~50 address / load
+      // instructions in front of the MFMA group, during which the matrix pipe idles (SQ counters of the first
+      // wave-specialised build: MFMA pipe 45 % busy although the compute waves never waited on memory).
+#define TCONV_STEP(D, PRED)                                                                              \
+      {                                                                                                  \
+        const int st_ = s0 + (D);                                                                        \
+        load_a(a[((D) + DA - 1) % DA]);                                                                  \
+        load_b(b[((D) + PD) % DB]);                                                                      \
+        if (!(PRED) || st_ < nit) {                                                                      \
+          _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                \
+            _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) mma_kgroup(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); \
+        }                                                                                                \
+        _Pragma("unroll") for (int i_ = 0; i_ < MTW * NTW; ++i_) {                                       \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* one MFMA */                            \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* one LDS read */                        \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* one global read */                     \
+          __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);   /* a few VALU / SALU */                   \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+      }
+      const int nfull = nit / DA;
+      int s0 = 0;
+      for (int c = 0; c < nfull; ++c, s0 += DA) {
+        TCONV_STEP(0, false) TCONV_STEP(1, false) TCONV_STEP(2, false) TCONV_STEP(3, false) TCONV_STEP(4, false) TCONV_STEP(5, false)
+      }
+      if (s0 < nit) {                                       // remainder chunk: ghost steps keep the ring's cadence
+        TCONV_STEP(0, true) TCONV_STEP(1, true) TCONV_STEP(2, true) TCONV_STEP(3, true) TCONV_STEP(4, true) TCONV_STEP(5, true)
+      }
+#undef TCONV_STEP
+      us = ubuf((it + 1) & 1);
+      lds_barrier();                                        // item done: this half of the tile buffer may be refilled
+      if (++ch == nch) {
+        ch = 0;
+        ++k;
+        // ---- tile end: accumulators -> LDS output image (row-major, channels innermost), one hand-over per pass ----
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+          for (int tt = 0; tt < NTW; ++tt) {
+            const int sr = wr * (32 * NTW) + tt * 32 + (lane & 31);        // image row = tile row
+#pragma unroll
+            for (int ml = 0; ml < MPP; ++ml) {
+              const int mg = ps * MPP + ml;                // channel tile of this pass; held by channel group mg / MTW
+              const int m = mg % MTW;
+              if (mg < MT && mg / MTW == wm) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                  const int cl = ml * 32 + 8 * q4 + 4 * (lane >> 5);
+                  float v4[4] = {acc[m][tt][4 * q4], acc[m][tt][4 * q4 + 1], acc[m][tt][4 * q4 + 2], acc[m][tt][4 * q4 + 3]};
+                  store4(outs + sr * P.out_stride + cl, v4);
+                }
+              }
+            }
+          }
+          lds_barrier();                                    // image of pass ps complete
+          if (ps < NPASS - 1) lds_barrier();                // ... and streamed out by the memory waves: reusable
+        }
       }
     }
-
-    // per-lane LDS row of its output rows at tap offset 0 (pad rows clamp to row 0: computed, never stored)
-    int brow[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int p = wave * (32 * NT) + t * 32 + (lane & 31);
-      brow[t] = p < rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0;
-    }
-
-    for (int ch = 0; ch < P.nch; ++ch) {
+  } else {
+    // =========================================== memory waves ============================================
+    const int Q = P.CC / EPL;                               // 16-byte vectors per staged row: 2 or 4 (power of two)
+    const int lq = 31 - __builtin_clz(Q);
+    const int q = ltid & (Q - 1), r0 = ltid >> lq, RS = NROLE >> lq;
+    // ---- global loads of item j -> registers: all UL loads of a thread are in flight together, and they stay in flight
+    //      while the previous tile's output image is streamed out (the loads are only waited for in `commit`) ----
+    auto issue = [&](int j, u32x4 (&R)[UL]) __attribute__((always_inline)) {
+      const int k = j / nch, ch = j - k * nch;
+      const Tile t = tile_of(k);
       const int cb = ch * P.CC;
-      // ---- stage the input rows of this chunk (BatchNorm affine + ReLU applied on the way in) ----
-      {
-        const long long row0 = (long long)(n * P.Tin + fin0) * V;
-        const int r_lo = fin0 < 0 ? -fin0 * V : 0;
-        const int r_hi = min(in_rows, (P.Tin - fin0) * V);
-        stage_block<T, (MTW * NT >= 8 ? 4 : 8), VEC>(ing + row0 * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, us, P.us_stride, in_rows, r_lo, r_hi,
-                               Q, P.pre ? P.pre + cb : nullptr, P.pre ? P.pre + P.Cin + cb : nullptr, P.pre_relu, tid,
-                               NTH);
+      const bool qlive = t.valid && (q * EPL < P.Cin - cb);
+      const T* base = ing + (t.row0 * P.Cin + cb + q * EPL);
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int r = r0 + u * RS;
+        const bool live = qlive && r >= t.r_lo && r < t.r_hi;
+        if (VEC) {
+          // UNCONDITIONAL load (dead slots read the tensor's first vector and are zeroed in `commit`): a constant number
+          // of loads per item is what lets the compiler wait for "all but the UL youngest" instead of for everything
+          const T* p = (live && P.abl != 1) ? base + (long long)r * P.Cin : ing;
+          R[u] = *reinterpret_cast<const u32x4*>(p);
+        } else {
+          frag_t v;
+          zero_frag<T>(v);
+          if (live) {
+            const T* p = base + (long long)r * P.Cin;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) if (cb + q * EPL + e < P.Cin) v[e] = p[e];
+          }
+          R[u] = __builtin_bit_cast(u32x4, v);
+        }
       }
-      STAMP(1);
-      __syncthreads();
-      STAMP(2);
-      // ---- taps x k-groups on the matrix cores, software pipelined: the weight fragments (L2) and the shifted
-      //      activation fragments (LDS) of step it+1 are in flight while the MFMAs of step it issue ----
-      {
-        const int nit = P.ntaps * P.NKG;                       // NKG is a power of two
-        const int lkg = 31 - __builtin_clz(P.NKG);
-        const T* wbase = Wp + (((size_t)ch * nit) * P.MTtot + mt0) * 64 * EPL + lane * EPL;
-        const int hoff = (lane >> 5) * EPL;
-        const int roff0 = (P.tap_off[0] - P.min_off) * V;
-        const int rstep = P.ntaps > 1 ? (P.tap_off[1] - P.tap_off[0]) * V : 0;
-        auto load_step = [&](int it, frag_t (&a)[MTW], frag_t (&b)[NT]) {
-          const int j = it >> lkg, kg = it & (P.NKG - 1);
-          const int roff = roff0 + j * rstep;              // taps are an arithmetic progression (checked on the host)
+    };
+    // ---- registers of item j -> BatchNorm affine + ReLU -> LDS tile (zero rows outside the sequence / chunk) ----
+    auto commit = [&](int j, u32x4 (&R)[UL], T* us) __attribute__((always_inline)) {
+      const int k = j / nch, ch = j - k * nch;
+      const Tile t = tile_of(k);
+      if (!t.valid) return;
+      const int cb = ch * P.CC;
+      const int c_lim = P.Cin - cb;
+      const bool qlive = q * EPL < c_lim;
+      float scv[EPL], shv[EPL];
 #pragma unroll
-          for (int m = 0; m < MTW; ++m)
-            a[m] = *reinterpret_cast<const frag_t*>(wbase + ((size_t)it * P.MTtot + wm * MTW + m) * 64 * EPL);
+      for (int e4 = 0; e4 < EPL; e4 += 4) {
+        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(pre_l + cb + q * EPL + e4);
+        const f32x4 sh4 = *reinterpret_cast<const f32x4*>(pre_l + P.cin_pad + cb + q * EPL + e4);
 #pragma unroll
-          for (int t = 0; t < NT; ++t)
-            b[t] = *reinterpret_cast<const frag_t*>(us + (brow[t] + roff) * P.us_stride + kg * KGS + hoff);
-        };
-        auto mma_step = [&](const frag_t (&a)[MTW], const frag_t (&b)[NT]) {
-#pragma unroll
-          for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
-        };
-        // ring depth: fp32 steps are 4x longer (4 MFMAs of 64 cycles per k-group), two slots cover L2; bf16 needs more
-        constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MTW * NT <= 4 ? 4 : 3);
-        mfma_ring<DEPTH, MTW, NT, frag_t>(nit, load_step, mma_step);
+        for (int e = 0; e < 4; ++e) { scv[e4 + e] = sc4[e]; shv[e4 + e] = sh4[e]; }
       }
-      STAMP(3);
-      __syncthreads();
-      STAMP(4);
-    }
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const int r = r0 + u * RS;
+        if (r < t.in_rows) {
+          const bool live = qlive && r >= t.r_lo && r < t.r_hi;
+          frag_t v = __builtin_bit_cast(frag_t, R[u]);
+          if (!live) zero_frag<T>(v);
+          else if (P.pre) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+              if (VEC || q * EPL + e < c_lim) {
+                float fv = E::to_f(v[e]) * scv[e] + shv[e];
+                if (P.pre_relu) fv = fmaxf(fv, 0.f);
+                v[e] = E::from_f(fv);
+              }
+            }
+          }
+          *reinterpret_cast<frag_t*>(us + r * P.us_stride + q * EPL) = v;
+        }
+      }
+    };
 
-    // ---- epilogue: one pass per 64-channel pair over ALL TR rows of the tile (in-kernel stamps showed this stage at
-    //      35-50 % of the bf16 kernel when it made one pass per 32-row slab): accumulators -> LDS (row-major, channels
-    //      innermost) -> coalesced 16-byte stores with the mask / BatchNorm sums applied on the way out ----
-    constexpr int NPASS = (MT + 1) / 2;
-    constexpr int VPR = 64 / EPL;
-    constexpr int RSTEP = NTH / VPR;
-    const bool dense_rows = P.out_mul == 1;        // the tile's output rows are then one contiguous run in HBM
-    const size_t out_base = ((size_t)(n * P.Tout + m0 * P.out_mul + P.out_off) * V) * P.Cout;
-    // per-channel constants of this thread's channel vector (fixed across passes up to the 64-channel offset)
-    const int vq = tid % VPR;
+    // ---- output image of pass ps -> HBM with the epilogue math; per-channel sums stay in registers across tiles ----
+    // thread -> (row, channel vector) map over the LIVE channels of a pass: with 64 output channels the image's 128-channel
+    // rows are half empty, and a map over all 16 vectors left half of these threads idle in the sweep
+    constexpr int CW = MT * 32 < OW ? MT * 32 : OW;         // live channels per pass
+    constexpr int VPR = CW / EPL;                           // vectors per image row
+    constexpr int RSTEP = NROLE / VPR;                      // rows per sweep
+    const int vq = ltid % VPR;
+    float st1[NPASS][EPL], st2[NPASS][EPL];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
+    for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int sr = wave * (32 * NT) + t * 32 + (lane & 31);       // staging row = tile row
+      for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] = 0.f; st2[ps][jj] = 0.f; }
+    auto store_pass = [&](const Tile& t, int ps, float (&s1)[EPL], float (&s2)[EPL]) __attribute__((always_inline)) {
+      const bool dense_rows = P.out_mul == 1;               // the tile's output rows are then one contiguous run in HBM
+      const size_t out_base = ((size_t)(t.n * P.Tout + t.m0 * P.out_mul + P.out_off) * V) * P.Cout;
+      const int cg = cbase_blk + ps * OW + vq * EPL;
+      const bool col_live = (ps * OW + vq * EPL) < MT * 32 && cg < P.Cout;
+      float msc[EPL], msh[EPL], mmu[EPL], mrs[EPL];
 #pragma unroll
-        for (int ml = 0; ml < 2; ++ml) {
-          const int mg = 2 * ps + ml;                  // channel tile of this pass; held by channel-wave mg / MTW
-          const int m = mg % MTW;
-          if (mg < MT && mg / MTW == wm) {
+      for (int jj = 0; jj < EPL; ++jj) { msc[jj] = MODE == 2 ? 1.f : 0.f; msh[jj] = 0.f; mmu[jj] = 0.f; mrs[jj] = 0.f; }
+      if constexpr (MODE == 2) {
+        if (P.maux && col_live) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-              float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
-              store4(outs + sr * P.out_stride + cl, v4);
-            }
-          }
+          for (int jj = 0; jj < EPL; ++jj)
+            if (cg + jj < P.Cout) { msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj]; }
         }
       }
-      __syncthreads();
-      {
-        const int cg = cbase_blk + ps * 64 + vq * EPL;
-        const bool col_live = (ps * 64 + vq * EPL) < MT * 32 && cg < P.Cout;
-        float s1[EPL], s2[EPL], msc[EPL], msh[EPL], mmu[EPL], mrs[EPL];
-#pragma unroll
-        for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; msc[jj] = 0.f; msh[jj] = 0.f; mmu[jj] = 0.f; mrs[jj] = 0.f; }
-        if constexpr (MODE == 2) {
-          // residual affine (the folded BatchNorm of the strided 1x1 residual conv) or identity
-#pragma unroll
-          for (int jj = 0; jj < EPL; ++jj) msc[jj] = 1.f;
-          if (P.maux && col_live) {
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) {
-              if (cg + jj < P.Cout) { msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj]; }
-            }
-          }
-        }
-        if constexpr (MODE == 1) {
-          // producer's BatchNorm constants of this thread's channel vector: whole 16-byte loads, no per-element branches
-          if (col_live) {
-            if (VEC) {
-#pragma unroll
-              for (int j4 = 0; j4 < EPL; j4 += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(P.maux + cg + j4);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(P.maux + P.Cout + cg + j4);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(P.maux + 2 * P.Cout + cg + j4);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(P.maux + 3 * P.Cout + cg + j4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { msc[j4 + e] = a[e]; msh[j4 + e] = b[e]; mmu[j4 + e] = c[e]; mrs[j4 + e] = d[e]; }
-              }
-            } else {
-#pragma unroll
-              for (int jj = 0; jj < EPL; ++jj) {
-                if (cg + jj < P.Cout) {
-                  msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj];
-                  mmu[jj] = P.maux[2 * P.Cout + cg + jj]; mrs[jj] = P.maux[3 * P.Cout + cg + jj];
-                }
-              }
-            }
-          }
-        }
+      if constexpr (MODE == 1) {
         if (col_live) {
-          // UB rows per batch: their LDS reads and (data gradient) aux loads are all issued before the first is used
-          constexpr int UB = 4;
-          for (int p0 = tid / VPR; p0 < rows; p0 += RSTEP * UB) {
-            frag_t sv[UB], av[UB];
-            size_t g[UB];
-            bool ok[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-              const int p = p0 + u * RSTEP;
-              ok[u] = p < rows;
-              const int pc = ok[u] ? p : p0;
-              if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
-              else g[u] = ((size_t)(n * P.Tout + (m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
-              sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
-              if constexpr (MODE >= 1) {
-                if (MODE == 1 || auxg) {
-                  if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
-                  else {
-#pragma unroll
-                    for (int jj = 0; jj < EPL; ++jj) av[u][jj] = (cg + jj < P.Cout) ? auxg[g[u] + jj] : E::from_f(0.f);
-                  }
-                } else {
-                  zero_frag<T>(av[u]);
-                }
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-              if (!ok[u]) continue;
-              if constexpr (MODE == 1) {
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) {
-                  if (VEC || cg + jj < P.Cout) {
-                    const float xa = E::to_f(av[u][jj]);
-                    const T o = E::from_f(xa * msc[jj] + msh[jj] > 0.f ? E::to_f(sv[u][jj]) : 0.f);
-                    sv[u][jj] = o;
-                    const float fv = E::to_f(o);
-                    s1[jj] += fv;
-                    s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
-                  }
-                }
-              } else if constexpr (MODE == 2) {
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) {
-                  if (VEC || cg + jj < P.Cout) {
-                    const float r = auxg ? E::to_f(av[u][jj]) * msc[jj] + msh[jj] : 0.f;
-                    sv[u][jj] = E::from_f(fmaxf(E::to_f(sv[u][jj]) + r, 0.f));
-                  }
-                }
-              } else {
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) {
-                  if (VEC || cg + jj < P.Cout) {
-                    const float fv = E::to_f(sv[u][jj]);
-                    s1[jj] += fv;
-                    s2[jj] += fv * fv;
-                  }
-                }
-              }
-              if (VEC) *reinterpret_cast<frag_t*>(outg + g[u]) = sv[u];
-              else {
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g[u] + jj] = sv[u][jj];
-              }
-            }
-          }
-        }
-        if constexpr (REG_STATS) {
-#pragma unroll
-          for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] += s1[jj]; st2[ps][jj] += s2[jj]; }
-        } else if (P.stats) {
 #pragma unroll
           for (int jj = 0; jj < EPL; ++jj) {
-#pragma unroll
-            for (int msk = VPR; msk < 64; msk <<= 1) {
-              s1[jj] += __shfl_xor(s1[jj], msk);
-              s2[jj] += __shfl_xor(s2[jj], msk);
-            }
-          }
-          if (lane < VPR && col_live) {
-#pragma unroll
-            for (int jj = 0; jj < EPL; ++jj) {
-              const int cl = ps * 64 + vq * EPL + jj;
-              if (cbase_blk + cl < P.Cout) {
-                atomicAdd(&stat[cl], s1[jj]);
-                atomicAdd(&stat[MT * 32 + cl], s2[jj]);
-              }
+            if (cg + jj < P.Cout) {
+              msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj];
+              mmu[jj] = P.maux[2 * P.Cout + cg + jj]; mrs[jj] = P.maux[3 * P.Cout + cg + jj];
             }
           }
         }
       }
-      __syncthreads();
-    }
-    STAMP(5);
-  }
-#ifdef ISTGCN_STAMP
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamp[i], st_acc[i]);
-#endif
-
-  if (P.stats) {
-    if constexpr (REG_STATS) {
-      constexpr int VPR = 64 / EPL;
-      const int vq = tid % VPR;
+      if (!col_live || P.abl == 4) return;
+      // UB rows per batch: their LDS reads and (modes 1, 2) aux loads are all issued before the first is used
+      constexpr int UB = 4;
+      for (int p0 = ltid / VPR; p0 < t.rows; p0 += RSTEP * UB) {
+        frag_t sv[UB], av[UB];
+        size_t g[UB];
+        bool ok[UB];
 #pragma unroll
-      for (int ps = 0; ps < NPASS_; ++ps) {
+        for (int u = 0; u < UB; ++u) {
+          const int p = p0 + u * RSTEP;
+          ok[u] = p < t.rows;
+          const int pc = ok[u] ? p : p0;
+          if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
+          else g[u] = ((size_t)(t.n * P.Tout + (t.m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
+          sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
+          if constexpr (MODE >= 1) {
+            if (MODE == 1 || auxg) {
+              if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
+              else {
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) av[u][jj] = (cg + jj < P.Cout) ? auxg[g[u] + jj] : E::from_f(0.f);
+              }
+            } else {
+              zero_frag<T>(av[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (!ok[u]) continue;
+          if constexpr (MODE == 1) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+              if (VEC || cg + jj < P.Cout) {
+                const float xa = E::to_f(av[u][jj]);
+                const T o = E::from_f(xa * msc[jj] + msh[jj] > 0.f ? E::to_f(sv[u][jj]) : 0.f);
+                sv[u][jj] = o;
+                const float fv = E::to_f(o);
+                s1[jj] += fv;
+                s2[jj] += fv * (xa - mmu[jj]) * mrs[jj];
+              }
+            }
+          } else if constexpr (MODE == 2) {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+              if (VEC || cg + jj < P.Cout) {
+                const float r = auxg ? E::to_f(av[u][jj]) * msc[jj] + msh[jj] : 0.f;
+                sv[u][jj] = E::from_f(fmaxf(E::to_f(sv[u][jj]) + r, 0.f));
+              }
+            }
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+              if (VEC || cg + jj < P.Cout) {
+                const float fv = E::to_f(sv[u][jj]);
+                s1[jj] += fv;
+                s2[jj] += fv * fv;
+              }
+            }
+          }
+          if (VEC) *reinterpret_cast<frag_t*>(outg + g[u]) = sv[u];
+          else {
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) if (cg + jj < P.Cout) outg[g[u] + jj] = sv[u][jj];
+          }
+        }
+      }
+    };
+
+    // ---- the item loop.  While the compute waves are on item `it`, item it+1 goes registers -> LDS (other half of the
+    //      tile buffer) and item it+2 HBM -> registers: two items of global loads are in flight all the time (these waves
+    //      own no accumulators, the registers are free), so the stream never waits out a memory latency; behind them the
+    //      previous tile's output image goes LDS -> HBM.  Item j lives in register set j & 1. ----
+    u32x4 RA[UL], RB[UL];
+    issue(0, RA);
+    issue(1, RB);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(0, RA, ubuf(0));
+    lds_barrier();                                          // item 0 staged
+    bool pending = false;
+    Tile pend = tile_of(0);
+    auto iteration = [&](int it, u32x4 (&Rn)[UL], u32x4 (&Rf)[UL]) __attribute__((always_inline)) {    // Rn: item it+1, Rf: free -> item it+2
+      const int k = it / nch, ch = it - k * nch;
+      if constexpr (MODE >= 1) {
+        // this sweep reads `aux` from HBM and waits for it, which also retires every OLDER load: run it before the new
+        // prefetch is issued, so that wait only sees loads that have had a whole item to land
+        if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]); pending = false; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      issue(it + 2, Rf);                                    // (past the last item: dead slots, same number of loads)
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < total_items && P.abl != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
+      if constexpr (MODE == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]); pending = false; }   // stores only
+      }
+      lds_barrier();                                        // item `it` computed, item it+1 staged
+      if (ch == nch - 1) {                                  // tile end: take over the output image
+        const Tile t = tile_of(k);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          lds_barrier();                                    // image of pass ps written by the compute waves
+          if (ps < NPASS - 1) {
+            store_pass(t, ps, st1[ps], st2[ps]);
+            lds_barrier();
+          }
+        }
+        pending = true;
+        pend = t;
+      }
+    };
+    for (int it = 0; it < total_items; it += 2) {
+      iteration(it, RB, RA);
+      if (it + 1 < total_items) iteration(it + 1, RA, RB);
+    }
+    if (pending) store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]);
+
+    // ---- BatchNorm partial sums: registers -> lanes sharing a channel vector -> LDS ----
+    if (P.stats) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) {
           float a = st1[ps][jj], b = st2[ps][jj];
 #pragma unroll
           for (int msk = VPR; msk < 64; msk <<= 1) { a += __shfl_xor(a, msk); b += __shfl_xor(b, msk); }
-          const int cl = ps * 64 + vq * EPL + jj;
+          const int cl = ps * OW + vq * EPL + jj;
           if (lane < VPR && cl < MT * 32 && cbase_blk + cl < P.Cout) {
             atomicAdd(&stat[cl], a);
             atomicAdd(&stat[MT * 32 + cl], b);
@@ -401,7 +552,10 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
         }
       }
     }
-    __syncthreads();
+  }
+
+  if (P.stats) {
+    lds_barrier();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
     for (int c = tid; c < MT * 32; c += NTH) {
       if (cbase_blk + c < P.Cout) {
@@ -412,18 +566,17 @@ __global__ __launch_bounds__(NTHREADS * WM, 2) void tconv_kernel(const TconvPara
   }
 }
 
-template <typename T, int MT, int NT>
-int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
-  constexpr int WM = 1;   // WM = 2 (8 waves) needs <= 128 VGPRs for two workgroups per CU; the staging/epilogue code does not fit yet
+template <typename T, int MT, int NT, int WM>
+int launch4(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
 #define GO(VV, MD)                                                                                           \
   do {                                                                                                      \
-    auto kfn = tconv_kernel<T, MT, NT, VV, WM, MD>;                                                               \
+    auto kfn = tconv_kernel<T, MT, NT, VV, MD, WM>;                                                         \
     static std::atomic<unsigned long long> optin{0};                                                        \
     if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
-    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS * WM, lds)) / gy; \
+    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTH, lds)) / gy;           \
     gx = round_up(gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx), 8);  /* XCD-affine order: multiple of 8 */ \
-    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS * WM), lds, stream, P);                                  \
+    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTH), lds, stream, P);                                            \
   } while (0)
   if (P.mode == 1) { if (vec) GO(true, 1); else GO(false, 1); }
   else if (P.mode == 2) { if (vec) GO(true, 2); else GO(false, 2); }
@@ -434,7 +587,7 @@ int launch3(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
 }
 
 // Tiling decision shared by the launcher and the geometry query (the host packs weights to match).
-struct TconvGeom { int CC, nch, NKG, MT, MTtot, gy, NT, F, Fin, min_off, lds, off_stat, off_work, us_stride, out_stride; };
+struct TconvGeom { int CC, nch, NKG, MT, MTtot, gy, NT, F, Fin, min_off, lds, off_stat, off_u0, off_u1, off_o, us_stride, out_stride; };
 
 inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, TconvGeom* G) {
   const int epl = dtype == 0 ? 4 : 8, kgs = 2 * epl, esz = dtype == 0 ? 4 : 2;
@@ -444,32 +597,39 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
   G->MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
   G->gy = ceil_div(Cout, G->MT * 32);
   G->MTtot = G->gy * G->MT;
-  G->out_stride = 64 + epl;
-  const int budget = 78 * 1024;                       // two workgroups per CU
-  const int cc_max = dtype == 0 ? 32 : 64;
+  const int ow = 256 / esz;
+  G->out_stride = ow + epl;
+  // double-buffered chunk tile + output image + tables in one CU's LDS; the widest chunk and the tallest tile that fit
+  // (a staged row is CC + EPL elements: 80 bytes at the full chunk width, conflict-free for the 16-byte fragment reads)
+  const int cc_max = dtype == 0 ? 16 : 32;
+  const int budget = 160 * 1024;
   int best_nt = 0, best_cc = 0;
   for (int nt = 2; nt >= 1 && !best_nt; --nt) {
-    if (nt * 128 / V < 1) continue;
+    const int F = nt * 128 / V;
+    if (F < 1) continue;
     for (int cc = cc_max; cc >= kgs; cc >>= 1) {
-      const int F = nt * 128 / V;
+      int cce = Cin < cc ? round_up(Cin, kgs) : cc;
       const int Fin = in_mul * (F - 1) + (mx - mn) + 1;
-      const long need = (long)Fin * V * (cc + epl) * esz;
-      if (need <= budget) { best_nt = nt; best_cc = cc; break; }
+      const long rows = (long)Fin * V;
+      const long tables = 1024 + (long)(3 * G->MT * 32 + 2 * round_up(Cin, cce)) * 4 + 64;
+      const long need = tables + 2 * rows * (cce + epl) * esz + (long)128 * nt * G->out_stride * esz;
+      if (need <= budget && rows * (cce / epl) <= UL * NROLE) { best_nt = nt; best_cc = cce; break; }
     }
   }
-  if (!best_nt) { best_nt = 1; best_cc = kgs; }
-  int cc = best_cc;
-  if (Cin < cc) cc = round_up(Cin, kgs);
+  if (!best_nt) return ISTGCN_EINVAL;
+  const int cc = best_cc;
   G->NT = best_nt; G->CC = cc; G->nch = ceil_div(Cin, cc); G->NKG = cc / kgs;
+  if (G->NKG & (G->NKG - 1)) return ISTGCN_EINVAL;
   G->F = best_nt * 128 / V;
   G->Fin = in_mul * (G->F - 1) + (mx - mn) + 1;
   G->us_stride = cc + epl;
   size_t off = (size_t)2 * 128 * best_nt * sizeof(unsigned short);
-  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off; off += (size_t)2 * G->MT * 32 * 4 + MAX_TAPS * 4;
-  off = (off + 15) & ~(size_t)15; G->off_work = (int)off;
-  size_t work = (size_t)G->Fin * V * G->us_stride * esz;
-  size_t ost = (size_t)128 * best_nt * G->out_stride * esz;
-  off += work > ost ? work : ost;
+  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off;
+  off += (size_t)(3 * G->MT * 32 + 2 * G->nch * cc) * 4;                     // BN partial sums, conv bias, `pre` rows
+  const size_t ubytes = (((size_t)G->Fin * V * G->us_stride * esz) + 15) & ~(size_t)15;
+  off = (off + 15) & ~(size_t)15; G->off_u0 = (int)off; off += ubytes;
+  G->off_u1 = (int)off; off += ubytes;
+  G->off_o = (int)off; off += (size_t)128 * best_nt * G->out_stride * esz;
   G->lds = (int)off;
   return off <= 160 * 1024 ? ISTGCN_OK : ISTGCN_EINVAL;
 }
@@ -477,12 +637,23 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
 template <typename T>
 int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t stream) {
   P.F = G.F; P.CC = G.CC; P.nch = G.nch; P.NKG = G.NKG; P.MTtot = G.MTtot; P.min_off = G.min_off; P.Fin = G.Fin;
-  P.us_stride = G.us_stride; P.out_stride = G.out_stride; P.off_stat = G.off_stat; P.off_work = G.off_work;
+  P.us_stride = G.us_stride; P.out_stride = G.out_stride; P.off_stat = G.off_stat; P.cin_pad = G.nch * G.CC;
+  P.off_u0 = G.off_u0; P.off_u1 = G.off_u1; P.off_o = G.off_o;
   P.tiles_per_seq = ceil_div(P.Mlog, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
   const size_t lds = G.lds;
-#define CASE(MTv, NTv) if (G.MT == MTv && G.NT == NTv) return launch3<T, MTv, NTv>(P, grid_cap, G.gy, lds, stream)
-  CASE(1, 1); CASE(2, 1); CASE(4, 1); CASE(1, 2); CASE(2, 2); CASE(4, 2);
+  const char* e_abl = getenv("ISTGCN_TCONV_ABL");
+  P.abl = e_abl ? atoi(e_abl) : 0;
+  // compute-wave layout: two channel groups x two row groups wherever there are two channel tiles to split
+#define CASE(MTv, NTv, WMv) if (G.MT == MTv && G.NT == NTv) return launch4<T, MTv, NTv, WMv>(P, grid_cap, G.gy, lds, stream)
+#ifdef ISTGCN_TCONV_ONE          /* ISA inspection builds: one instantiation */
+  if constexpr (sizeof(T) == 2 && !std::is_same<T, _Float16>::value) { CASE(2, 2, 2); CASE(4, 2, 2); }
+#else
+  // (four channel tiles: one per wave, every wave all rows -- each weight fragment is then fetched ONCE per CU and step)
+  // (one wave per channel tile x all rows -- each weight fragment fetched once per CU -- measured 5-7 % SLOWER for four
+  //  channel tiles: 8 activation fragments per step and wave from LDS instead of 4)
+  CASE(1, 1, 1); CASE(1, 2, 1); CASE(2, 1, 2); CASE(4, 1, 2); CASE(2, 2, 2); CASE(4, 2, 2);
+#endif
 #undef CASE
   return ISTGCN_EINVAL;
 }
@@ -530,13 +701,3 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);
 }
 
-#ifdef ISTGCN_STAMP
-extern "C" int istgcn_debug_stamps(unsigned long long* out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return ISTGCN_ELAUNCH;
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return ISTGCN_ELAUNCH;
-  }
-  return ISTGCN_OK;
-}
-#endif
