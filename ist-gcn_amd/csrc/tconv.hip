@@ -392,7 +392,34 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
       for (int jj = 0; jj < EPL; ++jj) { st1[ps][jj] = 0.f; st2[ps][jj] = 0.f; }
-    auto store_pass = [&](const Tile& t, int ps, float (&s1)[EPL], float (&s2)[EPL]) __attribute__((always_inline)) {
+    // modes 1 / 2 read `aux` (the producer's input / the residual) at the output positions: ALL rows of a thread are
+    // fetched in one go and early -- before the chunk prefetch of the same iteration -- so the sweep itself only stores
+    // (batches of four rows, each waiting out an HBM round trip, were most of the data-gradient kernel's memory side)
+    constexpr int NR = TR / RSTEP;                          // image rows per thread
+    // MEASURED AND SWITCHED OFF: with four channel tiles the compute waves' 128 accumulator registers set the kernel's
+    // allocation and 64 more here spilled 100 registers; with two it fit (9 spills) but the 64-channel data gradient went
+    // from 128 to 152 us -- the extra 16-32 KB of loads in flight per CU queue in front of the chunk prefetch.  Kept as a
+    // compile-time switch; the sweep reads `aux` in batches of four rows.
+    constexpr bool AUXPF = false && MODE >= 1 && VEC && MT <= 2;
+    auto out_index = [&](const Tile& t, int pc, int cg) __attribute__((always_inline)) {
+      if (P.out_mul == 1)                                   // the tile's output rows are then one contiguous run in HBM
+        return ((size_t)(t.n * P.Tout + t.m0 * P.out_mul + P.out_off) * V + pc) * P.Cout + cg;
+      return ((size_t)(t.n * P.Tout + (t.m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
+    };
+    auto aux_prefetch = [&](const Tile& t, int ps, u32x4 (&AV)[AUXPF ? NR : 1]) __attribute__((always_inline)) {
+      if constexpr (AUXPF) {
+        const int cg = cbase_blk + ps * OW + vq * EPL;
+        const bool col_live = (ps * OW + vq * EPL) < MT * 32 && cg < P.Cout;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int p = ltid / VPR + i * RSTEP;
+          const bool ok = col_live && auxg && p < t.rows;
+          const T* src = ok ? auxg + out_index(t, p, cg) : (auxg ? auxg : ing);   // dead slots: a valid address, ignored
+          AV[i] = *reinterpret_cast<const u32x4*>(src);
+        }
+      }
+    };
+    auto store_pass = [&](const Tile& t, int ps, float (&s1)[EPL], float (&s2)[EPL], u32x4 (&AV)[AUXPF ? NR : 1]) __attribute__((always_inline)) {
       const bool dense_rows = P.out_mul == 1;               // the tile's output rows are then one contiguous run in HBM
       const size_t out_base = ((size_t)(t.n * P.Tout + t.m0 * P.out_mul + P.out_off) * V) * P.Cout;
       const int cg = cbase_blk + ps * OW + vq * EPL;
@@ -421,20 +448,26 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       if (!col_live || P.abl == 4) return;
       // UB rows per batch: their LDS reads and (modes 1, 2) aux loads are all issued before the first is used
       constexpr int UB = 4;
-      for (int p0 = ltid / VPR; p0 < t.rows; p0 += RSTEP * UB) {
+      static_assert(NR % UB == 0 || NR < UB, "rows per thread come in whole batches");
+#pragma unroll
+      for (int i0 = 0; i0 < NR; i0 += UB) {
+        const int p0 = ltid / VPR + i0 * RSTEP;
+        if (p0 >= t.rows) break;
         frag_t sv[UB], av[UB];
         size_t g[UB];
         bool ok[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int p = p0 + u * RSTEP;
-          ok[u] = p < t.rows;
+          ok[u] = (i0 + u < NR) && p < t.rows;
           const int pc = ok[u] ? p : p0;
           if (dense_rows) g[u] = out_base + (size_t)pc * P.Cout + cg;
           else g[u] = ((size_t)(t.n * P.Tout + (t.m0 + row_f[pc]) * P.out_mul + P.out_off) * V + row_v[pc]) * P.Cout + cg;
           sv[u] = *reinterpret_cast<const frag_t*>(outs + pc * P.out_stride + vq * EPL);
           if constexpr (MODE >= 1) {
-            if (MODE == 1 || auxg) {
+            if constexpr (AUXPF) {
+              av[u] = __builtin_bit_cast(frag_t, AV[(i0 + u) < NR ? i0 + u : 0]);
+            } else if (MODE == 1 || auxg) {
               if (VEC) av[u] = *reinterpret_cast<const frag_t*>(auxg + g[u]);
               else {
 #pragma unroll
@@ -501,19 +534,14 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     Tile pend = tile_of(0);
     auto iteration = [&](int it, u32x4 (&Rn)[UL], u32x4 (&Rf)[UL]) __attribute__((always_inline)) {    // Rn: item it+1, Rf: free -> item it+2
       const int k = it / nch, ch = it - k * nch;
-      if constexpr (MODE >= 1) {
-        // this sweep reads `aux` from HBM and waits for it, which also retires every OLDER load: run it before the new
-        // prefetch is issued, so that wait only sees loads that have had a whole item to land
-        if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]); pending = false; }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      u32x4 AV[AUXPF ? NR : 1];
+      if (pending) aux_prefetch(pend, NPASS - 1, AV);       // oldest loads of the iteration: landed when the sweep starts
+      __builtin_amdgcn_sched_barrier(0);
       issue(it + 2, Rf);                                    // (past the last item: dead slots, same number of loads)
       __builtin_amdgcn_sched_barrier(0);
       if (it + 1 < total_items && P.abl != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
-      if constexpr (MODE == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]); pending = false; }   // stores only
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AV); pending = false; }
       lds_barrier();                                        // item `it` computed, item it+1 staged
       if (ch == nch - 1) {                                  // tile end: take over the output image
         const Tile t = tile_of(k);
@@ -521,7 +549,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         for (int ps = 0; ps < NPASS; ++ps) {
           lds_barrier();                                    // image of pass ps written by the compute waves
           if (ps < NPASS - 1) {
-            store_pass(t, ps, st1[ps], st2[ps]);
+            u32x4 AVp[AUXPF ? NR : 1];
+            aux_prefetch(t, ps, AVp);
+            store_pass(t, ps, st1[ps], st2[ps], AVp);
             lds_barrier();
           }
         }
@@ -533,7 +563,11 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       iteration(it, RB, RA);
       if (it + 1 < total_items) iteration(it + 1, RA, RB);
     }
-    if (pending) store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1]);
+    if (pending) {
+      u32x4 AVl[AUXPF ? NR : 1];
+      aux_prefetch(pend, NPASS - 1, AVl);
+      store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AVl);
+    }
 
     // ---- BatchNorm partial sums: registers -> lanes sharing a channel vector -> LDS ----
     if (P.stats) {
