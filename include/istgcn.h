@@ -127,6 +127,20 @@ long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype);
 int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin, int Cout, int K,
                         int dtype, void* stream);
 
+/* All weight packs of a model in ONE launch (a training step repacks every weight after the optimiser update: ~46 tiny
+ * launches for a 10-block model).  The host fills one opaque record of istgcn_pack_job_bytes() bytes per weight with the
+ * istgcn_pack_job_* functions (arguments as for the single-weight packers above; they return the number of workgroups
+ * the job needs, or < 0), uploads the records and the exclusive prefix sums block_start[njobs] of those counts, and
+ * launches istgcn_pack_batch whenever the parameters have changed.  Pointers inside the records must stay valid. */
+int istgcn_pack_job_bytes(void);
+int istgcn_pack_job_gcn(void* rec, const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin, int Cout,
+                        int K, int dtype);
+int istgcn_pack_job_tconv(void* rec, const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,
+                          void* dst, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype);
+int istgcn_pack_job_gcn_bwd(void* rec, const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin,
+                            int Cout, int K, int dtype);
+int istgcn_pack_batch(const void* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, int dtype, void* stream);
+
 /* Parameter folds of the graph-conv unit (one launch each way; everything fp32):
  *   A_eff = sum_j B_j (.) imp_j   (J = 1: A*importance, st_gcnold.py:86; J = 3: the Inception-GCN sum of
  *           st_gcn_msgcn.py:116-117 or the elementwise powers of tgcn_multi3_fix_3A.py:86-89; B = [J][K][V][V])
@@ -137,6 +151,16 @@ int istgcn_fold_fwd(const float* B, int J, const float* imp0, const float* imp1,
 int istgcn_fold_bwd(const float* B, int J, const float* imp0, const float* imp1, const float* imp2, const float* bias,
                     const float* dA, const float* S, float* dimp0, float* dimp1, float* dimp2, float* dbias, int K, int V,
                     int C, void* stream);
+
+/* The same folds for all nb <= 16 blocks of a model in one launch each way (one workgroup per block).  imps / dimps are
+ * [nb][3] pointer tables (entries >= J unused), biases / A_eff / bterm / dA / S / dbias [nb] pointer tables (biases, bterm,
+ * dA, S, dbias may be NULL or hold NULL entries with the meaning above), Cs [nb] the blocks' output channel counts; B, J, K,
+ * V are shared.  The tables are host arrays read at launch. */
+int istgcn_fold_fwd_batch(int nb, const float* B, int J, const float* const* imps, const float* const* biases,
+                          float* const* A_eff, float* const* bterm, const int* Cs, int K, int V, void* stream);
+int istgcn_fold_bwd_batch(int nb, const float* B, int J, const float* const* imps, const float* const* biases,
+                          const float* const* dA, const float* const* S, float* const* dimps, float* const* dbias,
+                          const int* Cs, int K, int V, void* stream);
 
 /* The three-branch Inception-TCN folded into ONE 15-tap convolution (linear in the weights), and its gradient:
  *   taps[j][o][i] = scale*(m0*W1[o][i][j-6] + m1*W2[o][i][j-3] + m2*W3[o][i][j]),  bias = scale*(m0*b1 + m1*b2 + m2*b3)

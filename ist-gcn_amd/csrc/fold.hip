@@ -55,9 +55,7 @@ __device__ static inline void fold_and_sum(const FoldParams& P, float* a_l, floa
 // K*V*V <= MAXA floats (48 KiB) of LDS for A_eff: V <= 64 with K = 3; the skeleton graphs have V <= 25
 constexpr int MAXA = 3 * 64 * 64;
 
-__global__ __launch_bounds__(NT) void fold_fwd_kernel(const FoldParams P) {
-  __shared__ float colsum[MAXKV];
-  extern __shared__ float a_l[];
+__device__ static inline void fold_fwd_body(const FoldParams& P, float* colsum, float* a_l) {
   if (!P.bias) {
     const int KVV = P.K * P.V * P.V;
     for (int e = threadIdx.x; e < KVV; e += NT) {
@@ -76,10 +74,24 @@ __global__ __launch_bounds__(NT) void fold_fwd_kernel(const FoldParams P) {
   }
 }
 
-__global__ __launch_bounds__(NT) void fold_bwd_kernel(const FoldParams P) {
+__global__ __launch_bounds__(NT) void fold_fwd_kernel(const FoldParams P) {
   __shared__ float colsum[MAXKV];
-  __shared__ float dcol[MAXKV];
   extern __shared__ float a_l[];
+  fold_fwd_body(P, colsum, a_l);
+}
+
+// every block of a model in one launch: one workgroup per block (the folds only depend on parameters, so all blocks'
+// A_eff / bterm can be produced at the top of the forward pass, and all their gradients when the last one is known)
+constexpr int MAXB = 16;
+struct FoldBatch { FoldParams p[MAXB]; };
+
+__global__ __launch_bounds__(NT) void fold_fwd_batch_kernel(const FoldBatch PB) {
+  __shared__ float colsum[MAXKV];
+  extern __shared__ float a_l[];
+  fold_fwd_body(PB.p[blockIdx.x], colsum, a_l);
+}
+
+__device__ static inline void fold_bwd_body(const FoldParams& P, float* colsum, float* dcol, float* a_l) {
   const int KV = P.K * P.V, VV = P.V * P.V, KVV = P.K * VV;
   const bool hb = P.bias && P.S;
   if (hb) {
@@ -115,6 +127,20 @@ __global__ __launch_bounds__(NT) void fold_bwd_kernel(const FoldParams P) {
     const float g = (P.dA ? P.dA[e] : 0.f) + (hb ? dcol[k * P.V + w] : 0.f);
     for (int j = 0; j < P.J; ++j) P.dimp[j][e] = P.B[(size_t)j * KVV + e] * g;
   }
+}
+
+__global__ __launch_bounds__(NT) void fold_bwd_kernel(const FoldParams P) {
+  __shared__ float colsum[MAXKV];
+  __shared__ float dcol[MAXKV];
+  extern __shared__ float a_l[];
+  fold_bwd_body(P, colsum, dcol, a_l);
+}
+
+__global__ __launch_bounds__(NT) void fold_bwd_batch_kernel(const FoldBatch PB) {
+  __shared__ float colsum[MAXKV];
+  __shared__ float dcol[MAXKV];
+  extern __shared__ float a_l[];
+  fold_bwd_body(PB.p[blockIdx.x], colsum, dcol, a_l);
 }
 
 // ---- the three-branch Inception-TCN as ONE 15-tap convolution (linear in the weights):
@@ -235,6 +261,51 @@ extern "C" int istgcn_fold_bwd(const float* B, int J, const float* imp0, const f
   P.dimp[0] = dimp0; P.dimp[1] = dimp1; P.dimp[2] = dimp2; P.dbias = dbias;
   P.J = J; P.K = K; P.V = V; P.C = C;
   ISTGCN_LAUNCH(fold_bwd_kernel, dim3(1), dim3(NT), (size_t)K * V * V * sizeof(float), (hipStream_t)stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_fold_fwd_batch(int nb, const float* B, int J, const float* const* imps, const float* const* biases,
+                                     float* const* A_eff, float* const* bterm, const int* Cs, int K, int V, void* stream) {
+  if (nb < 1 || nb > MAXB || !B || !imps || !A_eff || !Cs || J < 1 || J > 3) return ISTGCN_EINVAL;
+  if (K < 1 || V < 1 || K * V > MAXKV || K * V * V > MAXA) return ISTGCN_EINVAL;
+  FoldBatch PB{};
+  for (int i = 0; i < nb; ++i) {
+    FoldParams& P = PB.p[i];
+    P.B = B;
+    for (int j = 0; j < J; ++j) { P.imp[j] = imps[i * 3 + j]; if (!P.imp[j]) return ISTGCN_EINVAL; }
+    P.bias = biases ? biases[i] : nullptr;
+    P.A_eff = A_eff[i];
+    P.bterm = bterm ? bterm[i] : nullptr;
+    if (!P.A_eff || (P.bias && (!P.bterm || Cs[i] < 1))) return ISTGCN_EINVAL;
+    P.J = J; P.K = K; P.V = V; P.C = Cs[i];
+  }
+  ISTGCN_LAUNCH(fold_fwd_batch_kernel, dim3(nb), dim3(NT), (size_t)K * V * V * sizeof(float), (hipStream_t)stream, PB);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_fold_bwd_batch(int nb, const float* B, int J, const float* const* imps, const float* const* biases,
+                                     const float* const* dA, const float* const* S, float* const* dimps, float* const* dbias,
+                                     const int* Cs, int K, int V, void* stream) {
+  if (nb < 1 || nb > MAXB || !B || !imps || !dimps || !Cs || J < 1 || J > 3) return ISTGCN_EINVAL;
+  if (K < 1 || V < 1 || K * V > MAXKV || K * V * V > MAXA) return ISTGCN_EINVAL;
+  FoldBatch PB{};
+  for (int i = 0; i < nb; ++i) {
+    FoldParams& P = PB.p[i];
+    P.B = B;
+    for (int j = 0; j < J; ++j) {
+      P.imp[j] = imps[i * 3 + j]; P.dimp[j] = dimps[i * 3 + j];
+      if (!P.imp[j] || !P.dimp[j]) return ISTGCN_EINVAL;
+    }
+    P.bias = biases ? biases[i] : nullptr;
+    P.dA = dA ? dA[i] : nullptr;
+    P.S = S ? S[i] : nullptr;
+    P.dbias = dbias ? dbias[i] : nullptr;
+    if (P.S && P.bias && Cs[i] < 1) return ISTGCN_EINVAL;
+    P.J = J; P.K = K; P.V = V; P.C = Cs[i];
+  }
+  ISTGCN_LAUNCH(fold_bwd_batch_kernel, dim3(nb), dim3(NT), (size_t)K * V * V * sizeof(float), (hipStream_t)stream, PB);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

@@ -30,10 +30,9 @@ struct PackGcn {
 
 // one thread per 16-byte output vector (h, r fixed, e = 0..EPL-1)
 template <typename T>
-__global__ __launch_bounds__(256) void pack_gcn_kernel(const PackGcn P) {
+__device__ static inline void pack_gcn_body(const PackGcn& P, int idx) {
   constexpr int EPL = Elem<T>::EPL;
   const int total = P.nch * P.MTtot * P.NKG * 2 * 32;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   int t = idx;
   const int r = t % 32; t /= 32;
@@ -60,10 +59,12 @@ struct PackTconv {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack_tconv_kernel(const PackTconv P) {
+__global__ __launch_bounds__(256) void pack_gcn_kernel(const PackGcn P) { pack_gcn_body<T>(P, blockIdx.x * 256 + threadIdx.x); }
+
+template <typename T>
+__device__ static inline void pack_tconv_body(const PackTconv& P, int idx) {
   constexpr int EPL = Elem<T>::EPL;
   const int total = P.nch * P.ntaps * P.NKG * P.MTtot * 2 * 32;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   int t = idx;
   const int r = t % 32; t /= 32;
@@ -89,10 +90,12 @@ struct PackGcnBwd {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void pack_gcn_bwd_kernel(const PackGcnBwd P) {
+__global__ __launch_bounds__(256) void pack_tconv_kernel(const PackTconv P) { pack_tconv_body<T>(P, blockIdx.x * 256 + threadIdx.x); }
+
+template <typename T>
+__device__ static inline void pack_gcn_bwd_body(const PackGcnBwd& P, int idx) {
   constexpr int EPL = Elem<T>::EPL;
   const int total = P.nchi * P.nchc * P.NKGc * P.MTK * 2 * 32;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   int t = idx;
   const int r = t % 32; t /= 32;
@@ -112,7 +115,85 @@ __global__ __launch_bounds__(256) void pack_gcn_bwd_kernel(const PackGcnBwd P) {
   *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pack_gcn_bwd_kernel(const PackGcnBwd P) { pack_gcn_bwd_body<T>(P, blockIdx.x * 256 + threadIdx.x); }
+
+// ---- every weight of a model in ONE launch: a table of job records in device memory (filled on the host by the
+//      istgcn_pack_job_* functions, uploaded once; the parameter pointers are stable between optimiser steps), each
+//      workgroup finds its job from the table of first-workgroup indices ----
+struct PackJob {
+  int kind;              // 0 gcn, 1 tconv, 2 gcn_bwd
+  int pad_;
+  union { PackGcn g; PackTconv t; PackGcnBwd b; } u;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJob* __restrict__ jobs, const int* __restrict__ bstart, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= bstart[j + 1]) ++j;          // wave-uniform scan of <= a few dozen entries
+  const int idx = ((int)blockIdx.x - bstart[j]) * 256 + threadIdx.x;
+  const PackJob& J = jobs[j];
+  if (J.kind == 0) { const PackGcn P = J.u.g; pack_gcn_body<T>(P, idx); }
+  else if (J.kind == 1) { const PackTconv P = J.u.t; pack_tconv_body<T>(P, idx); }
+  else { const PackGcnBwd P = J.u.b; pack_gcn_bwd_body<T>(P, idx); }
+}
+
 }  // namespace
+
+extern "C" int istgcn_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+
+extern "C" int istgcn_pack_job_gcn(void* rec, const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin,
+                                   int Cout, int K, int dtype) {
+  if (!rec || !src || !dst || Cin < 1 || Cout < 1 || K < 1) return -1;
+  int cce, nch, kkp, mttot, epl;
+  if (istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return -1;
+  PackJob J{};
+  J.kind = 0;
+  J.u.g = PackGcn{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot};
+  *reinterpret_cast<PackJob*>(rec) = J;
+  return ceil_div(nch * mttot * J.u.g.NKG * 2 * 32, 256);
+}
+
+extern "C" int istgcn_pack_job_tconv(void* rec, const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,
+                                     void* dst, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype) {
+  if (!rec || !src || !dst || !tap_sel || !tap_off) return -1;
+  int cc, nch, mttot, epl;
+  if (istgcn_tconv_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &cc, &nch, &mttot, &epl)) return -1;
+  PackJob J{};
+  J.kind = 1;
+  PackTconv& P = J.u.t;
+  P.src = src; P.dst = dst; P.s_t = s_t; P.s_o = s_o; P.s_i = s_i;
+  P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps; P.CC = cc; P.nch = nch; P.NKG = cc / (2 * epl); P.MTtot = mttot;
+  for (int j = 0; j < ntaps; ++j) {
+    if (tap_sel[j] < 0) return -1;
+    P.tap_sel[j] = tap_sel[j];
+  }
+  *reinterpret_cast<PackJob*>(rec) = J;
+  return ceil_div(nch * ntaps * P.NKG * mttot * 2 * 32, 256);
+}
+
+extern "C" int istgcn_pack_job_gcn_bwd(void* rec, const float* src, long long s_k, long long s_c, long long s_i, void* dst, int Cin,
+                                       int Cout, int K, int dtype) {
+  if (!rec || !src || !dst || Cin < 1 || Cout < 1) return -1;
+  int cci, nchi, ccc, nchc, kkp, epl;
+  if (istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
+  PackJob J{};
+  J.kind = 2;
+  J.u.b = PackGcnBwd{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32};
+  *reinterpret_cast<PackJob*>(rec) = J;
+  return ceil_div(nchi * nchc * J.u.b.NKGc * J.u.b.MTK * 2 * 32, 256);
+}
+
+extern "C" int istgcn_pack_batch(const void* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, int dtype,
+                                 void* stream) {
+  if (!jobs_dev || !block_start_dev || njobs < 1 || total_blocks < 1 || !istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
+  const PackJob* jobs = reinterpret_cast<const PackJob*>(jobs_dev);
+  if (dtype == 0) ISTGCN_LAUNCH(pack_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, block_start_dev, njobs);
+  else if (dtype == 2) ISTGCN_LAUNCH(pack_batch_kernel<_Float16>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, block_start_dev, njobs);
+  else ISTGCN_LAUNCH(pack_batch_kernel<__bf16>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, block_start_dev, njobs);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
 
 extern "C" long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype) {
   int cce, nch, kkp, mttot, epl;

@@ -62,6 +62,42 @@ class FoldFn(torch.autograd.Function):
         return (None, dbias, None) + tuple(dimps)
 
 
+class FoldAllFn(torch.autograd.Function):
+    """FoldFn for ALL blocks of a model at once: (A_eff_0, bterm_0, A_eff_1, bterm_1, ...) = folds(B; biases, importances)
+    in one launch, and -- since autograd runs a node's backward only when every output's gradient is known -- all the
+    importance / bias gradients in one launch at the very end of the backward pass (were 2 x 10 launches per step).
+    forward(ctx, B, Cs, J, *tensors) with tensors = nb biases followed by nb*J importances (block-major)."""
+
+    @staticmethod
+    def forward(ctx, B, Cs, J, *tensors):
+        nb = len(Cs)
+        biases = [None if b is None else b.contiguous() for b in tensors[:nb]]
+        imps = [[tensors[nb + i * J + j].contiguous() for j in range(J)] for i in range(nb)]
+        A_effs, bts = ops.fold_fwd_batch(B, imps, biases, Cs)
+        ctx.save_for_backward(B, *[b for b in biases if b is not None], *[t for imp in imps for t in imp])
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.Cs, ctx.J = tuple(Cs), J
+        out = []
+        for a, bt in zip(A_effs, bts):
+            out += [a, bt]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        B = saved[0]
+        nb, J = len(ctx.Cs), ctx.J
+        nbias = sum(ctx.has_bias)
+        bl = list(saved[1:1 + nbias])
+        biases = [bl.pop(0) if h else None for h in ctx.has_bias]
+        flat = saved[1 + nbias:]
+        imps = [[flat[i * J + j] for j in range(J)] for i in range(nb)]
+        dAs = [None if grads[2 * i] is None else grads[2 * i].contiguous() for i in range(nb)]
+        Ss = [None if (grads[2 * i + 1] is None or biases[i] is None) else grads[2 * i + 1].contiguous() for i in range(nb)]
+        dimps, dbs = ops.fold_bwd_batch(B, imps, biases, dAs, Ss, ctx.Cs)
+        return (None, None, None) + tuple(dbs) + tuple(t for d in dimps for t in d)
+
+
 def fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
     """x1*m0 + x2*m1 + x3*m2 (st_gcn_multi3_fix_3A_mstcn.py:212-215; /3 in st_gcn_mstcn.py:245) with kernel sizes
     3/9/15 and paddings 1/4/7 is ONE 15-tap convolution: taps [15][Cout][Cin] and one bias."""
@@ -104,8 +140,30 @@ def fold_tcn_taps_any(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
     return fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale)
 
 
-def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None):
-    """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase."""
+_EYE = {}
+
+
+def _eye(V, device):
+    """[1,V,V] identity adjacency (K = 1, A = I turns the graph-conv kernel into a strided 1x1 conv), cached per device."""
+    e = _EYE.get((V, device))
+    if e is None:
+        e = _EYE[(V, device)] = torch.eye(V, device=device, dtype=torch.float32).view(1, V, V)
+    return e
+
+
+def conv_bwd_phases(k, stride):
+    """[(phase, tap offsets, tap selection)] of the data gradient's launches (phases without a tap are left out)."""
+    out = []
+    for phase in range(stride):
+        tl = ops.conv_taps_bwd(k, stride, phase)
+        if tl:
+            out.append((phase, [dj for _, dj in tl], [j for j, _ in tl]))
+    return out
+
+
+def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None, packed=None):
+    """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase.
+    packed: {phase: fragment-packed transposed taps} from a PackPlan (else packed here, one launch per phase)."""
     NM, Tz = dz.shape[0], dz.shape[1]
     out = torch.empty((NM, T_in, V, cin), dtype=dz.dtype, device=dz.device)
     for phase in range(stride):
@@ -118,7 +176,8 @@ def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, sta
             continue
         offs = [dj for _, dj in tl]
         # transposed taps [k][Cin][Cout] as a view; the packer gathers this phase's taps straight from the parameter
-        wp = ops.pack_tconv_weight(w_taps.transpose(1, 2), V, offs, 1, dz.dtype, tap_sel=[j for j, _ in tl])
+        wp = packed[phase] if packed is not None else \
+            ops.pack_tconv_weight(w_taps.transpose(1, 2), V, offs, 1, dz.dtype, tap_sel=[j for j, _ in tl])
         ops.tconv(dz, wp, cin, offs, aux=aux, maux=maux, out=out, stats=stats, mode=0 if aux is None else 1,
                   Tout=T_in, Mlog=Mlog, in_mul=1, out_mul=stride, out_off=phase)
     return out
@@ -176,6 +235,7 @@ class BlockCfg:
         self.width = width                # bottleneck width int(sqrt(C))
         self.momentum, self.eps = momentum, eps
         self.pattern = pattern            # [K,V,V] fp32 sparsity pattern of the adjacency gradient (None: dense)
+        self.packed = None                # dict of fragment-packed weights from the Model's PackPlan (None: pack per call)
 
 
 class STGCNBlockFn(torch.autograd.Function):
@@ -196,7 +256,8 @@ class STGCNBlockFn(torch.autograd.Function):
         A_eff = A_eff.contiguous()
         # 1. graph conv (+ BN1 batch sums)
         st1 = ops.stats_scratch(0, cout, dev) if training else None
-        wp = ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt)
+        pk = cfg.packed or {}
+        wp = pk['wg'] if 'wg' in pk else ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt)
         g = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, stats=st1, nnz_cap=cfg.nnz_cap)
         coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training,
                                 clear=True)
@@ -205,7 +266,7 @@ class STGCNBlockFn(torch.autograd.Function):
         taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
         q = yb = None
         if cfg.tcn == 'conv':
-            wt = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
+            wt = pk['wt'] if 'wt' in pk else ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
             z = ops.tconv(g, wt, cout, taps, bias=bt, pre=coef1[:2].contiguous(), pre_relu=True, stats=st2,
                           Tout=Tz, Mlog=Tz, in_mul=in_mul)
         else:
@@ -224,7 +285,7 @@ class STGCNBlockFn(torch.autograd.Function):
             res, cr = x, None
         elif cfg.residual == 'conv':
             strs = ops.stats_scratch(2, cout, dev) if training else None
-            wr = ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
+            wr = pk['wr'] if 'wr' in pk else ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
             r = ops.tconv(x, wr, cout, [0], bias=br, stats=strs, Tout=Tz, Mlog=Tz, in_mul=s)
             coefr = ops.bn_finalize(strs, NM * Tz * V, gr, betar, bufs['bnr'][0], bufs['bnr'][1], cfg.momentum,
                                     cfg.eps, training, clear=True)
@@ -250,6 +311,7 @@ class STGCNBlockFn(torch.autograd.Function):
         dout = dout.contiguous()
         if dout.dtype != dt:
             dout = dout.to(dt)
+        pk = cfg.packed or {}
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
         dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True)
         abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
@@ -277,7 +339,7 @@ class STGCNBlockFn(torch.autograd.Function):
         buf_r = (arena.take(), arena.take()) if cfg.residual == 'conv' else None
         if cfg.tcn == 'conv':
             dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True, out=buf_t)
-            d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b)
+            d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b, packed=pk.get('wt_bwd'))
         else:
             w = cfg.width
             dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
@@ -300,14 +362,14 @@ class STGCNBlockFn(torch.autograd.Function):
             if need_A and pat is None:
                 pat, cap = torch.ones_like(A_eff), A_eff.numel()
             dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cap, dA_out=buf_A,
-                                      pattern=pat)
+                                      pattern=pat, wb=pk.get('wb'))
         if cfg.residual == 'conv':
             abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training, clear=True)
             dr = ops.affine2(dres, r, abcr)
             dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s, out=buf_r)
             dWr = dWr3.view(cout, cin)
-            eye = torch.eye(V, device=x.device, dtype=torch.float32).view(1, V, V)
-            wrt = ops.pack_gcn_weight(Wr.t().unsqueeze(1), dt)                      # [cin][1][cout] view
+            eye = _eye(V, x.device)
+            wrt = pk['wrt'] if 'wrt' in pk else ops.pack_gcn_weight(Wr.t().unsqueeze(1), dt)     # [cin][1][cout] view
             ops.gcn_forward(dr, eye, wrt, cin, addend=dx, out=dx, Tout=T, out_t_stride=s, nnz_cap=V)
         return (None, None, None, None, dx, dA, (S if ctx.has_b else None), dWg, dg1, db1, dWt, dbt, dg2, db2,
                 dWr, dbr, dgr, dbetar, dWs, dbs, dWe, dbe)

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import functional as Fn
+from .. import ops
 from .utils.graph import Graph
 
 PLAN10 = ((64, 1), (64, 1), (64, 1), (64, 1), (128, 2), (128, 1), (128, 1), (256, 2), (256, 1), (256, 1))
@@ -172,11 +173,13 @@ class STGCNBlock(nn.Module):
         return Fn.run_infer_plan(cache[1], cache[2], x)
 
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
-    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True):
+    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True, packed=None):
         """pattern: [K,V,V] fp32 sparsity pattern of the adjacency gradient (None = dense); seed_base: the Model's
-        per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself."""
+        per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself; packed: this
+        block's fragment-packed weights from the Model's one-launch PackPlan (None: packed per call)."""
         cfg, ((A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar, Ws, bs, We, be), bns) = \
             self._gather(x, A_eff, mst, nnz_cap, bterm, pattern)
+        cfg.packed = packed
         bn1, bn2 = bns[0], bns[1]
         bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
         if len(bns) > 2:
@@ -189,6 +192,26 @@ class STGCNBlock(nn.Module):
             seed = mix_seed(draw_seed() if seed_base is None else seed_base, self.block_index, x.device)
         return Fn.STGCNBlockFn.apply(cfg, training, seed, bufs, x, A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2,
                                      Wr, br, gr, betar, Ws, bs, We, be)
+
+    def pack_jobs(self, plan, V):
+        """Register this block's weight packs with a PackPlan -> dict of the destination tensors (functional.STGCNBlockFn
+        looks them up by name).  Temporal taps that are themselves computed per step (the pre-summed Inception-TCN,
+        net/st_gcn_multi3_fix_3A_mstcn.py:212-215) are not parameters and stay with the per-call packer."""
+        c, cin, K, s = self.cout, self.cin, self.K, self.stride
+        conv = self.gcn.the_conv()
+        Wg3 = conv.weight.view(K, c, cin)
+        d = {'wg': plan.add_gcn(Wg3.permute(1, 0, 2)), 'wb': plan.add_gcn_wb(Wg3)}
+        if self.tcn_kind == 'single':
+            Wt = self.tcn[2].weight.view(c, c, self.tk).permute(2, 0, 1)
+            taps, in_mul = ops.conv_taps_fwd(self.tk, s)
+            d['wt'] = plan.add_tconv(Wt, V, taps, in_mul)
+            d['wt_bwd'] = {ph: plan.add_tconv(Wt.transpose(1, 2), V, offs, 1, tap_sel=sel)
+                           for ph, offs, sel in Fn.conv_bwd_phases(self.tk, s)}
+        if self.res_mode == 'conv':
+            Wr = self.residual[0].weight.view(c, cin)
+            d['wr'] = plan.add_tconv(Wr.view(1, c, cin), V, [0], s)
+            d['wrt'] = plan.add_gcn(Wr.t().unsqueeze(1))
+        return d
 
     def _gather(self, x, A_eff, mst, nnz_cap, bterm, pattern):
         """-> (BlockCfg, ((A_eff, bterm, Wg3, gamma1, beta1, Wt, bt, gamma2, beta2, Wr, br, gamma_r, beta_r, Ws, bs, We, be),
@@ -365,6 +388,35 @@ class STGCNModel(nn.Module):
             return Fn.FoldFn.apply(self._fold_B(imps[0].device), conv.bias, blk.cout, *imps)
         return self._a_eff(i), _UNSET
 
+    def _folded_all(self):
+        """[(A_eff_i, bterm_i)] of every block from ONE launch (Fn.FoldAllFn), or None when the fused fold does not apply
+        (importances that are not GPU parameters, too many blocks / joints): the caller then folds per block."""
+        blocks = list(self.st_gcn_networks)
+        names = ['edge_importance'] + (['edge_importance2', 'edge_importance3'] if self.gcn_kind in ('incep', '3a') else [])
+        imps = [[getattr(self, n)[i] for n in names] for i in range(len(blocks))]
+        K, V = self.A.shape[0], self.A.shape[1]
+        ok = all(isinstance(p, torch.Tensor) and p.is_cuda for imp in imps for p in imp)
+        if not ok or len(blocks) > 16 or K * V > 512 or K * V * V > 12288:
+            return None
+        biases = [blk.gcn.the_conv().bias for blk in blocks]
+        Cs = tuple(blk.cout for blk in blocks)
+        out = Fn.FoldAllFn.apply(self._fold_B(imps[0][0].device), Cs, len(names), *biases, *[p for imp in imps for p in imp])
+        return [(out[2 * i], out[2 * i + 1]) for i in range(len(blocks))]
+
+    def _packed_weights(self, x):
+        """Every weight pack of the trunk in ONE launch per forward (they were ~46 launches per step): the plan is rebuilt
+        when a parameter's storage moved (an optimizer re-pointing `.data` into its flat buffer, `.to()`), the launch is
+        repeated every forward because the optimizer has updated the weights in between."""
+        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        key = (x.dtype, x.device, x.shape[2], ptrs)
+        ent = self.__dict__.get('_pack_plan')
+        if ent is None or ent[0] != key:
+            plan = ops.PackPlan(x.dtype, x.device)
+            ent = (key, plan, [blk.pack_jobs(plan, x.shape[2]) for blk in self.st_gcn_networks])
+            self.__dict__['_pack_plan'] = ent
+        ent[1].run()
+        return ent[2]
+
     def _folded_bias(self, i, blk):
         """(A_eff, bterm) with the bias term resolved (for the inference plan)."""
         A_eff, bterm = self._folded(i, blk)
@@ -397,6 +449,8 @@ class STGCNModel(nn.Module):
             torch._foreach_add_([bn.num_batches_tracked] + [b.num_batches_tracked for blk in self.st_gcn_networks
                                                             for b in blk.batchnorms()], 1)
         infer = (not self.training) and (not torch.is_grad_enabled())
+        packed = None if infer else self._packed_weights(x)
+        folds = None if infer else self._folded_all()
         for i, blk in enumerate(self.st_gcn_networks):
             mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
             if infer:                      # folded BatchNorms, cached plans, 2-4 launches per block
@@ -405,8 +459,9 @@ class STGCNModel(nn.Module):
                 x = blk.infer(x, lambda i=i, blk=blk: self._folded_bias(i, blk),
                               key_extra=[t for t in imps if isinstance(t, torch.Tensor)] + [self.A], mst=mst, nnz_cap=cap)
                 continue
-            A_eff, bterm = self._folded(i, blk)
-            x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False)
+            A_eff, bterm = folds[i] if folds is not None else self._folded(i, blk)
+            x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False,
+                        packed=packed[i])
         return x
 
     def forward(self, x):

@@ -337,7 +337,7 @@ def pack_gcn_wb_ref(w3, dtype):
     return w.to(dtype).contiguous()
 
 
-def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None):
+def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None, wb=None):
     """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None).  pattern [K,V,V] fp32 (non-zero = entry whose
     gradient is wanted; None = the non-zeros of A): pass the constant adjacency of A = B * importance so that an
     importance value of exactly 0 keeps its gradient, or ones for a dense learnable A (autograd of tgcn.py:86)."""
@@ -353,7 +353,8 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
         assert dA.shape == (K, V, V) and dA.dtype == torch.float32 and dA.is_contiguous()
     if addend is not None:
         assert addend.shape == dx.shape and addend.dtype == dy.dtype
-    wb = pack_gcn_wb(w3, dy.dtype)
+    if wb is None:
+        wb = pack_gcn_wb(w3, dy.dtype)
     if nnz_cap is None:
         nnz_cap = K * V * V
     if pattern is not None:
@@ -531,6 +532,41 @@ def fold_bwd(B, imps, bias, dA, S, C):
     return dimps, dbias
 
 
+def _ptr_table(ts):
+    return (ctypes.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
+
+
+def fold_fwd_batch(B, imps, biases, Cs):
+    """All blocks' folds in one launch.  B [J,K,V,V]; imps: nb lists of J tensors; biases: nb tensors or Nones; Cs: nb ints.
+    -> ([A_eff_i] views of one [nb,K,V,V] buffer, [bterm_i or None])."""
+    J, K, V, _ = B.shape
+    nb = len(imps)
+    A_all = torch.empty((nb, K, V, V), dtype=torch.float32, device=B.device)
+    bts = [None if b is None else torch.empty((V, C), dtype=torch.float32, device=B.device) for b, C in zip(biases, Cs)]
+    flat = [t for imp in imps for t in imp]
+    dv = _check_dev(B, A_all, *flat, *[b for b in biases if b is not None])
+    itab = _ptr_table([imp[j] if j < J else None for imp in imps for j in range(3)])
+    _call('istgcn_fold_fwd_batch', nb, _ptr(B), J, itab, _ptr_table(biases), _ptr_table([A_all[i] for i in range(nb)]),
+          _ptr_table(bts), _int_array(Cs), K, V, _stream(B), dev=dv)
+    return [A_all[i] for i in range(nb)], bts
+
+
+def fold_bwd_batch(B, imps, biases, dAs, Ss, Cs):
+    """-> ([[dimp_ij]], [dbias_i or None]) for all blocks in one launch (dAs / Ss entries may be None)."""
+    J, K, V, _ = B.shape
+    nb = len(imps)
+    dimp_all = torch.empty((nb, J, K, V, V), dtype=torch.float32, device=B.device)
+    dbs = []
+    for b, S in zip(biases, Ss):
+        dbs.append(None if b is None else (torch.empty_like(b) if S is not None else torch.zeros_like(b)))
+    dv = _check_dev(B, dimp_all, *[t for imp in imps for t in imp], *[t for t in list(dAs) + list(Ss) if t is not None])
+    itab = _ptr_table([imp[j] if j < J else None for imp in imps for j in range(3)])
+    dtab = _ptr_table([dimp_all[i, j] if j < J else None for i in range(nb) for j in range(3)])
+    _call('istgcn_fold_bwd_batch', nb, _ptr(B), J, itab, _ptr_table(biases), _ptr_table(dAs), _ptr_table(Ss), dtab,
+          _ptr_table([d if S is not None else None for d, S in zip(dbs, Ss)]), _int_array(Cs), K, V, _stream(B), dev=dv)
+    return [[dimp_all[i, j] for j in range(J)] for i in range(nb)], dbs
+
+
 def tcn_fold_fwd(w1, w2, w3, b1, b2, b3, mst, scale):
     """-> (taps [15,Co,Ci], bias [Co]): the 3/9/15-tap branches pre-summed into one 15-tap convolution."""
     Co, Ci = w3.shape[0], w3.shape[1]
@@ -616,3 +652,91 @@ def input_bwd(raw, dout, coef, stats, shift=None, move=None, T=None):
     dv = _check_dev(raw, shift, move, dout, coef, stats)
     _call('istgcn_input_bwd', _ptr(raw), _ptr(shift), _ptr(move), _ptr(dout), _ptr(coef), _ptr(stats), stats.shape[0],
           N, C, Traw, T, V, M, dtype_code(dout), _stream(raw), dev=dv)
+
+
+# ----------------------------------------------------------------------------------------------
+# all weight packs of a model in one launch (pack.hip: istgcn_pack_batch)
+# ----------------------------------------------------------------------------------------------
+class PackPlan:
+    """A table of weight-pack jobs (graph-conv weights, temporal-conv taps forward and per data-gradient phase,
+    graph-conv backward weights) that one launch executes: `add_*` registers a job and returns its persistent
+    destination tensor, `run()` launches (building / uploading the job table on first use).  The parameter views are
+    kept alive and their data pointers recorded: `stale()` tells when a parameter moved (optimizer re-pointing `.data`,
+    `.to()`), in which case the owner builds a new plan."""
+
+    def __init__(self, dtype, device):
+        self.dtype, self.device = dtype, device
+        self.jobs = []                 # (kind, src view, dst, extra)
+        self._table = None
+
+    def add_gcn(self, wr):
+        """wr [Cout][K][Cin] fp32 view -> dst as ops.pack_gcn_weight"""
+        _src_ok(wr)
+        cout, K, cin = wr.shape
+        n = _lib.load().istgcn_pack_gcn_elems(cin, cout, K, _DT[self.dtype])
+        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
+        self.jobs.append((0, wr, dst, None))
+        return dst
+
+    def add_tconv(self, wf, V, tap_off, in_mul, tap_sel=None):
+        """wf [taps][Cout][Cin] fp32 view -> dst as ops.pack_tconv_weight"""
+        _src_ok(wf)
+        if tap_sel is None:
+            tap_sel = list(range(wf.shape[0]))
+        _, cout, cin = wf.shape
+        n = _lib.load().istgcn_pack_tconv_elems(V, cin, cout, len(tap_off), _int_array(tap_off), in_mul, _DT[self.dtype])
+        if n < 0:
+            raise RuntimeError('istgcn_pack_tconv_elems: invalid geometry')
+        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
+        self.jobs.append((1, wf, dst, (V, list(tap_off), in_mul, list(tap_sel))))
+        return dst
+
+    def add_gcn_wb(self, w3):
+        """w3 [K][Cout][Cin] fp32 view -> dst as ops.pack_gcn_wb"""
+        _src_ok(w3)
+        K, cout, cin = w3.shape
+        n = _lib.load().istgcn_pack_gcn_bwd_elems(cin, cout, K, _DT[self.dtype])
+        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
+        self.jobs.append((2, w3, dst, None))
+        return dst
+
+    def stale(self):
+        return self._table is not None and any(src.data_ptr() != ptr for (_, src, _, _), ptr in zip(self.jobs, self._ptrs))
+
+    def _build(self):
+        lib = _lib.load()
+        rb = lib.istgcn_pack_job_bytes()
+        buf = ctypes.create_string_buffer(rb * len(self.jobs))
+        base = ctypes.addressof(buf)
+        starts, total, dc = [], 0, _DT[self.dtype]
+        ll = ctypes.c_longlong
+        for j, (kind, src, dst, extra) in enumerate(self.jobs):
+            rec = ctypes.c_void_p(base + j * rb)
+            st = src.stride()
+            if kind == 0:
+                cout, K, cin = src.shape
+                nb = lib.istgcn_pack_job_gcn(rec, _ptr(src), ll(st[0]), ll(st[1]), ll(st[2]), _ptr(dst), cin, cout, K, dc)
+            elif kind == 1:
+                V, tap_off, in_mul, tap_sel = extra
+                _, cout, cin = src.shape
+                nb = lib.istgcn_pack_job_tconv(rec, _ptr(src), ll(st[0]), ll(st[1]), ll(st[2]), _int_array(tap_sel), _ptr(dst),
+                                               V, cin, cout, len(tap_off), _int_array(tap_off), in_mul, dc)
+            else:
+                K, cout, cin = src.shape
+                nb = lib.istgcn_pack_job_gcn_bwd(rec, _ptr(src), ll(st[0]), ll(st[1]), ll(st[2]), _ptr(dst), cin, cout, K, dc)
+            if nb < 0:
+                raise RuntimeError('istgcn_pack_job: invalid job %d' % j)
+            starts.append(total)
+            total += nb
+        self._ptrs = [src.data_ptr() for _, src, _, _ in self.jobs]
+        self._table = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(self.device)
+        self._starts = torch.tensor(starts, dtype=torch.int32).to(self.device)
+        self._total = total
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self._table is None:
+            self._build()
+        _call('istgcn_pack_batch', _ptr(self._table), _ptr(self._starts), len(self.jobs), self._total, _DT[self.dtype],
+              _stream(self._table), dev=self.device)
