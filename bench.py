@@ -201,17 +201,18 @@ def main():
     else:
         roof = {'bound': 'hbm', 'achieved': round(nbytes / secs / 1e9, 1), 'peak': PEAK['hbm'], 'unit': 'GB/s'}
     roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
-    # HBM bytes per launch of that kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of this
-    # command, corrected as MI355X_MICROARCH.md prescribes; profiles/r01_final_bf16_pmc_traffic.json) -- only for the
-    # configuration they were collected on
+    # HBM bytes per launch and MFMA-pipe utilisation of that kernel family from the PMC passes of the same command
+    # (tools/profile_bench.sh: FETCH_SIZE / WRITE_SIZE / SQ_* in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md
+    # prescribes; summary committed under profiles/) -- only for the configuration they were collected on
     roof['traffic'] = None
     roof['algorithmic_bytes_per_launch'] = round(nbytes / n)
-    pmc_file = os.path.join(ROOT, 'profiles', 'r01_final_bf16_pmc_traffic.json')
+    pmc_file = os.path.join(ROOT, 'profiles', 'r02_final_bf16_pmc.json')
     if dt == torch.bfloat16 and args.model == 'st_gcn_msgcn' and B == 64 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))['kernels'].get(PMC_KEY.get(dom, ''))
         if pmc:
-            roof['traffic'] = pmc['hbm_bytes_avg']
-            roof['traffic_source'] = 'profiles/r01_final_bf16_pmc_traffic.json'
+            roof['traffic'] = pmc.get('hbm_bytes_avg')
+            roof['mfma_util'] = pmc.get('mfma_util')
+            roof['pmc_source'] = 'profiles/r02_final_bf16_pmc.json'
     roof['kernel'] = FAMILY.get(dom, dom)
     roof['launches'] = n
     roof['avg_launch_ms'] = round(secs / n * 1e3, 4)

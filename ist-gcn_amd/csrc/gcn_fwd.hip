@@ -1,18 +1,33 @@
 // Graph-convolution unit, forward: y = einsum('nkctv,kvw->nctw', conv1x1(x), A)  (+ per-joint bias term)
 // computed aggregate-first:
-//     xa[p=(t,w)][(k,i)] = sum_v A[k][v][w] * x[(t,v)][i]          sparse VALU pass, LDS -> LDS
+//     xa[p=(t,w)][(k,i)] = sum_v A[k][v][w] * x[(t,v)][i]          LDS -> LDS (16-bit: MFMA, fp32: sparse VALU pass)
 //     y[p][c]            = sum_(k,i) Wr[c][(k,i)] * xa[p][(k,i)]   MFMA 32x32, fp32 accumulate
 // Replaces (reference file:line): net/utils/tgcn.py:76-89, net/utils/tgcn_multi3_fix_3A.py:76-92,
 // net/utils/inceptionv2_gcn.py:64-89 (all variants fold into one effective adjacency A, host side),
 // and -- with K=1, A=I and a frame stride -- the residual 1x1 strided Conv2d of st_gcnold.py:186-193.
 // The same kernel run on dy with A^T and the transposed weights is the unit's data gradient.
 //
-// One workgroup (4 waves) owns a tile of F = floor(128/V) whole frames of one sequence (<=128 rows
-// of the NTVC tensor, contiguous in HBM) x all output channels of its grid.y block; workgroups walk
-// tiles in a grid-stride loop so that the adjacency lists, BatchNorm partial sums and the
-// weight-fragment working set are amortised.  Wave w owns rows [32w, 32w+32) (the MFMA "column" axis);
-// output channels are the MFMA "row" axis, so each lane ends up with 4 consecutive channels of one
-// row per register quad, which is what the LDS-staged, fully coalesced epilogue wants.
+// A workgroup owns tiles of F = floor(128/V) whole frames of one sequence (<= 128 rows of the NTVC tensor, contiguous
+// in HBM) x up to 128 output channels (its grid.y block) and walks tiles in a grid-stride loop so that the adjacency
+// tables, BatchNorm partial sums and the weight working set are amortised.  Output channels are the MFMA "row" axis,
+// positions the "column" axis, so each lane ends up with 4 consecutive channels of one row per register quad.
+//
+// Wave specialisation (round 2; the scheme of tconv.hip).  Round 1 ran stage -> barrier -> aggregate -> barrier ->
+// contract -> barrier -> epilogue in sequence on two 4-wave workgroups per CU: its SQ counters showed the MFMA pipe 15 %
+// busy and half of all wave-cycles parked on memory or barriers.  Now ONE workgroup of EIGHT waves per CU:
+//   waves 0-3 "compute": the channel contraction; weight fragments come from L2 through a register ring that runs
+//             continuously across chunks and tiles, activation fragments two steps ahead;
+//   waves 4-7 "memory":  the x chunk of the item after next is in flight in registers, the next item's chunk goes
+//             registers -> LDS (double-buffered), the previous tile's output image goes LDS -> HBM (+ addend, BN sums);
+//   all eight share the aggregation (LDS -> LDS), which is a latency chain per (frame, channel tile, k) unit.
+// An ITEM is one (tile, input-channel chunk) pair.  Two barriers per item:
+//     B1  chunk staged, previous contraction done     memory: store image, prefetch; then all: aggregate chunk -> xa
+//     B2  xa complete                                  compute: contract (+ image at the     memory: next chunk -> LDS
+//                                                               tile's last chunk)
+// Measured with the ISTGCN_GCN_ABL switches (64->64, T=300, bf16; DESIGN.md has the table): the first wave-specialised
+// build spent 40 us of 153 in the one-time setup (two passes of V dependent global loads per adjacency column) and
+// ~45 scalar bookkeeping instructions per contraction step (ring position, chunk wrap, ghost steps); hence the LDS copy
+// of A below and the round-based ring whose loads carry immediate offsets from two uniform base pointers.
 #include "common.hpp"
 
 namespace {
@@ -32,19 +47,41 @@ struct GcnFwdParams {
   int F, tiles_per_seq, total_tiles;
   int CCeff, nch, KKp, NKG, MTtot;
   int xs_stride, xa_stride, out_stride, xs_rows;   // in elements / rows
-  int off_csr_v, off_csr_a, off_stat, off_rows, off_afrag, off_work;  // LDS byte offsets
+  int gx_div, gx_mod;    // gridDim.x = gx_div * tiles_per_seq + gx_mod (item cursors advance without dividing)
+  int a_lds;             // the adjacency fits the work buffers: setup reads it from an LDS copy
+  unsigned long long* dbg;  // diagnostic: per-phase cycle sums of workgroup 0 (ISTGCN_GCN_DBG)
+  int abl;               // diagnostic ablation mask (ISTGCN_GCN_ABL): 1 no aggregation, 2 no contraction, 4 no image store, 8 no input loads/commit
+  int off_csr_v, off_csr_a, off_stat, off_rows, off_afrag, off_bterm, off_xs0, off_xs1, off_xa, off_o;  // LDS byte offsets
 };
 
 constexpr int TILE_ROWS = 128;
-constexpr int NTHREADS = 256;
+constexpr int NROLE = 256;           // threads per role (4 waves)
+constexpr int NTH = 2 * NROLE;
+constexpr int UL = 4;                // 16-byte vectors of a chunk per memory-wave thread (128 rows x <= 8 vectors / 256)
+
+struct Tile { int n, t0, nf, rows; bool valid; };
+
+// Depth of the weight-fragment ring in steps: DA-1 steps of matrix work must outlast an L2 round trip.  A step is
+// MH*NTW = 4 MFMA groups with four channel tiles but only 2 (MT = 2) or 1 (MT = 1), so those rings are twice as deep
+// (and their fragments are half as many per step: the same registers).  The geometry pads the contraction length to whole
+// rounds of DA steps.
+template <int MT> struct GcnRing { static constexpr int DA = MT >= 4 ? 6 : 12; };
+inline int gcn_ring_steps(int MT) { return MT >= 4 ? 6 : 12; }
+
+__device__ static inline void lds_barrier() {
+  // LDS traffic of this wave retired, then the workgroup barrier.  NOT __syncthreads(): its fence drains vmcnt(0), which
+  // would wait for the prefetches both roles deliberately keep in flight across barriers.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <typename T, int MT, bool VEC_IN, bool VEC_OUT>
-__global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(const GcnFwdParams P) {
+__global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   constexpr int KGS = E::KGS;
   typedef typename E::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (P.abl & 256) return;
 
   int* csr_off = reinterpret_cast<int*>(smem);                       // [K*V+1]
   unsigned char* csr_v = smem + P.off_csr_v;                         // [nnz_cap]
@@ -54,362 +91,654 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
   unsigned char* row_w = row_f + TILE_ROWS;                          // [128]
   unsigned char* col_k = row_w + TILE_ROWS;                          // [K*V]
   unsigned char* col_w = col_k + P.K * P.V;                          // [K*V]
-  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);               // bf16 only: [K][2][64][8] MFMA fragments of A_k
-  T* xs = reinterpret_cast<T*>(smem + P.off_work);                   // [xs_rows][xs_stride]
-  T* xa = xs + P.xs_rows * P.xs_stride;                              // [128][xa_stride]
-  T* outs = xs;                                                      // [128][out_stride] (aliases xs/xa)
+  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);               // 16-bit only: [K][2][64][8] MFMA fragments of A_k
+  float* bterm_l = reinterpret_cast<float*>(smem + P.off_bterm);     // [V][BTS] bias term of this channel block
+  constexpr int BTS = MT * 32 + 4;                                   // row stride: 4 banks apart (an unpadded row put all 32 joints on one bank)
+  // the two halves of the x chunk buffer, [xs_rows][xs_stride] each: always smem + offset (a select between two POINTERS
+  // makes the compiler lose the LDS address space and emit flat loads)
+  auto xsbuf = [&](int half) __attribute__((always_inline)) {
+    return reinterpret_cast<T*>(smem + (half ? P.off_xs1 : P.off_xs0));
+  };
+  T* xa = reinterpret_cast<T*>(smem + P.off_xa);                     // [128][xa_stride]
+  T* outs = reinterpret_cast<T*>(smem + P.off_o);                    // [128][OSTR]
+  constexpr int OSTR = MT * 32 + EPL;                                // image row stride in elements
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; tell the compiler
+  const bool is_compute = wave8 < 4;
+  const int ltid = tid & (NROLE - 1), wave = wave8 & 3;
   const int V = P.V, K = P.K;
   const int KV = K * V;
-  constexpr bool MSPLIT = (MT % 2) == 0;
-  constexpr int MH = MSPLIT ? MT / 2 : MT;           // channel tiles per wave
-  constexpr int NTW = MSPLIT ? 2 : 1;                // 32-row tiles per wave
-  const int ph = MSPLIT ? (wave & 1) : wave, mh = MSPLIT ? (wave >> 1) : 0;
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
+  const int Q = P.CCeff / EPL;            // channel vectors per chunk row (<= 8)
+  const int NV = P.KKp / EPL;             // vectors per xa row (incl. zero padding)
 
-  // ---- one-time setup: CSR lists of the adjacency columns, row tables, stat accumulators ----
-  for (int c = tid; c <= KV; c += NTHREADS) csr_off[c] = 0;
-  for (int c = tid; c < 2 * MT * 32; c += NTHREADS) stat[c] = 0.f;
-  for (int r = tid; r < TILE_ROWS; r += NTHREADS) {
+  // ---- one-time setup: adjacency -> LDS scratch (ONE coalesced round trip; the work buffers are not in use yet), then
+  //      the CSR lists of its columns, the MFMA fragments of A_k, row tables, stat accumulators, bias term.  (Reading A
+  //      from global memory inside the per-column loops -- two passes of V dependent loads -- cost 30 us per launch.) ----
+  float* Asc = reinterpret_cast<float*>(smem + P.off_xs0);
+  if (P.a_lds) for (int idx = tid; idx < KV * V; idx += NTH) Asc[idx] = P.A[idx];
+  if (tid == 0) csr_off[0] = 0;
+  for (int c = tid; c < 2 * MT * 32; c += NTH) stat[c] = 0.f;
+  for (int r = tid; r < TILE_ROWS; r += NTH) {
     int f = r / V;
     row_f[r] = (unsigned char)f;
     row_w[r] = (unsigned char)(r - f * V);
   }
-  __syncthreads();
-  for (int col = tid; col < KV; col += NTHREADS) {
-    int k = col / V, w = col - k * V, cnt = 0;
-    col_k[col] = (unsigned char)k;
-    col_w[col] = (unsigned char)w;
-    for (int v = 0; v < V; ++v) cnt += (P.A[(k * V + v) * V + w] != 0.f);
-    csr_off[col + 1] = cnt;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int c = 0; c < KV; ++c) { int n = csr_off[c + 1]; csr_off[c] = run; run += n; }
-    csr_off[KV] = run;
-    if (run > P.nnz_cap && P.status) *P.status = 1;
-  }
-  __syncthreads();
-  for (int col = tid; col < KV; col += NTHREADS) {
-    int k = col / V, w = col - k * V, e = csr_off[col];
-    for (int v = 0; v < V; ++v) {
-      float a = P.A[(k * V + v) * V + w];
-      if (a != 0.f) {
-        if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
-        ++e;
-      }
+  if (P.bterm) {
+    for (int idx = tid; idx < V * MT * 32; idx += NTH) {
+      const int w = idx / (MT * 32), c = idx - w * (MT * 32);
+      bterm_l[w * BTS + c] = (cbase_blk + c < P.Cout) ? P.bterm[w * P.Cout + cbase_blk + c] : 0.f;
     }
   }
   __syncthreads();
-
-  if constexpr (sizeof(T) == 2) {
-    // B-operand fragments of the adjacency for the MFMA aggregation: lane (w = lane&31, h = lane>>5), k-step s,
-    // element j holds A[k][v = 16s + 8h + j][w] (zero outside the V x V block)
-    for (int idx = tid; idx < K * 2 * 64; idx += NTHREADS) {
-      const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
-      const int w = ln & 31, h = ln >> 5;
-      frag_t fr;
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        const int v = 16 * sstep + 8 * h + j;
-        fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
-      }
-      *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
+  auto build_tables = [&](auto Aat) __attribute__((always_inline)) {
+    for (int col = tid; col < KV; col += NTH) {
+      int k = col / V, w = col - k * V, cnt = 0;
+      col_k[col] = (unsigned char)k;
+      col_w[col] = (unsigned char)w;
+      for (int v = 0; v < V; ++v) cnt += (Aat((k * V + v) * V + w) != 0.f);
+      csr_off[col + 1] = cnt;
     }
     __syncthreads();
+    if (wave8 == 0) {
+      // exclusive scan of the column counts, 64 columns per step (reads of a step precede its writes: one wave, in order)
+      int carry = 0;
+      for (int base = 0; base < KV; base += 64) {
+        const int c = base + lane;
+        const int v = c < KV ? csr_off[c + 1] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int tsh = __shfl_up(incl, o);
+          if (lane >= o) incl += tsh;
+        }
+        const int tot = __shfl(incl, 63);
+        if (c < KV && c > 0) csr_off[c] = carry + incl - v;
+        carry += tot;
+      }
+      if (lane == 0) {
+        csr_off[KV] = carry;
+        if (carry > P.nnz_cap && P.status) *P.status = 1;
+      }
+    }
+    __syncthreads();
+    for (int col = tid; col < KV; col += NTH) {
+      int k = col / V, w = col - k * V, e = csr_off[col];
+      for (int v = 0; v < V; ++v) {
+        float a = Aat((k * V + v) * V + w);
+        if (a != 0.f) {
+          if (e < P.nnz_cap) { csr_v[e] = (unsigned char)v; csr_a[e] = a; }
+          ++e;
+        }
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      // B-operand fragments of the adjacency for the MFMA aggregation: lane (w = lane&31, h = lane>>5), k-step s,
+      // element j holds A[k][v = 16s + 8h + j][w] (zero outside the V x V block)
+      for (int idx = tid; idx < K * 2 * 64; idx += NTH) {
+        const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
+        const int w = ln & 31, h = ln >> 5;
+        frag_t fr;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+          const int v = 16 * sstep + 8 * h + j;
+          fr[j] = E::from_f((v < V && w < V) ? Aat((k * V + v) * V + w) : 0.f);
+        }
+        *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
+      }
+    }
+  };
+  // two instantiations, not one accessor that selects between an LDS and a global pointer (that becomes a flat load)
+  if (P.a_lds) build_tables([&](int idx) __attribute__((always_inline)) { return Asc[idx]; });
+  else build_tables([&](int idx) __attribute__((always_inline)) { return P.A[idx]; });
+  __syncthreads();                                                    // the scratch copy of A is dead from here
+  {
+    // both chunk halves start as zeros: the rows behind the 128 data rows (the 16-bit aggregation reads a 32-row range
+    // per frame) are never written again; everything else is rewritten per item
+    const int nvec = 2 * P.xs_rows * (P.xs_stride / EPL);
+    T* x0 = xsbuf(0);                                                 // the halves are adjacent
+    for (int idx = tid; idx < nvec; idx += NTH) {
+      frag_t z;
+      zero_frag<T>(z);
+      *reinterpret_cast<frag_t*>(x0 + idx * EPL) = z;
+    }
+    // contraction padding columns of xa (K * CCeff is padded to whole ring rounds) must be finite: zeroed once
+    if (NV > K * Q) {
+      const int padv = NV - K * Q;
+      for (int idx = tid; idx < TILE_ROWS * padv; idx += NTH) {
+        const int r = idx / padv, c = idx - r * padv;
+        frag_t z;
+        zero_frag<T>(z);
+        *reinterpret_cast<frag_t*>(xa + r * P.xa_stride + (K * Q + c) * EPL) = z;
+      }
+    }
   }
-  const int Q = P.CCeff / EPL;            // channel vectors per partition
-  const int NV = P.KKp / EPL;             // vectors per xa row (incl. zero padding)
+  __syncthreads();
+  if (P.abl & 512) return;
+
   const T* xg = reinterpret_cast<const T*>(P.x);
   const T* Wp = reinterpret_cast<const T*>(P.Wp);
   T* yg = reinterpret_cast<T*>(P.y);
   const T* addg = reinterpret_cast<const T*>(P.addend);
 
-  // BatchNorm partial sums: a thread always copies out the same channel vector, so it keeps its sums in registers for
-  // the whole grid-stride walk and the cross-lane reduction happens once per workgroup, not once per tile
-  constexpr int NPASS_ = (MT + 1) / 2;
-  float st1[NPASS_][EPL], st2[NPASS_][EPL];
-#pragma unroll
-  for (int ps = 0; ps < NPASS_; ++ps)
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) { st1[ps][j] = 0.f; st2[ps][j] = 0.f; }
+  // ---- item cursors.  An ITEM is (tile, chunk); a workgroup's tiles are blockIdx.x + k * gridDim.x.  Every phase of the
+  //      loop used to re-derive (sequence, first frame, rows) of its item by two integer divisions -- ~40 vector
+  //      instructions each, several times per item and role.  A cursor is advanced with a handful of scalar operations
+  //      instead: gridDim.x = gx_div * tiles_per_seq + gx_mod (host side). ----
+  struct Cur { int n, tq, ch; };
+  const int nch = P.nch;
+  const int ntile_w = (P.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+  const int total_items = ntile_w * nch;
+  auto cur_first = [&]() __attribute__((always_inline)) {
+    Cur c;
+    c.n = (int)blockIdx.x / P.tiles_per_seq;
+    c.tq = (int)blockIdx.x - c.n * P.tiles_per_seq;
+    c.ch = 0;
+    return c;
+  };
+  auto cur_next_tile = [&](Cur& c) __attribute__((always_inline)) {
+    c.n += P.gx_div;
+    c.tq += P.gx_mod;
+    if (c.tq >= P.tiles_per_seq) { c.tq -= P.tiles_per_seq; ++c.n; }
+  };
+  auto cur_next = [&](Cur& c) __attribute__((always_inline)) {
+    if (++c.ch == nch) { c.ch = 0; cur_next_tile(c); }
+  };
+  auto cur_nf = [&](const Cur& c) __attribute__((always_inline)) {      // frames of the tile; 0 beyond the last tile
+    return c.n < P.NM ? min(P.F, P.Tlog - c.tq * P.F) : 0;
+  };
 
-  for (int tile = blockIdx.x; tile < P.total_tiles; tile += gridDim.x) {
-    const int n = tile / P.tiles_per_seq;
-    const int t0 = (tile - n * P.tiles_per_seq) * P.F;
-    const int nf = min(P.F, P.Tlog - t0);
-    const int rows = nf * V;
+  // Wave decomposition of the contraction: with an even number of channel tiles the four compute waves split 2 (64-row
+  // halves) x 2 (channel-tile halves), so a weight fragment feeds TWO MFMAs -- one fragment per MFMA asks the vector
+  // L1 for 128 B/clk per CU, twice what it delivers.  (Odd MT: one 32-row slab and all tiles per wave.)
+  constexpr bool MSPLIT = (MT % 2) == 0;
+  constexpr int MH = MSPLIT ? MT / 2 : MT;           // channel tiles per wave
+  constexpr int NTW = MSPLIT ? 2 : 1;                // 32-row tiles per wave
 
-    // Wave decomposition of the contraction: with an even number of channel tiles the four waves split 2 (64-row
-    // halves) x 2 (channel-tile halves), so a weight fragment feeds TWO MFMAs -- one fragment per MFMA asks the vector
-    // L1 for 128 B/clk per CU, twice what it delivers.  (Odd MT: one 32-row slab and all tiles per wave, as before.)
-    // accumulators start at the bias term bterm[w][c] of their (row, channel): loads issued here, behind the staging
-    f32x16 acc[MH][NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int p = ph * 32 * NTW + t * 32 + (lane & 31);
-      const bool rowb = P.bterm && p < rows;
-      const float* brow = P.bterm + (rowb ? (int)row_w[p] : 0) * P.Cout + cbase_blk + 4 * (lane >> 5);
-#pragma unroll
-      for (int m = 0; m < MH; ++m) {
-        const int mg = mh * MH + m;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          const int cg = cbase_blk + mg * 32 + 8 * g + 4 * (lane >> 5);
-          if (rowb) {
-            if (VEC_OUT && cg + 3 < P.Cout) {
-              const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + mg * 32 + 8 * g);
-              bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) if (cg + j < P.Cout) bv[j] = brow[mg * 32 + 8 * g + j];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[m][t][4 * g + j] = bv[j];
-        }
-      }
-    }
-
-    for (int ch = 0; ch < P.nch; ++ch) {
-      const int cb = ch * P.CCeff;
-      // ---- stage x chunk: rows x CCeff channels -> xs (zero beyond Cin) ----
-      if (P.in_t_stride == 1) {
-        stage_block<T, 8, VEC_IN>(xg + ((size_t)(n * P.Tin + t0) * V) * P.Cin + cb, (size_t)P.Cin, P.Cin - cb, xs,
-                                  P.xs_stride, rows, 0, rows, Q, nullptr, nullptr, 0, tid, NTHREADS);
-      } else {
-        const int tot = rows * Q;
-        for (int it = tid; it < tot; it += NTHREADS) {
-          int r = it / Q, q = it - r * Q;
-          int f = row_f[r], v = row_w[r];
-          size_t g = ((size_t)(n * P.Tin + (t0 + f) * P.in_t_stride) * V + v) * P.Cin + cb + q * EPL;
-          frag_t val;
-          if (VEC_IN) {
-            if (cb + q * EPL < P.Cin) val = *reinterpret_cast<const frag_t*>(xg + g);
-            else zero_frag<T>(val);
-          } else {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) val[j] = (cb + q * EPL + j < P.Cin) ? xg[g + j] : E::from_f(0.f);
-          }
-          *reinterpret_cast<frag_t*>(xs + r * P.xs_stride + q * EPL) = val;
-        }
-      }
-      __syncthreads();
-      // weight fragments of the first ring slots: fetched now, in flight during the aggregation (which touches only LDS).
-      // The contraction loop is 12 k-groups long; an L2 round trip in front of its first MFMA was most of its time.
-      constexpr int DEPTH = sizeof(T) == 4 ? 2 : (MT <= 2 ? 4 : (MT <= 4 ? 3 : 2));
-      const T* wfrag = Wp + ((size_t)(ch * P.MTtot + mt0) * P.NKG * 64 + lane) * EPL;
-      auto load_a = [&](int kg, frag_t (&a)[MH]) {
-#pragma unroll
-        for (int m = 0; m < MH; ++m)
-          a[m] = *reinterpret_cast<const frag_t*>(wfrag + ((size_t)(mh * MH + m) * P.NKG + kg) * 64 * EPL);
+  // ---------------- aggregation xs -> xa, shared by all eight waves (w8 = 0..7) ----------------
+  // lane constants of the 16-bit path (addresses are lane part + a wave-uniform part per unit)
+  const int a_grp = lane >> 4, a_h = a_grp >> 1, a_cblk = (a_grp & 1) * 16, a_q4 = (lane & 15) >> 2, a_pp = lane & 3;
+  const int a_w = lane & 31;
+  const int a_src = (8 * a_h + a_q4) * P.xs_stride + a_cblk + 4 * a_pp;       // element offset in the chunk (k-step 0, low half)
+  const int a_dst = a_w * P.xa_stride + 4 * (lane >> 5);                      // element offset in xa (frame 0, k 0, channel tile 0)
+  const int CT = (P.CCeff + 31) >> 5;
+  const int NC = CT * K;                                                      // unit columns (channel tile, partition)
+  const unsigned rcpK = (65536u + K - 1) / K;                                 // c / K for c < 256 as (c * rcpK) >> 16
+  // u / nf for the two tile heights that occur (full tiles, the last tile of a sequence)
+  const int nf_tail = P.Tlog - (P.tiles_per_seq - 1) * P.F;
+  const unsigned rcpF = ((1u << 20) + P.F - 1) / P.F, rcpTail = ((1u << 20) + nf_tail - 1) / nf_tail;
+  auto aggregate = [&](const T* xs, int nf, int w8) __attribute__((always_inline)) {
+    if (P.abl & 1) return;
+    if constexpr (sizeof(T) == 2) if (V <= 32) {
+      // 16-bit: aggregation on the matrix cores.  Per unit (column c = (channel tile ct, partition k), frame f):
+      // D[i][w] = sum_v x[(f,v)][i] * A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows
+      // v beyond the frame multiply zero adjacency rows and are kept finite by the memory waves), A_k fragments from LDS;
+      // the VALU version of this pass cost ~2500 instructions per wave and tile (conversions + addressing) against 24
+      // MFMAs of real work.  A unit is one dependent chain (LDS reads -> 2 MFMAs -> convert -> LDS writes) and the phase
+      // is bound by INSTRUCTION ISSUE (two waves share a SIMD), so: units are ordered column-major (frames fastest),
+      // each wave takes one contiguous range -- two twelfths per compute wave, one per memory wave, which enters late --
+      // and walks it with two address increments per unit; the A_k fragments are re-read only when the column changes;
+      // two units are in flight per wave (the MFMAs of the next one are issued before this one's conversions).
+      const int nunit = nf * NC;
+      const int pre0 = w8 < 4 ? 2 * w8 : 4 + w8, pre1 = w8 < 4 ? pre0 + 2 : pre0 + 1;
+      const int u0 = nunit * pre0 / 12, u1 = nunit * pre1 / 12;
+      int n = u1 - u0;
+      if (n <= 0) return;
+      int c = (int)(((unsigned)u0 * (nf == P.F ? rcpF : rcpTail)) >> 20), f = u0 - c * nf;
+      int afe = 0, srce = 0, dste = 0, lim = 0;
+      bool full = false;
+      auto column = [&]() __attribute__((always_inline)) {
+        const int ct = (int)(((unsigned)c * rcpK) >> 16), kk = c - ct * K;
+        afe = kk * (2 * 64 * EPL) + lane * EPL;
+        srce = f * V * P.xs_stride + ct * 32 + a_src;
+        dste = f * V * P.xa_stride + kk * P.CCeff + ct * 32 + a_dst;
+        full = P.CCeff - ct * 32 >= 32;
+        // channels of the chunk at or above this lane's first quad (quad g is channel i0 + 8g); adjacency columns
+        // w >= V have nothing to write
+        lim = a_w < V ? P.CCeff - ct * 32 - 4 * (lane >> 5) : 0;
       };
-      MfmaRing<DEPTH, MH, NTW, frag_t> ring;
-      ring_prime_a(ring, P.NKG, load_a);
-      bool agg_done = false;
-      if constexpr (sizeof(T) == 2) if (V <= 32) {
-        agg_done = true;
-        // ---- bf16: aggregation on the matrix cores.  Per (frame f, 32-channel tile ct): D[i][w] = sum_v x[(f,v)][i] *
-        //      A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows v beyond the frame
-        //      multiply zero adjacency rows), A_k fragments from LDS; the VALU version of this pass cost ~2500
-        //      instructions per wave and tile (conversions + addressing) against 24 MFMAs of real work. ----
-        const int CT = (P.CCeff + 31) >> 5;
-        const int npair = nf * CT;
-        const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
-        const int q4 = (lane & 15) >> 2, pp = lane & 3;
-        // the last frame's 32-row k-range reaches rows [rows, (nf-1)*V + 32): keep them finite (they meet zero adjacency)
-        const int zrows = (nf - 1) * V + 32 - rows, zq = P.xs_stride / EPL;
-        for (int idx = tid; idx < zrows * zq; idx += NTHREADS) {
-          frag_t z;
-          zero_frag<T>(z);
-          *reinterpret_cast<frag_t*>(xs + (rows + idx / zq) * P.xs_stride + (idx % zq) * EPL) = z;
-        }
-        __syncthreads();
-        for (int pr = wave; pr < npair; pr += 4) {
-          const int f = pr / CT, ct = pr - f * CT;
-          frag_t a[2];
+      column();
+      // Waves issue in order, so the chain is cut into three stages that run one unit apart:
+      //   rd(u+2)  six LDS reads into operand set (u+2)&1      mm(u+1)  two MFMAs on the set read one round earlier
+      //   put(u)   convert + four LDS writes of the accumulators issued one round earlier
+      struct Ops { frag_t x0, x1, b0, b1; int o, l; bool fl; };
+      auto rd = [&](Ops& q) __attribute__((always_inline)) {
+        const T* r0 = xs + srce;
+        q.x0 = tr_pair<T>(r0, r0 + 4 * P.xs_stride);
+        q.x1 = tr_pair<T>(r0 + 16 * P.xs_stride, r0 + 20 * P.xs_stride);
+        q.b0 = *reinterpret_cast<const frag_t*>(afrag + afe);
+        q.b1 = *reinterpret_cast<const frag_t*>(afrag + afe + 64 * EPL);
+        q.o = dste; q.l = lim; q.fl = full;
+        srce += V * P.xs_stride;                            // next frame of the column ...
+        dste += V * P.xa_stride;
+        if (++f == nf) { f = 0; ++c; column(); }            // ... or the next column (harmless one past the range)
+      };
+      auto mm = [&](const Ops& q, f32x16& d) __attribute__((always_inline)) {
 #pragma unroll
-          for (int sstep = 0; sstep < 2; ++sstep) {
-            const T* r0 = xs + (f * V + 16 * sstep + 8 * h + q4) * P.xs_stride + ct * 32 + cblk + 4 * pp;
-            a[sstep] = tr_pair<T>(r0, r0 + 4 * P.xs_stride);
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        mma_kgroup(d, q.x0, q.b0);
+        mma_kgroup(d, q.x1, q.b1);
+      };
+      auto put = [&](const f32x16& d, int o, int l, bool fl) __attribute__((always_inline)) {
+        if (fl) {
+          if (l > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+              store4(xa + o + 8 * g, v4);
+            }
           }
-          const int w = lane & 31;
-          for (int k = 0; k < K; ++k) {
-            f32x16 d;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            const frag_t b0 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 0) * 64 + lane) * EPL);
-            const frag_t b1 = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + 1) * 64 + lane) * EPL);
-            mma_kgroup(d, a[0], b0);
-            mma_kgroup(d, a[1], b1);
-            if (w < V) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int i0 = ct * 32 + 8 * g + 4 * (lane >> 5);
-                if (i0 < P.CCeff) {
-                  float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-                  store4(xa + (f * V + w) * P.xa_stride + k * P.CCeff + i0, v4);
-                }
-              }
+          for (int g = 0; g < 4; ++g) {
+            if (8 * g < l) {
+              float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+              store4(xa + o + 8 * g, v4);
             }
           }
         }
+      };
+      Ops qa, qb;
+      f32x16 d0, d1;
+      rd(qa);
+      if (n > 1) rd(qb);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(qa, d0);
+      int oa = qa.o, la = qa.l, ob = 0, lb = 0;
+      bool fa = qa.fl, fb = false;
+      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < n; i += 2) {
+        // even unit i: its MFMAs are in flight in d0, the operands of i+1 in qb
+        if (i + 2 < n) rd(qa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < n) { mm(qb, d1); ob = qb.o; lb = qb.l; fb = qb.fl; }
+        __builtin_amdgcn_sched_barrier(0);
+        put(d0, oa, la, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 >= n) break;
+        // odd unit i+1
+        if (i + 3 < n) rd(qb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < n) { mm(qa, d0); oa = qa.o; la = qa.l; fa = qa.fl; }
+        __builtin_amdgcn_sched_barrier(0);
+        put(d1, ob, lb, fb);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (!agg_done) {
-      // ---- sparse aggregation xs -> xa.  Wave w owns adjacency columns col = w, w+4, ... (their compressed lists are
-        //      wave-uniform: no divergence, LDS broadcast reads); lanes span (frame, channel vector).  Rows >= rows are
-        //      never written: they only feed output rows that are never stored. ----
-        {
-          const int npair = nf * Q;
-          for (int col = wave; col < KV; col += 4) {
-            const int k = col_k[col], w = col_w[col];
-            const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
-            for (int pr = lane; pr < npair; pr += 64) {
-              const int f = pr / Q, q = pr - f * Q;
-              const T* xrow = xs + (f * V) * P.xs_stride + q * EPL;
-              float sum[EPL];
-#pragma unroll
-              for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
-              for (int e = e0; e < e1; ++e) {
-                const float a = csr_a[e];
-                const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[e] * P.xs_stride);
-#pragma unroll
-                for (int j = 0; j < EPL; ++j) sum[j] += a * E::to_f(xv[j]);
-              }
-              frag_t o;
-#pragma unroll
-              for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
-              *reinterpret_cast<frag_t*>(xa + (f * V + w) * P.xa_stride + k * P.CCeff + q * EPL) = o;
-            }
-          }
-        }
-      }
-      {
-        if (NV > K * Q) {          // contraction padding columns (tiny Cin only) must be finite: zero them
-          const int padv = NV - K * Q;
-          for (int idx = tid; idx < TILE_ROWS * padv; idx += NTHREADS) {
-            const int r = idx / padv, c = idx - r * padv;
-            frag_t o;
-            zero_frag<T>(o);
-            *reinterpret_cast<frag_t*>(xa + r * P.xa_stride + (K * Q + c) * EPL) = o;
-          }
-        }
-      }
-      __syncthreads();
-      // ---- channel contraction on the matrix cores (ring of weight fragments from L2 and xa fragments from LDS) ----
-      {
-        const T* brow = xa + (ph * 32 * NTW + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
-        auto load_b = [&](int kg, frag_t (&b)[NTW]) {
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) b[t] = *reinterpret_cast<const frag_t*>(brow + t * 32 * P.xa_stride + kg * KGS);
-        };
-        auto mma_step = [&](const frag_t (&a)[MH], const frag_t (&b)[NTW]) {
-#pragma unroll
-          for (int m = 0; m < MH; ++m)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) mma_kgroup(acc[m][t], a[m], b[t]);
-        };
-        ring_run(ring, P.NKG, load_a, load_b, mma_step);
-      }
-      __syncthreads();   // xa / xs free again (next chunk or the epilogue's staging buffer)
+      return;
     }
+    // sparse aggregation.  A wave owns adjacency columns col = w8, w8+8, ... (their compressed lists are wave-uniform:
+    // no divergence, LDS broadcast reads); lanes span (frame, channel vector).  Rows >= rows are never written:
+    // they only feed output rows that are never stored.
+    const int npair = nf * Q;
+    for (int col = w8; col < KV; col += 8) {
+      const int kk = col_k[col], w = col_w[col];
+      const int e0 = csr_off[col], e1 = min(csr_off[col + 1], P.nnz_cap);
+      for (int pr = lane; pr < npair; pr += 64) {
+        const int f = pr / Q, q = pr - f * Q;
+        const T* xrow = xs + (f * V) * P.xs_stride + q * EPL;
+        float sum[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) sum[j] = 0.f;
+        for (int e = e0; e < e1; ++e) {
+          const float av = csr_a[e];
+          const frag_t xv = *reinterpret_cast<const frag_t*>(xrow + csr_v[e] * P.xs_stride);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) sum[j] += av * E::to_f(xv[j]);
+        }
+        frag_t o;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) o[j] = E::from_f(sum[j]);
+        *reinterpret_cast<frag_t*>(xa + (f * V + w) * P.xa_stride + kk * P.CCeff + q * EPL) = o;
+      }
+    }
+  };
 
-    // ---- epilogue: accumulators -> LDS (row-major, channels innermost) -> coalesced HBM store ----
-    constexpr int NPASS = (MT + 1) / 2;
-    constexpr int VPR = 64 / EPL;                // vectors per staged row
-    constexpr int RSTEP = NTHREADS / VPR;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define STAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+
+  if (is_compute) {
+    // =========================================== compute waves ===========================================
+    const int ph = MSPLIT ? (wave & 1) : wave, mh = MSPLIT ? (wave >> 1) : 0;
+    // The weight ring.  One step = one k-group = MH*NTW MFMA groups; a ROUND is DA steps and an item is a whole number
+    // of rounds (the geometry pads K*CCeff to that).  Slot d holds step d of the current round; step d of a round
+    // issues the load of the slot just freed: step DA-1 of this round (d = 0) or step d-1 of the NEXT round -- whatever
+    // chunk or tile that belongs to -- so every fragment is requested DA-1 steps ahead and the ring never drains, not
+    // even across the aggregation phase.  Addresses are two wave-uniform bases (this round, next round) + the lane's
+    // 32-bit offset + an immediate: the per-step bookkeeping of the first version (position, wrap, ghost steps: ~45
+    // scalar instructions against four MFMAs) is now ~10 scalar instructions per round.
+    constexpr int DA = GcnRing<MT>::DA;
+    constexpr int DB = 3;                                  // activation ring: DB-1 steps ahead; divides DA
+    constexpr int PD = DB - 1;
+    constexpr unsigned FRAGB = 64 * EPL * sizeof(T);       // bytes of one fragment (1 KB)
+    f32x16 acc[MH][NTW];
+    // fragments live in the rings as four raw dwords (loop-carried arrays of 8 x 16-bit vectors get scalarised and
+    // re-packed element by element); they become MFMA operands by a bit cast
+    u32x4 a[DA][MH], b[DB][NTW];
+    const int nit = P.NKG;                                 // steps per item
+    const int R = nit / DA;                                // rounds per item
+    const size_t chstride_b = (size_t)P.MTtot * P.NKG * FRAGB;      // bytes between the weights of consecutive chunks
+    const char* wblk = reinterpret_cast<const char*>(Wp) + (size_t)(mt0 + mh * MH) * P.NKG * FRAGB;   // wave-uniform
+    unsigned voff[MH];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      {
+    for (int m = 0; m < MH; ++m) voff[m] = (unsigned)lane * 16u + (unsigned)m * (unsigned)P.NKG * FRAGB;
+    auto ldw = [&](const char* base, int step, u32x4 (&dst)[MH]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const int p = ph * 32 * NTW + t * 32 + (lane & 31);
+      for (int m = 0; m < MH; ++m) dst[m] = *reinterpret_cast<const u32x4*>(base + step * FRAGB + (size_t)voff[m]);
+    };
+    int ch_n = 0, r_n = 0;                                 // chunk / round of `nxt`
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++r_n == R) { r_n = 0; if (++ch_n == nch) ch_n = 0; }
+      return wblk + (size_t)ch_n * chstride_b + (size_t)r_n * (DA * FRAGB);
+    };
+    const char* cur = wblk;
 #pragma unroll
-          for (int ml = 0; ml < 2; ++ml) {
-            const int mg = 2 * ps + ml;                    // channel tile of this pass; held by the waves with mh == mg / MH
-            const int m = mg % MH;
-            if (mg < MT && mg / MH == mh) {
+    for (int d = 0; d < DA - 1; ++d) {                     // in flight while the first chunk is being staged
+      ldw(cur, d, a[d]);
+      // keep the issue order slot 0, 1, ...: the loop's waits count loads YOUNGER than the slot they need, and the
+      // compiler takes the minimum over the loop's entry paths -- a reordered prologue turned them all into vmcnt(1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const char* nxt = advance();
+    const T* brow[NTW];
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int cl = ml * 32 + 8 * g + 4 * (lane >> 5);
-                float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
-                store4(outs + p * P.out_stride + cl, v4);
-              }
+    for (int tt = 0; tt < NTW; ++tt) brow[tt] = xa + (ph * 32 * NTW + tt * 32 + (lane & 31)) * P.xa_stride + (lane >> 5) * EPL;
+    // bias-term rows of this lane's positions (tile-independent: position p is joint p mod V of some frame)
+    const float* brp[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) brp[tt] = bterm_l + (int)row_w[ph * 32 * NTW + tt * 32 + (lane & 31)] * BTS + 4 * (lane >> 5) + mh * MH * 32;
+    lds_barrier();                                          // B1(0): item 0 staged (the memory waves' prologue)
+    tlast = __builtin_amdgcn_s_memtime();
+    Cur c = cur_first();
+    int nf = cur_nf(c);
+    for (int it = 0; it < total_items; ++it) {
+      if (c.ch == 0) {
+        // tile start: accumulators = bias term bterm[w][c] of their (row, channel)
+        const int rows = nf * V;
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int p = ph * 32 * NTW + tt * 32 + (lane & 31);
+          const bool rowb = P.bterm && p < rows;
+#pragma unroll
+          for (int m = 0; m < MH; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+              if (rowb) b4 = *reinterpret_cast<const f32x4*>(brp[tt] + m * 32 + 8 * g);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[m][tt][4 * g + j] = b4[j];
             }
           }
         }
       }
-      __syncthreads();
-      {
-        const int vq = tid % VPR;
-        const int cg = cbase_blk + ps * 64 + vq * EPL;
-        float s1[EPL], s2[EPL];
+      STAMP(0)                                              // tile start
+      // ---------------- P1: aggregation ----------------
+      aggregate(xsbuf(it & 1), nf, wave);
+      STAMP(1)
+      lds_barrier();                                        // B2: xa complete
+      STAMP(2)
+      // ---------------- P2: channel contraction ----------------
+      // A step's loads and its MFMAs are independent: sched_group_barrier asks for them INTERLEAVED, one MFMA and then
+      // the loads in its shadow, instead of a clump of load instructions during which the matrix pipe idles.
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-        const bool col_live = (2 * ps * 32 + vq * EPL) < MT * 32 && cg < P.Cout;
-        if (col_live) {
-          for (int r = tid / VPR; r < rows; r += RSTEP) {
-            const int f = row_f[r], w = row_w[r];
-            const size_t g = ((size_t)(n * P.Tout + (t0 + f) * P.out_t_stride) * V + w) * P.Cout + cg;
-            const frag_t sv = *reinterpret_cast<const frag_t*>(outs + r * P.out_stride + vq * EPL);
-            if (VEC_OUT) {
-              frag_t o = sv;
+      for (int d = 0; d < PD; ++d)
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) b[d][tt] = *reinterpret_cast<const u32x4*>(brow[tt] + d * KGS);
+#define GCN_STEP(D)                                                                                      \
+      {                                                                                                  \
+        if ((D) == 0) ldw(cur, DA - 1, a[DA - 1]); else ldw(nxt, (D) - 1, a[(D) - 1]);                   \
+        _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt)                                               \
+          b[((D) + PD) % DB][tt] = *reinterpret_cast<const u32x4*>(bp[tt] + ((D) + PD) * KGS);           \
+        _Pragma("unroll") for (int m = 0; m < MH; ++m)                                                   \
+          _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) mma_kgroup(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); \
+        _Pragma("unroll") for (int i_ = 0; i_ < MH * NTW; ++i_) {                                        \
+          __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 4 ? 4 : 1, 0);                        \
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                             \
+          __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);                                             \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+      }
+      const int nround = (P.abl & 2) ? 0 : R;
+      for (int r = 0; r < nround; ++r) {
+        const T* bp[NTW];
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) bp[tt] = brow[tt] + r * (DA * KGS);
+        GCN_STEP(0) GCN_STEP(1) GCN_STEP(2) GCN_STEP(3) GCN_STEP(4) GCN_STEP(5)
+        if constexpr (DA == 12) { GCN_STEP(6) GCN_STEP(7) GCN_STEP(8) GCN_STEP(9) GCN_STEP(10) GCN_STEP(11) }
+        cur = nxt;
+        nxt = advance();
+      }
+#undef GCN_STEP
+      STAMP(3)
+      if (c.ch == nch - 1) {
+        // tile end: accumulators -> LDS output image (row-major, channels innermost); the memory waves stream it out
+        // during the next item's aggregation phase
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int p = ph * 32 * NTW + tt * 32 + (lane & 31);
+#pragma unroll
+          for (int m = 0; m < MH; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int cl = (mh * MH + m) * 32 + 8 * g + 4 * (lane >> 5);
+              float v4[4] = {acc[m][tt][4 * g], acc[m][tt][4 * g + 1], acc[m][tt][4 * g + 2], acc[m][tt][4 * g + 3]};
+              store4(outs + p * OSTR + cl, v4);
+            }
+          }
+        }
+      }
+      cur_next(c);
+      if (c.ch == 0) nf = cur_nf(c);
+      STAMP(4)
+      lds_barrier();                                        // B1(it+1): contraction done (+ image), next chunk staged
+      STAMP(5)
+    }
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+      for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i];
+  } else {
+    // =========================================== memory waves ============================================
+    // Everything a thread needs per item is a wave-uniform base (from the item's cursor) plus per-thread constants:
+    // which rows / channel vector of a chunk it moves (UL slots), and which rows / channel vector of the image it stores.
+    const int RS = NROLE / Q;                               // rows per sweep of the role's threads (>= 32)
+    const int r0 = ltid / Q, q = ltid - r0 * Q;
+    const bool tlive = r0 < RS;
+    unsigned goff[UL];                                      // element offset of slot u's row in the tile (+ its channel vector)
+    int xoff[UL];                                           // element offset in the LDS chunk, -1: no such row
+    int xrow[UL];                                           // tile row of the slot (>= 128: none)
+#pragma unroll
+    for (int u = 0; u < UL; ++u) {
+      const int r = r0 + u * RS;
+      const bool ex = tlive && r < TILE_ROWS;
+      xrow[u] = ex ? r : 1 << 20;
+      goff[u] = ex ? (unsigned)(((int)row_f[r] * P.in_t_stride * V + (int)row_w[r]) * P.Cin + q * EPL) : 0u;
+      xoff[u] = ex ? r * P.xs_stride + q * EPL : -1;
+    }
+    const size_t in_seq = (size_t)P.Tin * V * P.Cin;        // elements per input sequence
+    const int in_tile = P.F * P.in_t_stride * V * P.Cin;    // elements between the first rows of consecutive tiles
+    // ---- global loads of the cursor's item -> registers.  UNCONDITIONAL loads (dead slots read the tile's first vector
+    //      -- the tensor's first for items beyond the end -- and are zeroed in `commit`): a constant number of loads per
+    //      item lets the compiler wait for "all but the youngest UL" instead of draining the queue ----
+    auto issue = [&](const Cur& c, u32x4 (&R)[UL]) __attribute__((always_inline)) {
+      const int rows = cur_nf(c) * V;                       // 0 beyond the last tile
+      const int cb = c.ch * P.CCeff;
+      const T* base = xg + (rows > 0 ? (size_t)c.n * in_seq + (size_t)c.tq * in_tile + cb : 0);     // wave-uniform
+      const bool qlive = q * EPL < P.Cin - cb;
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        const bool live = qlive && xrow[u] < rows;
+        const unsigned g = live ? goff[u] : 0u;
+        if constexpr (VEC_IN) R[u] = *reinterpret_cast<const u32x4*>(base + g);
+        else {
+          frag_t v;
+          zero_frag<T>(v);
+          if (live) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) if (cb + q * EPL + e < P.Cin) v[e] = base[g + e];
+          }
+          R[u] = __builtin_bit_cast(u32x4, v);
+        }
+      }
+    };
+    // ---- registers of the cursor's item -> LDS chunk (zeros in the rows behind the tile and in channel vectors beyond Cin) ----
+    auto commit = [&](const Cur& c, u32x4 (&R)[UL], T* xs) __attribute__((always_inline)) {
+      const int rows = cur_nf(c) * V;
+      const bool qlive = q * EPL < P.Cin - c.ch * P.CCeff;
+#pragma unroll
+      for (int u = 0; u < UL; ++u) {
+        if (xoff[u] >= 0) {
+          frag_t v = __builtin_bit_cast(frag_t, R[u]);
+          if (!(qlive && xrow[u] < rows)) zero_frag<T>(v);
+          *reinterpret_cast<frag_t*>(xs + xoff[u]) = v;
+        }
+      }
+    };
+    // ---- output image -> HBM (+ addend) with the BatchNorm sums; a thread always copies out the same channel vector,
+    //      so its sums stay in registers for the whole walk and are reduced once per workgroup ----
+    constexpr int VPR = MT * 32 / EPL;                      // vectors per image row
+    constexpr int RSTEP = NROLE / VPR;                      // rows per sweep
+    constexpr int NR = TILE_ROWS / RSTEP;                   // rows per thread
+    constexpr int UB = NR < 4 ? NR : 4;
+    const int vq = ltid % VPR, pr0 = ltid / VPR;
+    const int cg = cbase_blk + vq * EPL;
+    unsigned ooff[NR];                                      // element offset of the thread's i-th row in the output tile
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int p = pr0 + i * RSTEP;
+      ooff[i] = (unsigned)(((int)row_f[p] * P.out_t_stride * V + (int)row_w[p]) * P.Cout + cg);
+    }
+    const T* img = outs + pr0 * OSTR + vq * EPL;
+    const size_t out_seq = (size_t)P.Tout * V * P.Cout;
+    const int out_tile = P.F * P.out_t_stride * V * P.Cout;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 st1[EPL / 2], st2[EPL / 2];                       // packed pairs: v_pk_add_f32 / v_pk_fma_f32
+#pragma unroll
+    for (int j = 0; j < EPL / 2; ++j) { st1[j] = f32x2{0.f, 0.f}; st2[j] = f32x2{0.f, 0.f}; }
+    auto store_image = [&](int n, int tq) __attribute__((always_inline)) {
+      if (cg >= P.Cout) return;
+      const int rows = min(P.F, P.Tlog - tq * P.F) * V;
+      const size_t tb = (size_t)n * out_seq + (size_t)tq * out_tile;           // wave-uniform
+      T* yb = yg + tb;
+      const T* ab = addg + tb;
+#pragma unroll
+      for (int i0 = 0; i0 < NR; i0 += UB) {
+        if (pr0 + i0 * RSTEP < rows) {
+          frag_t sv[UB], av[UB];
+          bool ok[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            ok[u] = pr0 + (i0 + u) * RSTEP < rows;
+            sv[u] = *reinterpret_cast<const frag_t*>(img + (i0 + u) * RSTEP * OSTR);
+            if (addg) {
+              const unsigned g = ok[u] ? ooff[i0 + u] : ooff[i0];
+              if constexpr (VEC_OUT) av[u] = *reinterpret_cast<const frag_t*>(ab + g);
+              else {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) av[u][j] = (cg + j < P.Cout) ? ab[g + j] : E::from_f(0.f);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            if (ok[u]) {
+              frag_t o = sv[u];
               if (addg) {
-                const frag_t av = *reinterpret_cast<const frag_t*>(addg + g);
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) o[j] = E::from_f(E::to_f(sv[j]) + E::to_f(av[j]));
+                for (int j = 0; j < EPL; ++j) o[j] = E::from_f(E::to_f(sv[u][j]) + E::to_f(av[u][j]));
               }
-              *reinterpret_cast<frag_t*>(yg + g) = o;
 #pragma unroll
-              for (int j = 0; j < EPL; ++j) { float fv = E::to_f(o[j]); s1[j] += fv; s2[j] += fv * fv; }
-            } else {
+              for (int j = 0; j < EPL / 2; ++j) {
+                f32x2 fv = {E::to_f(o[2 * j]), E::to_f(o[2 * j + 1])};
+                if (!VEC_OUT) { if (cg + 2 * j >= P.Cout) fv[0] = 0.f; if (cg + 2 * j + 1 >= P.Cout) fv[1] = 0.f; }
+                st1[j] += fv;
+                st2[j] += fv * fv;
+              }
+              if constexpr (VEC_OUT) *reinterpret_cast<frag_t*>(yb + ooff[i0 + u]) = o;
+              else {
 #pragma unroll
-              for (int j = 0; j < EPL; ++j) {
-                if (cg + j < P.Cout) {
-                  float fv = E::to_f(sv[j]);
-                  if (addg) fv += E::to_f(addg[g + j]);
-                  const T o = E::from_f(fv);
-                  yg[g + j] = o;
-                  fv = E::to_f(o);
-                  s1[j] += fv; s2[j] += fv * fv;
-                }
+                for (int j = 0; j < EPL; ++j) if (cg + j < P.Cout) yb[ooff[i0 + u] + j] = o[j];
               }
             }
           }
         }
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) { st1[ps][j] += s1[j]; st2[ps][j] += s2[j]; }
       }
-      __syncthreads();
-    }
-  }
+    };
 
-  if (P.stats) {
-    constexpr int VPR = 64 / EPL;
-    const int vq = tid % VPR;
-#pragma unroll
-    for (int ps = 0; ps < NPASS_; ++ps) {
+    // ---- the item loop.  Item j travels in register set j & 1 and lands in chunk-buffer half j & 1.  Per item `it`:
+    //        P1  commit(it+1)   its loads were issued two items ago; half (it+1)&1 has been free since B2 of item it-1
+    //            store image    of the tile that ended with item it-1
+    //            this role's share of the aggregation
+    //        B2
+    //        P2  issue(it+3)    into the register set drained by the commit
+    //        B1
+    //      The memory counter retires in order, so the wait in `commit` also covers the image stores of the PREVIOUS item
+    //      (one whole item old by then) but never the stores of this one or the youngest prefetch. ----
+    u32x4 RA[UL], RB[UL];
+    const bool ld = !(P.abl & 8);
+    Cur c_it = cur_first();                                 // item it
+    Cur c_cm = c_it;                                        // item it+1 (next commit)
+    Cur c_is = c_it;                                        // item it+3 (next issue)
+    if (ld) {
+      issue(c_is, RA); cur_next(c_is);
+      issue(c_is, RB); cur_next(c_is);
+      __builtin_amdgcn_sched_barrier(0);
+      commit(c_cm, RA, xsbuf(0));
+      issue(c_is, RA); cur_next(c_is);
+    }
+    cur_next(c_cm);
+    lds_barrier();                                          // B1(0)
+    tlast = __builtin_amdgcn_s_memtime();
+    bool pending = false;
+    int pend_n = 0, pend_tq = 0;
+    auto iteration = [&](int it, u32x4 (&Rs)[UL]) __attribute__((always_inline)) {   // Rs: holds item it+1, refilled with it+3
+      if (ld && it + 1 < total_items) commit(c_cm, Rs, xsbuf((it + 1) & 1));
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(0)
+      if (pending) { if (!(P.abl & 4)) store_image(pend_n, pend_tq); pending = false; }
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP(1)
+      aggregate(xsbuf(it & 1), cur_nf(c_it), 4 + wave);
+      STAMP(2)
+      lds_barrier();                                        // B2
+      STAMP(3)
+      if (ld) issue(c_is, Rs);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c_it.ch == nch - 1) { pending = true; pend_n = c_it.n; pend_tq = c_it.tq; }
+      cur_next(c_it); cur_next(c_cm); cur_next(c_is);
+      STAMP(4)
+      lds_barrier();                                        // B1(it+1)
+      STAMP(5)
+    };
+    for (int it = 0; it < total_items; it += 2) {
+      iteration(it, RB);
+      if (it + 1 < total_items) iteration(it + 1, RA);
+    }
+    if (pending) store_image(pend_n, pend_tq);
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0)
+      for (int i = 0; i < 6; ++i) P.dbg[8 + i] = tacc[i];
+
+    if (P.stats) {
 #pragma unroll
       for (int j = 0; j < EPL; ++j) {
-        float a = st1[ps][j], b = st2[ps][j];
+        float sa = st1[j / 2][j & 1], sb = st2[j / 2][j & 1];
 #pragma unroll
-        for (int msk = VPR; msk < 64; msk <<= 1) { a += __shfl_xor(a, msk); b += __shfl_xor(b, msk); }
-        const int cl = ps * 64 + vq * EPL + j;
-        if (lane < VPR && cl < MT * 32 && cbase_blk + cl < P.Cout) {
-          atomicAdd(&stat[cl], a);
-          atomicAdd(&stat[MT * 32 + cl], b);
+        for (int msk = VPR; msk < 64; msk <<= 1) { sa += __shfl_xor(sa, msk); sb += __shfl_xor(sb, msk); }
+        const int cl = vq * EPL + j;
+        if (lane < VPR && cbase_blk + cl < P.Cout) {
+          atomicAdd(&stat[cl], sa);
+          atomicAdd(&stat[MT * 32 + cl], sb);
         }
       }
     }
+  }
+#undef STAMP
+
+  if (P.stats) {
     __syncthreads();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
-    for (int c = tid; c < MT * 32; c += NTHREADS) {
+    for (int c = tid; c < MT * 32; c += NTH) {
       if (cbase_blk + c < P.Cout) {
         atomic_add_f64(dst + cbase_blk + c, (double)stat[c]);
         atomic_add_f64(dst + P.Cout + cbase_blk + c, (double)stat[MT * 32 + c]);
@@ -419,7 +748,8 @@ __global__ __launch_bounds__(NTHREADS, MT <= 4 ? 2 : 1) void gcn_fwd_kernel(cons
 }
 
 template <typename T, int MT>
-int launch_mt(const GcnFwdParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
+int launch_mt(const GcnFwdParams& P0, int grid_cap, int gy, size_t lds, hipStream_t stream) {
+  GcnFwdParams P = P0;
   constexpr int EPL = Elem<T>::EPL;
   const bool vin = (P.Cin % EPL) == 0, vout = (P.Cout % EPL) == 0;
 #define GO(VI, VO)                                                                                          \
@@ -427,9 +757,10 @@ int launch_mt(const GcnFwdParams& P, int grid_cap, int gy, size_t lds, hipStream
     auto kfn = gcn_fwd_kernel<T, MT, VI, VO>;                                                               \
     static std::atomic<unsigned long long> optin{0};                                                        \
     if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
-    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTHREADS, lds)) / gy;      \
+    int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTH, lds)) / gy;           \
     gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);                                            \
-    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTHREADS), lds, stream, P);                                       \
+    P.gx_div = gx / P.tiles_per_seq; P.gx_mod = gx % P.tiles_per_seq;                                       \
+    ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTH), lds, stream, P);                                            \
   } while (0)
   if (vin && vout) GO(true, true);
   else if (vin) GO(true, false);
@@ -440,20 +771,40 @@ int launch_mt(const GcnFwdParams& P, int grid_cap, int gy, size_t lds, hipStream
   return ISTGCN_OK;
 }
 
+// Tiling decision shared by the launcher and the geometry query (the host packs weights to match).  The chunk width is a
+// function of (Cin, Cout, K, dtype) alone: the widest chunk whose V-independent buffers (two chunk halves, aggregated
+// image, output image) leave 32 KB of the CU's 160 KB for the adjacency tables and the bias term.
+struct GcnGeom { int CCeff, nch, KKp, NKG, MT, gy, MTtot; };
+
+inline int gcn_geom(int Cin, int Cout, int K, int dtype, GcnGeom* G) {
+  const int epl = dtype == 0 ? 4 : 8, esz = dtype == 0 ? 4 : 2, cc_max = dtype == 0 ? 32 : 64, kgs = 2 * epl;
+  // at most 4 channel tiles per workgroup (accumulators + rings must stay within 256 VGPRs); wider layers use grid.y
+  G->MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
+  G->gy = ceil_div(Cout, G->MT * 32);
+  G->MTtot = G->gy * G->MT;
+  for (int cc = cc_max; cc >= epl; cc >>= 1) {
+    const int cce = Cin >= cc ? cc : round_up(Cin, epl);
+    const int kkp = round_up(K * cce, kgs * gcn_ring_steps(G->MT));       // whole ring rounds
+    const size_t xs = dtype == 0 ? (size_t)2 * TILE_ROWS * (cce + epl) * esz : (size_t)2 * 160 * round_up(cce, 32) * esz;
+    const size_t fixed = xs + (size_t)TILE_ROWS * (kkp + epl) * esz + (size_t)TILE_ROWS * (G->MT * 32 + epl) * esz;
+    if ((fixed <= 128 * 1024 && kkp / epl <= 64) || cc == epl) {
+      if (kkp / epl > 64) return ISTGCN_EINVAL;
+      G->CCeff = cce; G->nch = ceil_div(Cin, cce); G->KKp = kkp; G->NKG = kkp / kgs;
+      return ISTGCN_OK;
+    }
+  }
+  return ISTGCN_EINVAL;
+}
+
 template <typename T>
 int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
-  P.CCeff = P.Cin >= E::CC ? E::CC : round_up(P.Cin, EPL);
-  P.nch = ceil_div(P.Cin, P.CCeff);
-  P.KKp = round_up(P.K * P.CCeff, E::KGS);
-  P.NKG = P.KKp / E::KGS;
-  if (P.KKp / EPL > 64) return ISTGCN_EINVAL;
-  // at most 4 channel tiles per workgroup: the 8-tile kernel needs > 256 VGPRs, i.e. ONE 4-wave workgroup per CU, and
-  // lost more to exposed latency than the second channel block costs in repeated aggregation
-  int MT = P.Cout <= 32 ? 1 : P.Cout <= 64 ? 2 : 4;
-  int gy = ceil_div(P.Cout, MT * 32);
-  P.MTtot = gy * MT;
+  const int dtype = sizeof(T) == 4 ? 0 : 1;
+  GcnGeom G;
+  if (int rc = gcn_geom(P.Cin, P.Cout, P.K, dtype, &G)) return rc;
+  P.CCeff = G.CCeff; P.nch = G.nch; P.KKp = G.KKp; P.NKG = G.NKG; P.MTtot = G.MTtot;
+  if (P.CCeff / EPL > 2 * UL) return ISTGCN_EINVAL;       // 128 rows x Q vectors must fit the role's UL x 256 prefetch slots
   P.F = TILE_ROWS / P.V;
   P.tiles_per_seq = ceil_div(P.Tlog, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
@@ -462,24 +813,41 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   P.xs_rows = mfma_agg ? (P.F - 1) * P.V + 32 : TILE_ROWS;
   if (P.xs_rows < TILE_ROWS) P.xs_rows = TILE_ROWS;
   P.xa_stride = P.KKp + EPL;
-  P.out_stride = 64 + EPL;
+  P.out_stride = G.MT * 32 + EPL;
   size_t off = (size_t)(P.K * P.V + 1) * sizeof(int);
   off = (off + 15) & ~(size_t)15; P.off_csr_v = (int)off; off += P.nnz_cap;
   off = (off + 15) & ~(size_t)15; P.off_csr_a = (int)off; off += (size_t)P.nnz_cap * 4;
-  off = (off + 15) & ~(size_t)15; P.off_stat = (int)off; off += (size_t)2 * MT * 32 * 4;
+  off = (off + 15) & ~(size_t)15; P.off_stat = (int)off; off += (size_t)2 * G.MT * 32 * 4;
   off = (off + 15) & ~(size_t)15; P.off_rows = (int)off; off += 2 * TILE_ROWS + 2 * P.K * P.V;
   off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += sizeof(T) == 2 ? (size_t)P.K * 2 * 64 * 16 : 0;
-  off = (off + 15) & ~(size_t)15; P.off_work = (int)off;
-  size_t work = ((size_t)P.xs_rows * P.xs_stride + (size_t)TILE_ROWS * P.xa_stride) * sizeof(T);
-  size_t ost = (size_t)TILE_ROWS * P.out_stride * sizeof(T);
-  off += work > ost ? work : ost;
+  off = (off + 15) & ~(size_t)15; P.off_bterm = (int)off; off += P.bterm ? (size_t)P.V * (G.MT * 32 + 4) * 4 : 0;
+  const size_t xsb = (((size_t)P.xs_rows * P.xs_stride * sizeof(T)) + 15) & ~(size_t)15;
+  off = (off + 15) & ~(size_t)15; P.off_xs0 = (int)off; off += xsb;
+  P.off_xs1 = (int)off; off += xsb;
+  P.off_xa = (int)off; off += (((size_t)TILE_ROWS * P.xa_stride * sizeof(T)) + 15) & ~(size_t)15;
+  P.off_o = (int)off; off += (size_t)TILE_ROWS * P.out_stride * sizeof(T);
   if (off > 160 * 1024) return ISTGCN_EINVAL;
+  P.a_lds = (size_t)P.K * P.V * P.V * 4 <= off - (size_t)P.off_xs0 ? 1 : 0;
   if (P.total_tiles < 1) return ISTGCN_OK;
-  switch (MT) {
-    case 1: return launch_mt<T, 1>(P, grid_x_cap, gy, off, stream);
-    case 2: return launch_mt<T, 2>(P, grid_x_cap, gy, off, stream);
-    case 4: return launch_mt<T, 4>(P, grid_x_cap, gy, off, stream);
-    default: return launch_mt<T, 8>(P, grid_x_cap, gy, off, stream);
+  { const char* e = getenv("ISTGCN_GCN_ABL"); P.abl = e ? atoi(e) : 0; }
+  if (getenv("ISTGCN_GCN_DBG")) {
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(&dbuf, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
+    P.dbg = dbuf;
+    int rc = G.MT == 1 ? launch_mt<T, 1>(P, grid_x_cap, G.gy, off, stream) : G.MT == 2 ? launch_mt<T, 2>(P, grid_x_cap, G.gy, off, stream)
+                                                                                       : launch_mt<T, 4>(P, grid_x_cap, G.gy, off, stream);
+    unsigned long long h[16];
+    (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    fprintf(stderr, "gcn_fwd dbg Cin=%d Cout=%d items/wg~%d | compute: init %llu agg %llu B2 %llu contract %llu image %llu B1 %llu | memory: commit %llu store %llu issue %llu agg %llu B2 %llu B1 %llu\n",
+            P.Cin, P.Cout, P.total_tiles * P.nch / 256, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
+    return rc;
+  }
+  switch (G.MT) {
+    case 1: return launch_mt<T, 1>(P, grid_x_cap, G.gy, off, stream);
+    case 2: return launch_mt<T, 2>(P, grid_x_cap, G.gy, off, stream);
+    default: return launch_mt<T, 4>(P, grid_x_cap, G.gy, off, stream);
   }
 }
 
@@ -510,11 +878,9 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
 // Geometry query so the host can size / order the fragment-packed weights exactly as the kernel reads them.
 extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp,
                                    int* MTtot, int* EPL) {
-  if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
-  const int epl = dtype == 0 ? 4 : 8, cc = dtype == 0 ? 32 : 64, kgs = 2 * epl;
-  int cce = Cin >= cc ? cc : round_up(Cin, epl);
-  int MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
-  *CCeff = cce; *nch = ceil_div(Cin, cce); *KKp = round_up(K * cce, kgs);
-  *MTtot = ceil_div(Cout, MT * 32) * MT; *EPL = epl;
+  if (!istgcn_dtype_ok(dtype) || Cin < 1 || Cout < 1 || K < 1) return ISTGCN_EINVAL;
+  GcnGeom G;
+  if (int rc = gcn_geom(Cin, Cout, K, dtype, &G)) return rc;
+  *CCeff = G.CCeff; *nch = G.nch; *KKp = G.KKp; *MTtot = G.MTtot; *EPL = dtype == 0 ? 4 : 8;
   return ISTGCN_OK;
 }
