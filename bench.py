@@ -103,6 +103,11 @@ def main():
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay forward+backward from one hipGraph (harness.GraphedStep) in the timed region.  Measured: no gain\n'
+                         '(19.02 vs 19.09 ms/step, bf16 batch 64) -- the host already runs ahead of the GPU, the ~5 us between\n'
+                         'dependent kernels is device-side -- so the default stays eager, where every launch of the dominant\n'
+                         'family carries HIP events inside the timed region')
     ap.add_argument('--loss-scale', type=float, default=None,
                     help='static loss scale of the backward pass (default: 65536 for f16 storage, 1 otherwise)')
     args = ap.parse_args()
@@ -159,6 +164,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = args.graph and not args.breakdown
+    # graph mode: EVERY step of this process (eager warm-up, capture, replays, the eager roofline pass) runs on one side
+    # stream -- capture is not allowed on the default stream, and autograd's gradient accumulators stay bound to the
+    # stream of the first backward pass they saw
+    import contextlib
+    stack = contextlib.ExitStack()
+    side = None
+    if use_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        stack.enter_context(torch.cuda.stream(side))
+
     # warm-up steps are profiled per launch to find the dominant kernel family; in the timed region only THAT family's
     # launches carry HIP events (two event records per launch on all ~350 launches cost ~3 % of a bf16 step)
     ops.PROFILE = []
@@ -170,14 +187,35 @@ def main():
         for name, _, _, e0, e1 in ops.PROFILE:
             wfam[name] = wfam.get(name, 0.0) + e0.elapsed_time(e1)
         ops.PROFILE_ONLY = max(wfam, key=wfam.get)
-    ops.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = harness.train_step(model, opt, x, y, sync)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if use_graph:
+        # The timed steps replay forward + backward from ONE hipGraph (harness.GraphedStep; gradient all-reduce and the
+        # optimizer's one-launch update stay eager): ~250 launches leave the host as one.  A replay has no per-launch
+        # hook, so the dominant family's launch durations are taken -- live, same process, same buffers -- from the same
+        # number of EAGER steps run right after the timed region, with HIP events on that family's launches only.
+        dom_only, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE_ONLY, None, None
+        gstep = harness.GraphedStep(model, opt, x, y, warmup=1, stream=side)
+        for _ in range(2):
+            gstep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = gstep()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.PROFILE, ops.PROFILE_ONLY = [], dom_only
+        for _ in range(args.steps):
+            harness.train_step(model, opt, x, y, sync)
+        barrier()
+    else:
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = harness.train_step(model, opt, x, y, sync)
+        barrier()
+        elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_ONLY = None
+    stack.close()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -220,6 +258,8 @@ def main():
         roof['share_of_gpu_time'] = round(secs / sum(v[1] for v in fam.values()), 3)
     else:
         roof['share_of_step_time'] = round(secs / elapsed, 3)
+    if use_graph:
+        roof['measured_over'] = '%d eager steps right after the timed region (the timed steps are hipGraph replays)' % args.steps
     if args.breakdown and rank == 0:
         tot = sum(v[1] for v in fam.values())
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1]):
@@ -236,6 +276,7 @@ def main():
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'net/%s.py NTU xsub shape (N,3,%d,%d,2), %d clips/GPU, train step (fwd+bwd+SGD-nesterov), '
                                    'dropout 0.5, random-init weights' % (args.model, T, V, B),
+                       'launch': 'fwd+bwd replayed from one hipGraph; all-reduce + SGD eager' if use_graph else 'eager',
                        'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
                        'storage': ('%s activations, fp32 accumulate/params, fp64 BN sums%s' % (
                            args.dtype, ', static loss scale %g' % loss_scale if loss_scale != 1.0 else '')) if half else 'fp32'},

@@ -116,7 +116,11 @@ int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_
  *   istgcn_pack_tconv:   Wf[tap_sel[j]][o][i] at src + t*s_t + o*s_o + i*s_i for the ntaps packed taps
  *                        (nn.Conv2d(C, C, (k,1)).weight [o][i][t][1]: s_o = Cin*k, s_i = k, s_t = 1; the data gradient
  *                        swaps s_o / s_i and selects the taps of its output phase) -> Wp of istgcn_tconv
- *   istgcn_pack_gcn_bwd: W3[k][c][i] at src + k*s_k + c*s_c + i*s_i -> Wb of istgcn_gcn_bwd_data */
+ *   istgcn_pack_gcn_bwd: W3[k][c][i] at src + k*s_k + c*s_c + i*s_i -> Wb of istgcn_gcn_bwd_data
+ * istgcn_pack_tconv_elems includes a tail pad of six steps (6 * MTtot * 64 * EPL elements) behind the fragments: the
+ * kernel's weight ring may READ it (loads of the ghost steps that pad an item to whole rounds) but never uses it; a Wp
+ * handed to istgcn_tconv must be at least that long.  The gcn contraction length K*CCeff is padded (with zero columns)
+ * to whole ring rounds inside the layout itself (istgcn_gcn_geometry's KKp). */
 long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype);
 int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin, int Cout, int K,
                     int dtype, void* stream);
@@ -193,18 +197,21 @@ int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, double count, co
  *   out = relu( dropout_p( z*coef2[0] + coef2[1] ) + res' ),  res' = res (identity) or res*coefr[0] + coefr[1]
  *   (the BatchNorm of the strided 1x1 residual branch, :186-193) or 0 (res == NULL).  rows = NM*T*V, C channels.
  * Dropout: counter-based Philox4x32-10 keyed by (seed, flat element index); the same (p, seed) in the backward
- * calls regenerates the mask.  p = 0 disables it.
+ * calls regenerates the mask.  p = 0 disables it.  seed_epoch (device pointer or NULL): *seed_epoch is added to `seed`
+ * when the kernel RUNS, so launches recorded once in a hipGraph draw a fresh mask per replay (harness.GraphedStep).
  * istgcn_block_out_bwd: dres = dout * [out > 0] (the gradient of both the residual branch and, after dropout, of
  *   tcn.3); stats2 += (sum dres*mask, sum dres*mask*zhat); statsr += (sum dres, sum dres*rhat) when the residual
  *   branch has a BatchNorm (r = its input, coefr = its coef[4][C]); r == NULL otherwise.
  * istgcn_affine2: out = abc[0]*d*mask + abc[1]*x + abc[2]  (elementwise part of BatchNorm backward; x may be NULL). */
 int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
-                         long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
+                         long long rows, int C, float p_drop, unsigned long long seed,
+                         const unsigned long long* seed_epoch, int dtype, void* stream);
 int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
                          const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
-                         long long rows, int C, float p_drop, unsigned long long seed, int dtype, void* stream);
+                         long long rows, int C, float p_drop, unsigned long long seed,
+                         const unsigned long long* seed_epoch, int dtype, void* stream);
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
-                   unsigned long long seed, int dtype, void* stream);
+                   unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream);
 
 /* Input stage: the feeder's augmentation (feeder/tools.py:31-101) and the data_bn prologue (net/st_gcnold.py:74-80) on
  * the GPU.  raw [N][C][Traw][V][M] fp32 is the clip batch as the reference's DataLoader delivers it;

@@ -83,11 +83,22 @@ __device__ static inline void store_vec(T* p, float (&f)[VW]) {
   }
 }
 
-struct DropCfg { uint32_t thr; float inv_keep; uint32_t s0, s1; int on; };
+struct DropCfg {
+  uint32_t thr; float inv_keep; uint32_t s0, s1; int on;
+  // optional device-resident offset added to the seed when the kernel runs: lets a launch recorded ONCE in a hipGraph
+  // draw a fresh mask on every replay (the host increments the counter -- or records its increment in the same graph)
+  const unsigned long long* epoch;
+};
+__device__ static inline void drop_key(const DropCfg& D, uint32_t& k0, uint32_t& k1) {
+  unsigned long long s = ((unsigned long long)D.s1 << 32) | D.s0;
+  if (D.on && D.epoch) s += *D.epoch;
+  k0 = (uint32_t)s; k1 = (uint32_t)(s >> 32);
+}
 
-static inline DropCfg make_drop(float p, unsigned long long seed) {
+static inline DropCfg make_drop(float p, unsigned long long seed, const unsigned long long* epoch) {
   DropCfg d{};
   d.on = p > 0.f;
+  d.epoch = epoch;
   if (d.on) {
     double t = (double)p * 65536.0 + 0.5;                  // 16-bit draws: drop when draw < thr
     d.thr = t >= 65536.0 ? 65536u : (uint32_t)t;
@@ -161,6 +172,8 @@ __global__ void bn_bwd_coef_kernel(double* stats, int rep, int clear, double cou
 template <typename T, int VW>
 __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const float* coef2, const T* res, const float* coefr,
                                                           T* out, size_t rows, int C, DropCfg D) {
+  uint32_t dk0, dk1;
+  drop_key(D, dk0, dk1);
   const int QC = C / VW;
   const size_t total = rows * QC;
   const bool fixed_q = (NT % QC) == 0;
@@ -187,10 +200,10 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
     load_vec<T, VW>(z + e0, zv);
     if (res) load_vec<T, VW>(res + e0, rv);
     if (D.on) {
-      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, dk0, dk1);
       }
     }
 #pragma unroll
@@ -209,6 +222,8 @@ template <typename T, int VW>
 __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const T* z, const float* coef2,
                                                           const T* r, const float* coefr, T* dres, double* stats2,
                                                           double* statsr, int rep, size_t rows, int C, DropCfg D) {
+  uint32_t dk0, dk1;
+  drop_key(D, dk0, dk1);
   __shared__ float red[4][NT];
   const int QC = C / VW;                 // vectors per row; NT % QC == 0 is guaranteed by the launcher
   const int q = threadIdx.x % QC;
@@ -229,10 +244,10 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
     load_vec<T, VW>(z + e0, zv);
     if (r) load_vec<T, VW>(r + e0, rv);
     if (D.on) {
-      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, dk0, dk1);
       }
     }
 #pragma unroll
@@ -274,6 +289,8 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
 template <typename T, int VW>
 __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, const float* abc, T* out, size_t rows, int C,
                                                     DropCfg D) {
+  uint32_t dk0, dk1;
+  drop_key(D, dk0, dk1);
   const int QC = C / VW;
   const size_t total = rows * QC;
   const bool fixed_q = (NT % QC) == 0;
@@ -294,10 +311,10 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
     load_vec<T, VW>(d + e0, dv);
     if (x) load_vec<T, VW>(x + e0, xv);
     if (D.on) {
-      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, D.s0, D.s1);
+      if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, D.s0, D.s1);
+        for (int j = 0; j < VW; ++j) m[j] = drop_scale1(e0 + j, D.thr, D.inv_keep, dk0, dk1);
       }
     }
 #pragma unroll
@@ -363,13 +380,13 @@ extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, doubl
   } while (0)
 
 extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
-                                    long long rows, int C, float p_drop, unsigned long long seed, int dtype,
-                                    void* stream) {
+                                    long long rows, int C, float p_drop, unsigned long long seed,
+                                    const unsigned long long* seed_epoch, int dtype, void* stream) {
   if (!z || !coef2 || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
-  const DropCfg D = make_drop(p_drop, seed);
+  const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
   EW_CASES(DISPATCH_VW(block_out_fwd_kernel, ET, VWB, grid, (const ET*)z, coef2, (const ET*)res, coefr, (ET*)out,
                        (size_t)rows, C, D));
@@ -379,15 +396,15 @@ extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const voi
 
 extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
                                     const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
-                                    long long rows, int C, float p_drop, unsigned long long seed, int dtype,
-                                    void* stream) {
+                                    long long rows, int C, float p_drop, unsigned long long seed,
+                                    const unsigned long long* seed_epoch, int dtype, void* stream) {
   if (!dout || !out || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
   if ((r != nullptr) != (coefr != nullptr) || (r && !statsr)) return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   int vw = dtype == 0 ? pick_vw<float>(C, true) : pick_vw<__bf16>(C, true);
   if (vw == 1 && (C > NT || NT % C != 0)) return ISTGCN_EINVAL;   // scalar map needs C | 256
-  const DropCfg D = make_drop(p_drop, seed);
+  const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const int rpb = NT / (C / vw);
   size_t g = ((size_t)rows + rpb - 1) / rpb;
   if (g > 1024) g = 1024;
@@ -399,12 +416,13 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const voi
 }
 
 extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C,
-                              float p_drop, unsigned long long seed, int dtype, void* stream) {
+                              float p_drop, unsigned long long seed, const unsigned long long* seed_epoch, int dtype,
+                              void* stream) {
   if (!d || !abc || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
-  const DropCfg D = make_drop(p_drop, seed);
+  const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
   EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();

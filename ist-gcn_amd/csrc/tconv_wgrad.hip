@@ -352,10 +352,15 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
             mma_kgroup(d, a[0], b0);
             mma_kgroup(d, a[1], b1);
             if (w < V) {
+              // a lane owns one image row; the rows are 64 bytes apart (what the transposed reads of the contraction
+              // want), so sixteen lanes storing the same 16-byte block of their rows would share two banks.  The block
+              // index is XOR-swizzled with bits 1-2 of the row (the contraction's reads apply the same map): the SQ
+              // counters of the unswizzled kernel had 60 % of its LDS cycles in bank conflicts.
+              const int row = f * V + w, sw = (row >> 1) & 3;
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
                 float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-                store4(us + ((sub * K + k) * TR + f * V + w) * CB + 8 * g + 4 * (lane >> 5), v4);
+                store4(us + ((sub * K + k) * TR + row) * CB + 8 * (g ^ sw) + 4 * (lane >> 5), v4);
               }
             }
           }
@@ -383,7 +388,8 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
             frag_t o;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) o[e] = E::from_f(sum[e]);
-            *reinterpret_cast<frag_t*>(us + ((sub * K + k) * TR + f * V + w) * CB + q * EPL) = o;
+            const int qs = sizeof(T) == 2 ? (q ^ (((f * V + w) >> 1) & 3)) : q;      // 16-bit: swizzled block (see above)
+            *reinterpret_cast<frag_t*>(us + ((sub * K + k) * TR + f * V + w) * CB + qs * EPL) = o;
           }
         }
         }
@@ -521,12 +527,16 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
       const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
       const int q = (lane & 15) >> 2, pp = lane & 3;
       const int coff = cblk + 4 * pp;
+      // AGG: the aggregated images are block-swizzled by row bits 1-2 (see the aggregation); a lane's rows are
+      // 8h + q and 8h + q + 4 (mod 16) in every k-step, so its two swizzled column offsets are constants
+      const int coff_u0 = (((coff >> 3) ^ (((8 * h + q) >> 1) & 3)) << 3) + (coff & 7);
+      const int coff_u1 = (((coff >> 3) ^ (((8 * h + q + 4) >> 1) & 3)) << 3) + (coff & 7);
       frag_t a0, a1, b0[JTW], b1[JTW];
       auto load_k = [&](int kk, frag_t& a, frag_t (&b)[JTW]) {
         const int pb = pbase + 16 * kk + 8 * h + q;          // this lane addresses rows pb and pb+4 of its 8 positions
         a = tr_pair<T>(dz_w + pb * CB + coff, dz_w + (pb + 4) * CB + coff);
-        const T* u0 = us_w + (AGG ? pb : (int)urow[pb]) * CB + coff;
-        const T* u1 = us_w + (AGG ? pb + 4 : (int)urow[pb + 4]) * CB + coff;
+        const T* u0 = us_w + (AGG ? pb * CB + coff_u0 : (int)urow[pb] * CB + coff);
+        const T* u1 = us_w + (AGG ? (pb + 4) * CB + coff_u1 : (int)urow[pb + 4] * CB + coff);
 #pragma unroll
         for (int j = 0; j < JTW; ++j) b[j] = tr_pair<T>(u0 + toff[j], u1 + toff[j]);
       };

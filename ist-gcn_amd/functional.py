@@ -236,6 +236,7 @@ class BlockCfg:
         self.momentum, self.eps = momentum, eps
         self.pattern = pattern            # [K,V,V] fp32 sparsity pattern of the adjacency gradient (None: dense)
         self.packed = None                # dict of fragment-packed weights from the Model's PackPlan (None: pack per call)
+        self.seed_epoch = None            # int64[1] device tensor added to the dropout seed at kernel run time (graph replay)
 
 
 class STGCNBlockFn(torch.autograd.Function):
@@ -294,7 +295,7 @@ class STGCNBlockFn(torch.autograd.Function):
             res, cr = None, None
         # 4. BN2 + dropout + residual + ReLU
         p = cfg.p_drop if training else 0.0
-        out = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed)
+        out = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed, epoch=cfg.seed_epoch)
         ctx.cfg, ctx.training, ctx.seed, ctx.p = cfg, training, seed, p
         ctx.save_for_backward(x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb)
         ctx.has_b = bterm is not None
@@ -313,9 +314,9 @@ class STGCNBlockFn(torch.autograd.Function):
             dout = dout.to(dt)
         pk = cfg.packed or {}
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
-        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True)
+        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True, epoch=cfg.seed_epoch)
         abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
-        dz = ops.affine2(dres, z, abc2, p, seed)
+        dz = ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
         taps, in_mul = ops.conv_taps_fwd(k, s)
         pre1 = coef1[:2].contiguous()

@@ -173,13 +173,16 @@ class STGCNBlock(nn.Module):
         return Fn.run_infer_plan(cache[1], cache[2], x)
 
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
-    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True, packed=None):
+    def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True, packed=None,
+            seed_epoch=None):
         """pattern: [K,V,V] fp32 sparsity pattern of the adjacency gradient (None = dense); seed_base: the Model's
         per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself; packed: this
-        block's fragment-packed weights from the Model's one-launch PackPlan (None: packed per call)."""
+        block's fragment-packed weights from the Model's one-launch PackPlan (None: packed per call); seed_epoch: int64[1]
+        device counter added to the dropout seed when the kernels run (Model.device_seed_epoch, for hipGraph replay)."""
         cfg, ((A_eff, bterm, Wg3, g1, b1, Wt, bt, g2, b2, Wr, br, gr, betar, Ws, bs, We, be), bns) = \
             self._gather(x, A_eff, mst, nnz_cap, bterm, pattern)
         cfg.packed = packed
+        cfg.seed_epoch = seed_epoch
         bn1, bn2 = bns[0], bns[1]
         bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
         if len(bns) > 2:
@@ -403,6 +406,18 @@ class STGCNModel(nn.Module):
         out = Fn.FoldAllFn.apply(self._fold_B(imps[0][0].device), Cs, len(names), *biases, *[p for imp in imps for p in imp])
         return [(out[2 * i], out[2 * i + 1]) for i in range(len(blocks))]
 
+    def device_seed_epoch(self, device=None):
+        """Switch the dropout masks to `seed + *epoch` with `epoch` an int64[1] counter on the GPU (returned; created on
+        first use): a training step recorded once in a hipGraph then draws fresh masks on every replay as long as the
+        counter is advanced once per step (harness.GraphedStep records `epoch += 1` at the head of the graph).  The host
+        seed is still drawn per eager forward; under replay it is the value drawn at capture time."""
+        ep = self.__dict__.get('_seed_epoch')
+        if ep is None:
+            device = device if device is not None else next(self.parameters()).device
+            ep = torch.zeros(1, dtype=torch.int64, device=device)
+            self.__dict__['_seed_epoch'] = ep
+        return ep
+
     def _packed_weights(self, x):
         """Every weight pack of the trunk in ONE launch per forward (they were ~46 launches per step): the plan is rebuilt
         when a parameter's storage moved (an optimizer re-pointing `.data` into its flat buffer, `.to()`), the launch is
@@ -461,7 +476,7 @@ class STGCNModel(nn.Module):
                 continue
             A_eff, bterm = folds[i] if folds is not None else self._folded(i, blk)
             x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False,
-                        packed=packed[i])
+                        packed=packed[i], seed_epoch=self.__dict__.get('_seed_epoch'))
         return x
 
     def forward(self, x):

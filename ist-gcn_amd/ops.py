@@ -175,7 +175,8 @@ def tconv_geometry(V, cin, cout, tap_off, in_mul, dt):
 
 def pack_tconv_weight(wf, V, tap_off, in_mul, dtype, tap_sel=None):
     """wf: [taps][Cout][Cin] fp32 view (any strides) -> [nch][ntaps][NKG][MTtot][2][32][EPL] fragments
-    (istgcn_pack_tconv, one launch).  tap_sel: which taps of wf feed the len(tap_off) packed taps (default: all, in
+    (istgcn_pack_tconv, one launch) followed by a tail pad of six steps that the kernel's weight ring may read but never
+    uses (istgcn_pack_tconv_elems sizes it; host tensors get the bare specification: they never feed a kernel).  tap_sel: which taps of wf feed the len(tap_off) packed taps (default: all, in
     order) -- the data gradient packs a per-phase subset of the transposed view without materialising it."""
     if tap_sel is None:
         tap_sel = list(range(wf.shape[0]))
@@ -460,18 +461,26 @@ def _rows(t):
     return t.numel() // t.shape[-1]
 
 
-def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0):
+def _epoch_ptr(epoch, like):
+    """Device-resident dropout seed offset (int64[1] on the tensors' device) or None -> pointer argument."""
+    if epoch is None:
+        return None
+    assert epoch.dtype == torch.int64 and epoch.numel() == 1 and epoch.device == like.device
+    return _ptr(epoch)
+
+
+def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0, epoch=None):
     out = torch.empty_like(z)
     dv = _check_dev(z, coef2, res, coefr, out)
     if res is not None:
         assert res.shape == z.shape and res.dtype == z.dtype
     _call('istgcn_block_out_fwd', _ptr(z), _ptr(coef2), _ptr(res), _ptr(coefr), _ptr(out), ctypes.c_longlong(_rows(z)),
-          z.shape[-1], ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
+          z.shape[-1], ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
           work=(3.0 * z.numel(), float(z.numel()) * (3 if res is not None else 2) * _esz(z)), dev=dv)
     return out
 
 
-def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False):
+def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None):
     """-> (dres = dout*[out>0], stats2, statsr or None); scratch=True: the sums go to `stats_scratch` slots 0 / 1
     (consume them with bn_bwd_coef(clear=True))."""
     C = z.shape[-1]
@@ -486,17 +495,17 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
     dv = _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
     _call('istgcn_block_out_bwd', _ptr(dout), _ptr(out), _ptr(z), _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres),
           _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C, ctypes.c_float(p_drop),
-          ctypes.c_ulonglong(seed), dtype_code(z), _stream(z),
+          ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
           work=(6.0 * z.numel(), float(z.numel()) * (5 if r is not None else 4) * _esz(z)), dev=dv)
     return dres, st2, str_
 
 
-def affine2(d, x, abc, p_drop=0.0, seed=0):
+def affine2(d, x, abc, p_drop=0.0, seed=0, epoch=None):
     """out = abc[0]*d*dropmask + abc[1]*x + abc[2]  (BatchNorm backward, elementwise part)."""
     out = torch.empty_like(d)
     dv = _check_dev(d, x, abc, out)
     _call('istgcn_affine2', _ptr(d), _ptr(x), _ptr(abc), _ptr(out), ctypes.c_longlong(_rows(d)), d.shape[-1],
-          ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), dtype_code(d), _stream(d),
+          ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, d), dtype_code(d), _stream(d),
           work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)), dev=dv)
     return out
 
