@@ -117,10 +117,8 @@ int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_
  *                        (nn.Conv2d(C, C, (k,1)).weight [o][i][t][1]: s_o = Cin*k, s_i = k, s_t = 1; the data gradient
  *                        swaps s_o / s_i and selects the taps of its output phase) -> Wp of istgcn_tconv
  *   istgcn_pack_gcn_bwd: W3[k][c][i] at src + k*s_k + c*s_c + i*s_i -> Wb of istgcn_gcn_bwd_data
- * istgcn_pack_tconv_elems includes a tail pad of six steps (6 * MTtot * 64 * EPL elements) behind the fragments: the
- * kernel's weight ring may READ it (loads of the ghost steps that pad an item to whole rounds) but never uses it; a Wp
- * handed to istgcn_tconv must be at least that long.  The gcn contraction length K*CCeff is padded (with zero columns)
- * to whole ring rounds inside the layout itself (istgcn_gcn_geometry's KKp). */
+ * The gcn contraction length K*CCeff is padded (with zero columns) to whole rounds of the kernel's weight ring inside
+ * the layout itself (istgcn_gcn_geometry's KKp). */
 long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype);
 int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, long long s_i, void* dst, int Cin, int Cout, int K,
                     int dtype, void* stream);

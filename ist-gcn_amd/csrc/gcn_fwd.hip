@@ -50,7 +50,8 @@ struct GcnFwdParams {
   int gx_div, gx_mod;    // gridDim.x = gx_div * tiles_per_seq + gx_mod (item cursors advance without dividing)
   int a_lds;             // the adjacency fits the work buffers: setup reads it from an LDS copy
   unsigned long long* dbg;  // diagnostic: per-phase cycle sums of workgroup 0 (ISTGCN_GCN_DBG)
-  int abl;               // diagnostic ablation mask (ISTGCN_GCN_ABL): 1 no aggregation, 2 no contraction, 4 no image store, 8 no input loads/commit
+  int abl;               // diagnostic ablation mask (ISTGCN_GCN_ABL; results are then wrong): 1 no aggregation, 2 no contraction,
+                         // 4 no image store, 8 no input loads / commit, 256 return at once (launch cost), 512 return after the setup
   int off_csr_v, off_csr_a, off_stat, off_rows, off_afrag, off_bterm, off_xs0, off_xs1, off_xa, off_o;  // LDS byte offsets
 };
 
@@ -267,9 +268,6 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   const int CT = (P.CCeff + 31) >> 5;
   const int NC = CT * K;                                                      // unit columns (channel tile, partition)
   const unsigned rcpK = (65536u + K - 1) / K;                                 // c / K for c < 256 as (c * rcpK) >> 16
-  // u / nf for the two tile heights that occur (full tiles, the last tile of a sequence)
-  const int nf_tail = P.Tlog - (P.tiles_per_seq - 1) * P.F;
-  const unsigned rcpF = ((1u << 20) + P.F - 1) / P.F, rcpTail = ((1u << 20) + nf_tail - 1) / nf_tail;
   auto aggregate = [&](const T* xs, int nf, int w8) __attribute__((always_inline)) {
     if (P.abl & 1) return;
     if constexpr (sizeof(T) == 2) if (V <= 32) {
@@ -277,95 +275,91 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
       // D[i][w] = sum_v x[(f,v)][i] * A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows
       // v beyond the frame multiply zero adjacency rows and are kept finite by the memory waves), A_k fragments from LDS;
       // the VALU version of this pass cost ~2500 instructions per wave and tile (conversions + addressing) against 24
-      // MFMAs of real work.  A unit is one dependent chain (LDS reads -> 2 MFMAs -> convert -> LDS writes) and the phase
-      // is bound by INSTRUCTION ISSUE (two waves share a SIMD), so: units are ordered column-major (frames fastest),
-      // each wave takes one contiguous range -- two twelfths per compute wave, one per memory wave, which enters late --
-      // and walks it with two address increments per unit; the A_k fragments are re-read only when the column changes;
-      // two units are in flight per wave (the MFMAs of the next one are issued before this one's conversions).
-      const int nunit = nf * NC;
-      const int pre0 = w8 < 4 ? 2 * w8 : 4 + w8, pre1 = w8 < 4 ? pre0 + 2 : pre0 + 1;
-      const int u0 = nunit * pre0 / 12, u1 = nunit * pre1 / 12;
-      int n = u1 - u0;
-      if (n <= 0) return;
-      int c = (int)(((unsigned)u0 * (nf == P.F ? rcpF : rcpTail)) >> 20), f = u0 - c * nf;
-      int afe = 0, srce = 0, dste = 0, lim = 0;
-      bool full = false;
-      auto column = [&]() __attribute__((always_inline)) {
+      // MFMAs of real work.  The phase is bound by INSTRUCTION ISSUE (SQ counters: ~2200 vector + ~2200 scalar
+      // instructions per item and workgroup when every unit decoded its own (c, f) and re-read the A_k fragments), so
+      // the work is cut into TASKS = (column, half of the frames): a task reads its two A_k fragments once and then walks
+      // its frames with five address increments each, three stages (LDS reads / MFMAs / convert + write) one frame
+      // apart.  Twelve task slots per round: two per compute wave (one short half and one long half each), one per
+      // memory wave, which enters this phase late, behind its commit and stores.
+      const int T2 = NC * 2;
+      const int h0 = nf >> 1;                               // frames [0, h0) and [h0, nf)
+      const int sstep = V * P.xs_stride, dstep = V * P.xa_stride;
+      auto task = [&](int t) __attribute__((always_inline)) {
+        const int c = t >> 1, hf = t & 1;
+        const int f0 = hf ? h0 : 0, n = hf ? nf - h0 : h0;
+        if (n <= 0) return;
         const int ct = (int)(((unsigned)c * rcpK) >> 16), kk = c - ct * K;
-        afe = kk * (2 * 64 * EPL) + lane * EPL;
-        srce = f * V * P.xs_stride + ct * 32 + a_src;
-        dste = f * V * P.xa_stride + kk * P.CCeff + ct * 32 + a_dst;
-        full = P.CCeff - ct * 32 >= 32;
+        const T* af = afrag + kk * (2 * 64 * EPL) + lane * EPL;
+        const frag_t b0 = *reinterpret_cast<const frag_t*>(af);
+        const frag_t b1 = *reinterpret_cast<const frag_t*>(af + 64 * EPL);
+        const bool full = P.CCeff - ct * 32 >= 32;
         // channels of the chunk at or above this lane's first quad (quad g is channel i0 + 8g); adjacency columns
         // w >= V have nothing to write
-        lim = a_w < V ? P.CCeff - ct * 32 - 4 * (lane >> 5) : 0;
-      };
-      column();
-      // Waves issue in order, so the chain is cut into three stages that run one unit apart:
-      //   rd(u+2)  six LDS reads into operand set (u+2)&1      mm(u+1)  two MFMAs on the set read one round earlier
-      //   put(u)   convert + four LDS writes of the accumulators issued one round earlier
-      struct Ops { frag_t x0, x1, b0, b1; int o, l; bool fl; };
-      auto rd = [&](Ops& q) __attribute__((always_inline)) {
-        const T* r0 = xs + srce;
-        q.x0 = tr_pair<T>(r0, r0 + 4 * P.xs_stride);
-        q.x1 = tr_pair<T>(r0 + 16 * P.xs_stride, r0 + 20 * P.xs_stride);
-        q.b0 = *reinterpret_cast<const frag_t*>(afrag + afe);
-        q.b1 = *reinterpret_cast<const frag_t*>(afrag + afe + 64 * EPL);
-        q.o = dste; q.l = lim; q.fl = full;
-        srce += V * P.xs_stride;                            // next frame of the column ...
-        dste += V * P.xa_stride;
-        if (++f == nf) { f = 0; ++c; column(); }            // ... or the next column (harmless one past the range)
-      };
-      auto mm = [&](const Ops& q, f32x16& d) __attribute__((always_inline)) {
+        const int lim = a_w < V ? P.CCeff - ct * 32 - 4 * (lane >> 5) : 0;
+        int srce = f0 * sstep + ct * 32 + a_src;
+        int dste = f0 * dstep + kk * P.CCeff + ct * 32 + a_dst;
+        auto rd = [&](frag_t& x0, frag_t& x1) __attribute__((always_inline)) {
+          const T* r0 = xs + srce;
+          x0 = tr_pair<T>(r0, r0 + 4 * P.xs_stride);
+          x1 = tr_pair<T>(r0 + 16 * P.xs_stride, r0 + 20 * P.xs_stride);
+          srce += sstep;
+        };
+        auto mm = [&](const frag_t& x0, const frag_t& x1, f32x16& d) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d[r] = 0.f;
-        mma_kgroup(d, q.x0, q.b0);
-        mma_kgroup(d, q.x1, q.b1);
-      };
-      auto put = [&](const f32x16& d, int o, int l, bool fl) __attribute__((always_inline)) {
-        if (fl) {
-          if (l > 0) {
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          mma_kgroup(d, x0, b0);
+          mma_kgroup(d, x1, b1);
+        };
+        auto put = [&](const f32x16& d) __attribute__((always_inline)) {
+          if (full) {
+            if (lim > 0) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                store4(xa + dste + 8 * g, v4);
+              }
+            }
+          } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-              store4(xa + o + 8 * g, v4);
+              if (8 * g < lim) {
+                float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+                store4(xa + dste + 8 * g, v4);
+              }
             }
           }
-        } else {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (8 * g < l) {
-              float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-              store4(xa + o + 8 * g, v4);
-            }
-          }
+          dste += dstep;
+        };
+        frag_t xa0, xa1, xb0, xb1;
+        f32x16 d0, d1;
+        rd(xa0, xa1);
+        if (n > 1) rd(xb0, xb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(xa0, xa1, d0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < n; i += 2) {
+          if (i + 2 < n) rd(xa0, xa1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 < n) mm(xb0, xb1, d1);
+          __builtin_amdgcn_sched_barrier(0);
+          put(d0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 1 >= n) break;
+          if (i + 3 < n) rd(xb0, xb1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 2 < n) mm(xa0, xa1, d0);
+          __builtin_amdgcn_sched_barrier(0);
+          put(d1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
-      Ops qa, qb;
-      f32x16 d0, d1;
-      rd(qa);
-      if (n > 1) rd(qb);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(qa, d0);
-      int oa = qa.o, la = qa.l, ob = 0, lb = 0;
-      bool fa = qa.fl, fb = false;
-      __builtin_amdgcn_sched_barrier(0);
-      for (int i = 0; i < n; i += 2) {
-        // even unit i: its MFMAs are in flight in d0, the operands of i+1 in qb
-        if (i + 2 < n) rd(qa);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < n) { mm(qb, d1); ob = qb.o; lb = qb.l; fb = qb.fl; }
-        __builtin_amdgcn_sched_barrier(0);
-        put(d0, oa, la, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 >= n) break;
-        // odd unit i+1
-        if (i + 3 < n) rd(qb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < n) { mm(qa, d0); oa = qa.o; la = qa.l; fa = qa.fl; }
-        __builtin_amdgcn_sched_barrier(0);
-        put(d1, ob, lb, fb);
-        __builtin_amdgcn_sched_barrier(0);
+      if (w8 < 4) {
+        for (int base = 0; base < T2; base += 12) {
+          if (base + w8 < T2) task(base + w8);
+          if (base + 7 - w8 < T2) task(base + 7 - w8);
+        }
+      } else {
+        for (int t = 4 + w8; t < T2; t += 12) task(t);
       }
       return;
     }

@@ -219,9 +219,7 @@ extern "C" long long istgcn_pack_tconv_elems(int V, int Cin, int Cout, int ntaps
                                              int dtype) {
   int cc, nch, mttot, epl;
   if (istgcn_tconv_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &cc, &nch, &mttot, &epl)) return -1;
-  // + a tail pad of 6 steps (never written, never used in arithmetic): the kernel's weight ring issues the loads of an
-  // item's ghost steps -- padding of ntaps * NKG to whole rounds of 6 -- unconditionally (tconv.hip)
-  return (long long)nch * ntaps * cc * mttot * 32 + 6LL * mttot * 64 * epl;
+  return (long long)nch * ntaps * cc * mttot * 32;
 }
 
 extern "C" int istgcn_pack_tconv(const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,

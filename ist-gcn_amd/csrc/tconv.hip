@@ -61,7 +61,6 @@ struct TconvParams {
   int F, tiles_per_seq, total_tiles, CC, nch, NKG, MTtot, min_off, Fin;
   int us_stride, out_stride, off_stat, off_u0, off_u1, off_o;
   int cin_pad;           // nch * CC: length of the LDS copies of the `pre` rows
-  unsigned long long* dbg;  // diagnostic: per-phase cycle sums of workgroup 0 (ISTGCN_TCONV_DBG)
   int abl;               // diagnostic ablation (ISTGCN_TCONV_ABL): 1 = no input loads, 2 = no MFMAs; results are then wrong
 };
 
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const bool is_compute = tid < NROLE;
-  const int ltid = tid & (NROLE - 1), wave = __builtin_amdgcn_readfirstlane(ltid >> 6);   // wave-uniform: tell the compiler
+  const int ltid = tid & (NROLE - 1), wave = ltid >> 6;
   const int V = P.V;
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
@@ -158,8 +157,6 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     return t;
   };
   lds_barrier();
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#define STAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 
   if (is_compute) {
     // =========================================== compute waves ===========================================
@@ -175,64 +172,54 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     // last item read fragment 0 -- and only the MFMAs are predicated.  With nitp a multiple of DA the ring slot of a step
     // is its position in the unrolled chunk, and the first steps of the next item are already in flight when an item ends.
     constexpr int DA = 6;                                   // weight ring: 5 steps ahead
-    constexpr int DB = NTW >= 4 ? 2 : 3;                    // activation ring: DB-1 steps ahead (divides DA: static slots);
-                                                            // one step of NTW >= 4 row tiles is >= 256 cycles of MFMA: one ahead covers LDS
+    constexpr int DB = NTW >= 8 ? 2 : 3;                    // activation ring: DB-1 steps ahead (divides DA: static slots)
     constexpr int PD = DB - 1;
-    constexpr unsigned FRAGB = 64 * EPL * sizeof(T);        // bytes of one fragment (1 KB)
     f32x16 acc[MTW][NTW];
     int brow[NTW];                                          // element offset of the lane's fragment at tap offset 0
     const int wr = wave / WM, wm = wave % WM;               // row group, channel group of this wave
     const int hoff = (lane >> 5) * EPL;
-    const int nit = P.ntaps * P.NKG;                       // steps per item; NKG is 1 or 2 (checked on the host)
-    const int R = (nit + DA - 1) / DA;                     // rounds of DA steps per item
-    const int nlast = nit - (R - 1) * DA;                  // real steps of an item's last round (DA: no ghost steps)
+    const int nit = P.ntaps * P.NKG;                       // steps per item; NKG is a power of two
+    const int nitp = (nit + DA - 1) / DA * DA;
     const int lkg = 31 - __builtin_clz(P.NKG);
     const int roff0 = (P.tap_off[0] - P.min_off) * V;
     const int rstep = P.ntaps > 1 ? (P.tap_off[1] - P.tap_off[0]) * V : 0;
+    const int period = nch * nit;
+    const size_t astride = (size_t)P.MTtot * 64 * EPL;      // elements between the fragments of consecutive steps
+    const T* abase = Wp + ((size_t)(mt0 + wm * MTW) * 64 + lane) * EPL;
     // fragments live in the rings as four raw dwords: loop-carried arrays of 8 x 16-bit vectors get scalarised and re-packed
     // element by element (20 v_perm_b32 per step in the first build); they become MFMA operands by a bit cast
     u32x4 a[DA][MTW], b[DB][NTW];
-    // The weight ring, in ROUNDS of DA steps.  Slot d holds step d of the current round; step d of a round issues the
-    // load of the slot just freed: step DA-1 of this round (d = 0) or step d-1 of the NEXT round -- whatever chunk or tile
-    // that belongs to -- so every fragment is requested DA-1 steps ahead and the ring never drains across items.
-    // Addresses are two wave-uniform bases (this round, next round) + a per-lane 32-bit offset per slot (precomputed once)
-    // + an immediate.  The first wave-specialised build kept a running position per step (wrap, ghost steps, tap /
-    // k-group of the activation fragment): ~11 scalar/vector instructions per MFMA of bookkeeping, and its SQ counters
-    // showed the matrix pipe 36-43 % busy with the compute waves never waiting on memory -- it was issue-bound.
-    // An item's last round may hold ghost steps (nit not a multiple of DA): their loads read on into the next chunk or the
-    // tail pad of the packed tensor (istgcn_pack_tconv_elems) and only the MFMAs are predicated, so the number of loads
-    // per round stays constant and the compiler's s_waitcnt bookkeeping exact.
-    const unsigned astride_b = (unsigned)P.MTtot * FRAGB;   // bytes between the fragments of consecutive steps
-    const char* wblk = reinterpret_cast<const char*>(Wp) + (size_t)(mt0 + wm * MTW) * FRAGB;   // wave-uniform
-    unsigned voff[DA];
+    // running positions (a handful of scalar adds / selects per step; recomputing tap, k-group and offsets from the step
+    // number cost ~20 scalar instructions per 4-8 MFMAs, and the 64-channel layers are instruction-issue bound)
+    size_t aoff = 0;                                        // element offset of the next real ring fragment (wraps at alimit)
+    const size_t alimit = (size_t)period * astride;
+    int ppos = 0;                                           // padded step (mod nitp) the next ring load is for
+    auto load_a = [&](u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
+      // branch-free: a ghost step (padding of an item to a multiple of DA steps) reads fragment 0 and does not advance
+      const bool real = ppos < nit;
+      const size_t off = real ? aoff : 0;
 #pragma unroll
-    for (int d = 0; d < DA; ++d) voff[d] = (unsigned)lane * 16u + (unsigned)d * astride_b;
-    auto ldw = [&](const char* base, int d, u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(base + (size_t)voff[d] + m * FRAGB);
+      for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + off + (size_t)m * 64 * EPL);
+      const size_t an = aoff + (real ? astride : 0);
+      aoff = an == alimit ? 0 : an;
+      ppos = ppos + 1 == nitp ? 0 : ppos + 1;
     };
-    int ch_n = 0, r_n = 0;                                  // chunk / round of `nxt`
-    auto advance = [&]() __attribute__((always_inline)) {
-      if (++r_n == R) { r_n = 0; if (++ch_n == nch) ch_n = 0; }
-      return wblk + (size_t)(ch_n * nit + r_n * DA) * astride_b;
+    const T* us = ubuf(0);
+    // activation fragments of the NEXT not yet loaded step of the current item: running (k-group, offset) pair; past the
+    // item's last step it stays there (the slot is reloaded with the same fragment and never used)
+    const int tapstep = rstep * P.us_stride - (P.NKG - 1) * KGS;
+    int sb = 0, kgb = 0, soffb = 0;                         // step, its k-group, its element offset in the tile
+    auto load_b = [&](u32x4 (&dst)[NTW]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) dst[tt] = *reinterpret_cast<const u32x4*>(us + brow[tt] + soffb);
+      const bool adv = sb + 1 < nit;
+      const bool wrap = kgb + 1 == P.NKG;
+      soffb += adv ? (wrap ? tapstep : KGS) : 0;
+      kgb = adv ? (wrap ? 0 : kgb + 1) : kgb;
+      sb += adv ? 1 : 0;
     };
-    const char* cur = wblk;
 #pragma unroll
-    for (int d = 0; d < DA - 1; ++d) {                      // in flight while the first chunk is being staged
-      ldw(cur, d, a[d]);
-      // keep the issue order slot 0, 1, ...: the loop's waits count loads YOUNGER than the slot they need, and the
-      // compiler takes the minimum over the loop's entry paths (a reordered prologue makes every wait near-total)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    const char* nxt = advance();
-    // activation fragments: step s of an item is (tap s / NKG, k-group s % NKG).  DA is a multiple of NKG, so step j of
-    // round r sits at  round base + oj[j],  oj[j] = (j / NKG) * (elements per tap) + (j % NKG) * KGS  -- eight wave-uniform
-    // offsets computed once; look-ahead past an item's last real step re-reads the round's first fragment.
-    const int tapB = rstep * P.us_stride;
-    int oj[DA + PD];
-#pragma unroll
-    for (int jj = 0; jj < DA + PD; ++jj) oj[jj] = ((jj >> lkg) * tapB + (jj & (P.NKG - 1)) * KGS) * (int)sizeof(T);   // bytes
-    const int rbstep = (DA >> lkg) * tapB * (int)sizeof(T); // round base advance, bytes
+    for (int d = 0; d < DA - 1; ++d) load_a(a[d]);         // in flight while the first chunk is being staged
     lds_barrier();                                          // item 0 staged (the memory waves' prologue)
     int ch = 0, k = 0;
     for (int it = 0; it < total_items; ++it) {
@@ -257,32 +244,20 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
           brow[tt] = (p < t.rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0) * P.us_stride + hoff;
         }
       }
-      // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations PD steps ahead),
-      // which are independent of each other: sched_group_barrier asks for them to be INTERLEAVED -- one MFMA, then the
-      // loads in the 32-cycle shadow of that MFMA -- instead of a clump of load instructions in front of the MFMA group.
-      // byte offsets in LDS, never pointers: an array of LDS pointers decays to generic pointers (flat loads)
-      int bp[NTW];
-      {
-        const int ub = (it & 1) ? P.off_u1 : P.off_u0;
+      sb = 0; kgb = 0; soffb = roff0 * P.us_stride;         // taps are an arithmetic progression (checked on the host)
 #pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) bp[tt] = ub + (brow[tt] + roff0 * P.us_stride) * (int)sizeof(T);   // taps are an arithmetic progression (checked on the host)
-      }
-      {
-        const int nr0 = R == 1 ? nlast : DA + PD;
-#pragma unroll
-        for (int d = 0; d < PD; ++d)
-#pragma unroll
-          for (int tt = 0; tt < NTW; ++tt) b[d][tt] = *reinterpret_cast<const u32x4*>(smem + bp[tt] + (d < nr0 ? oj[d] : oj[0]));
-      }
+      for (int d = 0; d < PD; ++d) load_b(b[d]);
+      // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations two steps ahead),
+      // which are independent of each other: sched_group_barrier asks for them to be INTERLEAVED -- one MFMA, then a few
+      // of the other instructions in the 32-cycle shadow of that MFMA -- instead of a clump of ~50 address / load
+      // instructions in front of the MFMA group, during which the matrix pipe idles (SQ counters of the first
+      // wave-specialised build: MFMA pipe 45 % busy although the compute waves never waited on memory).
 #define TCONV_STEP(D, PRED)                                                                              \
       {                                                                                                  \
-        if ((D) == 0) ldw(cur, DA - 1, a[DA - 1]); else ldw(nxt, (D) - 1, a[(D) - 1]);                   \
-        {                                                                                                \
-          const int ob_ = (D) + PD < nrb ? oj[(D) + PD] : oj[0];                                         \
-          _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt)                                             \
-            b[((D) + PD) % DB][tt] = *reinterpret_cast<const u32x4*>(smem + bp[tt] + ob_);               \
-        }                                                                                                \
-        if (!(PRED) || (D) < nreal) {                                                                    \
+        const int st_ = s0 + (D);                                                                        \
+        load_a(a[((D) + DA - 1) % DA]);                                                                  \
+        load_b(b[((D) + PD) % DB]);                                                                      \
+        if (!(PRED) || st_ < nit) {                                                                      \
           _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                \
             _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) mma_kgroup(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); \
         }                                                                                                \
@@ -290,31 +265,21 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* one MFMA */                            \
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* one LDS read */                        \
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* one global read */                     \
-          __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);   /* a few VALU / SALU */                   \
+          __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);   /* a few VALU / SALU */                   \
         }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
       }
-      STAMP(0)
-      const int Rf = nit / DA;                              // full rounds; then at most one round with ghost steps
-      for (int r = 0; r < Rf; ++r) {
-        const int nreal = DA;
-        const int nrb = r == R - 1 ? DA : DA + PD;          // activation look-ahead stays inside the item
+      const int nfull = nit / DA;
+      int s0 = 0;
+      for (int c = 0; c < nfull; ++c, s0 += DA) {
         TCONV_STEP(0, false) TCONV_STEP(1, false) TCONV_STEP(2, false) TCONV_STEP(3, false) TCONV_STEP(4, false) TCONV_STEP(5, false)
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) bp[tt] += rbstep;
-        cur = nxt;
-        nxt = advance();
       }
-      if (Rf < R) {                                         // ghost steps keep the ring's cadence
-        const int nreal = nlast, nrb = nlast;
+      if (s0 < nit) {                                       // remainder chunk: ghost steps keep the ring's cadence
         TCONV_STEP(0, true) TCONV_STEP(1, true) TCONV_STEP(2, true) TCONV_STEP(3, true) TCONV_STEP(4, true) TCONV_STEP(5, true)
-        cur = nxt;
-        nxt = advance();
       }
 #undef TCONV_STEP
-      STAMP(1)
+      us = ubuf((it + 1) & 1);
       lds_barrier();                                        // item done: this half of the tile buffer may be refilled
-      STAMP(2)
       if (++ch == nch) {
         ch = 0;
         ++k;
@@ -338,15 +303,11 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
               }
             }
           }
-          STAMP(3)
           lds_barrier();                                    // image of pass ps complete
           if (ps < NPASS - 1) lds_barrier();                // ... and streamed out by the memory waves: reusable
-          STAMP(4)
         }
       }
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-      for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i];
   } else {
     // =========================================== memory waves ============================================
     const int Q = P.CC / EPL;                               // 16-byte vectors per staged row: 2 or 4 (power of two)
@@ -578,14 +539,10 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       __builtin_amdgcn_sched_barrier(0);
       issue(it + 2, Rf);                                    // (past the last item: dead slots, same number of loads)
       __builtin_amdgcn_sched_barrier(0);
-      STAMP(0)
       if (it + 1 < total_items && P.abl != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
       __builtin_amdgcn_sched_barrier(0);
-      STAMP(1)
       if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AV); pending = false; }
-      STAMP(2)
       lds_barrier();                                        // item `it` computed, item it+1 staged
-      STAMP(3)
       if (ch == nch - 1) {                                  // tile end: take over the output image
         const Tile t = tile_of(k);
 #pragma unroll
@@ -600,7 +557,6 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         }
         pending = true;
         pend = t;
-        STAMP(4)
       }
     };
     for (int it = 0; it < total_items; it += 2) {
@@ -613,8 +569,6 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AVl);
     }
 
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0)
-      for (int i = 0; i < 6; ++i) P.dbg[8 + i] = tacc[i];
     // ---- BatchNorm partial sums: registers -> lanes sharing a channel vector -> LDS ----
     if (P.stats) {
 #pragma unroll
@@ -724,25 +678,6 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
   const size_t lds = G.lds;
   const char* e_abl = getenv("ISTGCN_TCONV_ABL");
   P.abl = e_abl ? atoi(e_abl) : 0;
-  unsigned long long* dbuf = nullptr;
-  if (getenv("ISTGCN_TCONV_DBG")) {
-    static unsigned long long* dbuf_s = nullptr;
-    if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
-    dbuf = dbuf_s;
-    (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
-    P.dbg = dbuf;
-  }
-  struct DbgPrint {                 // after the launch returns: read back and print the phase sums
-    unsigned long long* b; hipStream_t st; const TconvParams* P; int nt;
-    ~DbgPrint() {
-      if (!b) return;
-      unsigned long long h[16];
-      (void)hipMemcpyAsync(h, b, sizeof(h), hipMemcpyDeviceToHost, st);
-      (void)hipStreamSynchronize(st);
-      fprintf(stderr, "tconv dbg Cin=%d Cout=%d mode=%d NT=%d | compute: init %llu mfma %llu itembar %llu image %llu tilebar %llu | memory: issue %llu commit %llu store %llu itembar %llu tileend %llu\n",
-              P->Cin, P->Cout, P->mode, nt, h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[12]);
-    }
-  } dbgp{dbuf, stream, &P, G.NT};
   // compute-wave layout: two channel groups x two row groups wherever there are two channel tiles to split
 #define CASE(MTv, NTv, WMv) if (G.MT == MTv && G.NT == NTv) return launch4<T, MTv, NTv, WMv>(P, grid_cap, G.gy, lds, stream)
 #ifdef ISTGCN_TCONV_ONE          /* ISA inspection builds: one instantiation */

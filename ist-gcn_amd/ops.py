@@ -175,8 +175,7 @@ def tconv_geometry(V, cin, cout, tap_off, in_mul, dt):
 
 def pack_tconv_weight(wf, V, tap_off, in_mul, dtype, tap_sel=None):
     """wf: [taps][Cout][Cin] fp32 view (any strides) -> [nch][ntaps][NKG][MTtot][2][32][EPL] fragments
-    (istgcn_pack_tconv, one launch) followed by a tail pad of six steps that the kernel's weight ring may read but never
-    uses (istgcn_pack_tconv_elems sizes it; host tensors get the bare specification: they never feed a kernel).  tap_sel: which taps of wf feed the len(tap_off) packed taps (default: all, in
+    (istgcn_pack_tconv, one launch).  tap_sel: which taps of wf feed the len(tap_off) packed taps (default: all, in
     order) -- the data gradient packs a per-phase subset of the transposed view without materialising it."""
     if tap_sel is None:
         tap_sel = list(range(wf.shape[0]))
