@@ -694,10 +694,30 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
 
 }  // namespace
 
+// Round-1 kernel (tconv_small.hip), same arguments: serves the shapes without matrix work to overlap.
+extern "C" int istgcn_tconv_v1_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype,
+                                        int* CC, int* nch, int* MTtot, int* EPL);
+extern "C" int istgcn_tconv_v1(const void* in, const void* Wp, const float* bias, const float* pre, int pre_relu,
+                               const void* aux, const float* maux, void* out, double* stats, int stats_rep, int mode,
+                               int NM, int Tin, int Tout, int Mlog, int V, int Cin, int Cout, int ntaps,
+                               const int* tap_off, int in_mul, int out_mul, int out_off, int dtype, int grid_cap,
+                               void* stream);
+// Which kernel serves a shape (the packed-weight geometry follows the same decision).  ISTGCN_TCONV_V1=0/1 forces one
+// of them for A/B runs (set it before any weight is packed).
+static bool tconv_use_v1(int Cin, int Cout) {
+  static const int forced = [] { const char* e = getenv("ISTGCN_TCONV_V1"); return e ? atoi(e) : -1; }();
+  if (forced == 0 || forced == 1) return forced == 1;
+  // measured on config 5's bottleneck (fp16, NM=256; us new / round-1 kernel): 64->8 244/201, 128->11 831/552, 256->16
+  // 207/140, but 8->64 163/194, 16->256 131/182, 8->8 (15 taps) 160/195, 11->11 235/188: few OUTPUT channels behind many
+  // input channels (or unaligned ones) stream better from eight loading waves
+  return Cout <= 32 && (Cin > 32 || (Cin & 7) != 0);
+}
+
 extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype,
                                      int* CC, int* nch, int* MTtot, int* EPL) {
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (!tap_off || ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1) return ISTGCN_EINVAL;
+  if (tconv_use_v1(Cin, Cout)) return istgcn_tconv_v1_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, CC, nch, MTtot, EPL);
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
@@ -721,6 +741,9 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   for (int j = 2; j < ntaps; ++j)      // taps must be equally spaced (every forward / data-gradient phase of a conv is)
     if (tap_off[j] - tap_off[j - 1] != tap_off[1] - tap_off[0]) return ISTGCN_EINVAL;
   if (NM == 0 || Mlog == 0) return ISTGCN_OK;
+  if (tconv_use_v1(Cin, Cout))
+    return istgcn_tconv_v1(in, Wp, bias, pre, pre_relu, aux, maux, out, stats, stats_rep, mode, NM, Tin, Tout, Mlog, V, Cin, Cout,
+                           ntaps, tap_off, in_mul, out_mul, out_off, dtype, grid_cap, stream);
   TconvParams P{};
   P.in = in; P.Wp = Wp; P.bias = bias; P.pre = pre; P.aux = aux; P.maux = maux; P.out = out; P.stats = stats;
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Mlog = Mlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
