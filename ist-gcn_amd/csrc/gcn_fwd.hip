@@ -847,6 +847,19 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
 
 }  // namespace
 
+// Round-1 kernel (gcn_fwd_small.hip), same arguments: serves fp32 storage (VALU aggregation either way; no LDS room for
+// the wave-specialised layout at full chunk width).  ISTGCN_GCN_V1=0/1 forces one kernel for A/B runs (before packing).
+extern "C" int istgcn_gcn_fwd_v1(const void* x, const float* A, const void* Wp, const float* bterm,
+                                 const void* addend, void* y, double* stats, int stats_rep, int* status,
+                                 int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
+                                 int in_t_stride, int out_t_stride, int nnz_cap, int dtype, int grid_cap, void* stream);
+extern "C" int istgcn_gcn_v1_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp, int* MTtot, int* EPL);
+static bool gcn_use_v1(int dtype) {
+  static const int forced = [] { const char* e = getenv("ISTGCN_GCN_V1"); return e ? atoi(e) : -1; }();
+  if (forced == 0 || forced == 1) return forced == 1;
+  return dtype == 0;
+}
+
 extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* bterm,
                               const void* addend, void* y, double* stats, int stats_rep, int* status,
                               int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
@@ -858,6 +871,9 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   if (Tlog > 0 && ((Tlog - 1) * in_t_stride >= Tin || (Tlog - 1) * out_t_stride >= Tout)) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;
   if (NM == 0 || Tlog == 0) return ISTGCN_OK;
+  if (gcn_use_v1(dtype))
+    return istgcn_gcn_fwd_v1(x, A, Wp, bterm, addend, y, stats, stats_rep, status, NM, Tin, Tout, Tlog, V, Cin, Cout, K, in_t_stride,
+                             out_t_stride, nnz_cap, dtype, grid_cap, stream);
   GcnFwdParams P{};
   P.x = x; P.A = A; P.Wp = Wp; P.bterm = bterm; P.addend = addend; P.y = y; P.stats = stats; P.status = status;
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Tlog = Tlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K;
@@ -873,6 +889,7 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
 extern "C" int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp,
                                    int* MTtot, int* EPL) {
   if (!istgcn_dtype_ok(dtype) || Cin < 1 || Cout < 1 || K < 1) return ISTGCN_EINVAL;
+  if (gcn_use_v1(dtype)) return istgcn_gcn_v1_geometry(Cin, Cout, K, dtype, CCeff, nch, KKp, MTtot, EPL);
   GcnGeom G;
   if (int rc = gcn_geom(Cin, Cout, K, dtype, &G)) return rc;
   *CCeff = G.CCeff; *nch = G.nch; *KKp = G.KKp; *MTtot = G.MTtot; *EPL = dtype == 0 ? 4 : 8;
