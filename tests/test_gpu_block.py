@@ -603,3 +603,27 @@ def test_graphed_step_matches_eager_and_redraws_dropout(ops):
     losses = [float(gs2(x, y)) for _ in range(4)]
     assert len({round(v, 5) for v in losses}) > 1, losses
     assert int(m2.device_seed_epoch().item()) >= 4
+
+
+@pytest.mark.gpu
+def test_dataparallel_wrapper_runs_the_hip_path(ops):
+    """the reference wraps the model in nn.DataParallel (processor/my_io.py:86-87).  With the one visible
+    GPU as its only replica the wrapper must give the bare model's logits and gradients (kernels take the current stream
+    of the tensor's device and keep no global state that a replica could trip over)."""
+    from istgcn_amd.net import st_gcn_msgcn as prod
+    d = torch.device('cuda:0')
+    gargs = dict(layout='ntu-rgb+d', strategy='spatial_3')
+    torch.manual_seed(1)
+    m = prod.Model(3, 60, gargs, True, dropout=0).to(d).train()
+    x = torch.randn(4, 3, 24, 25, 2, generator=torch.Generator().manual_seed(2)).to(d)
+    y = torch.randint(0, 60, (4,), generator=torch.Generator().manual_seed(3)).to(d)
+    out0 = m(x)
+    torch.nn.functional.cross_entropy(out0, y).backward()
+    g0 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone()
+    m.zero_grad()
+    dpm = torch.nn.DataParallel(m, device_ids=[0])
+    out1 = dpm(x)
+    torch.nn.functional.cross_entropy(out1, y).backward()
+    g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert rel_err(out1, out0) < 1e-5
+    assert rel_err(g1, g0) < 1e-4
