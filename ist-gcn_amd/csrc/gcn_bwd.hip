@@ -68,6 +68,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
     float* A_l = reinterpret_cast<float*>(dxa);
     const float* patg = P.pat ? P.pat : P.A;
     for (int i = tid; i < K * V * V; i += NTHREADS) A_l[i] = patg[i];
+    // the VALUES too, into the (not yet used) dy staging region when they fit: the list fill below reads one value per
+    // pattern entry inside a data-dependent loop, and from global memory that was a chain of dependent round trips per
+    // row (the same setup cost 30 us per launch in gcn_fwd before it was moved to an LDS copy)
+    float* Av_l = reinterpret_cast<float*>(dys);
+    const bool av = (size_t)K * V * V * sizeof(float) <= (size_t)TR * DS * sizeof(T);
+    if (av) for (int i = tid; i < K * V * V; i += NTHREADS) Av_l[i] = P.A[i];
     for (int r = tid; r < TR; r += NTHREADS) {
       int f = r / V;
       row_f[r] = (unsigned char)f;
@@ -94,7 +100,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         for (int w = 0; w < V; ++w) {
           if (A_l[(k * V + tid) * V + w] != 0.f) {
             if (e < P.nnz_cap) {
-              r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w); r_a[e] = P.A[(k * V + tid) * V + w];
+              r_v[e] = (unsigned char)tid; r_kw[e] = (unsigned short)(k * V + w);
+              // (two loads behind a uniform branch, not one load through a selected pointer: that would be a flat load)
+              float aval;
+              if (av) aval = Av_l[(k * V + tid) * V + w]; else aval = P.A[(k * V + tid) * V + w];
+              r_a[e] = aval;
               r_ofs[e] = (k * NCH * TR + w) * EPL;
             }
             ++e;
