@@ -218,7 +218,9 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
 }
 
 // d = dout*[out>0] -> dres ; stats2 += (sum d*mask, sum d*mask*zhat) ; statsr += (sum d, sum d*rhat)
-template <typename T, int VW>
+// HASR: the residual branch has its own BatchNorm (strided 1x1 conv, 2 of 10 blocks); a compile-time switch because the
+// second set of per-channel constants and sums costs 32 registers = one resident wave per SIMD (126 -> 94 VGPRs)
+template <typename T, int VW, bool HASR>
 __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const T* z, const float* coef2,
                                                           const T* r, const float* coefr, T* dres, double* stats2,
                                                           double* statsr, int rep, size_t rows, int C, DropCfg D) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
   for (int j = 0; j < VW; ++j) {
     a1[j] = a2[j] = b1[j] = b2[j] = 0.f;
     mz[j] = coef2[2 * C + c0 + j]; rz[j] = coef2[3 * C + c0 + j];
-    mr[j] = r ? coefr[2 * C + c0 + j] : 0.f; rr_[j] = r ? coefr[3 * C + c0 + j] : 0.f;
+    mr[j] = HASR ? coefr[2 * C + c0 + j] : 0.f; rr_[j] = HASR ? coefr[3 * C + c0 + j] : 0.f;
   }
   for (size_t row = (size_t)blockIdx.x * (NT / QC) + threadIdx.x / QC; row < rows; row += rstep) {
     const size_t e0 = row * C + c0;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
     load_vec<T, VW>(dout + e0, dv);
     load_vec<T, VW>(out + e0, ov);
     load_vec<T, VW>(z + e0, zv);
-    if (r) load_vec<T, VW>(r + e0, rv);
+    if (HASR) load_vec<T, VW>(r + e0, rv);
     if (D.on) {
       if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
       const float dm = D.on ? d * m[j] : d;
       a1[j] += dm;
       a2[j] += dm * (zv[j] - mz[j]) * rz[j];
-      if (r) {
+      if (HASR) {
         b1[j] += d;
         b2[j] += d * (rv[j] - mr[j]) * rr_[j];
       }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
       double* d2 = stats2 + (size_t)(blockIdx.x % rep) * 2 * C;
       atomic_add_f64(d2 + c, (double)s0);
       atomic_add_f64(d2 + C + c, (double)s1);
-      if (r) {
+      if (HASR) {
         double* dr = statsr + (size_t)(blockIdx.x % rep) * 2 * C;
         atomic_add_f64(dr + c, (double)s2);
         atomic_add_f64(dr + C + c, (double)s3);
@@ -407,10 +409,19 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const voi
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const int rpb = NT / (C / vw);
   size_t g = ((size_t)rows + rpb - 1) / rpb;
-  if (g > 1024) g = 1024;
+  // persistent grid = the resident workgroups: 4 per CU with the residual BatchNorm's constants in registers (120 VGPRs),
+  // 6 per CU without them (75)
+  const size_t gcap = r ? 1024 : 1536;
+  if (g > gcap) g = gcap;
   const dim3 grid((int)g);
-  EW_CASES(DISPATCH_VW(block_out_bwd_kernel, ET, VWB, grid, (const ET*)dout, (const ET*)out, (const ET*)z, coef2,
-                       (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D));
+#define BOB_LAUNCH(VWv, HR)                                                                                              \
+  ISTGCN_LAUNCH((block_out_bwd_kernel<ET, VWv, HR>), grid, dim3(NT), 0, (hipStream_t)stream, (const ET*)dout, (const ET*)out,  \
+                (const ET*)z, coef2, (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D)
+  EW_CASES({
+    if (vw == VWB) { if (r) BOB_LAUNCH(VWB, true); else BOB_LAUNCH(VWB, false); }
+    else { if (r) BOB_LAUNCH(1, true); else BOB_LAUNCH(1, false); }
+  });
+#undef BOB_LAUNCH
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
