@@ -54,7 +54,7 @@ struct TwgParams {
   // a second kernel sums the slices (no same-address atomic chains).  null: flush with atomics.
   float* ws;
   long long ws_slice;
-  int off_dz1;           // wave-specialised variant: second half of the double-buffered dz region
+  int off_dz1, off_x1;   // wave-specialised variants: second halves of the double-buffered dz / x regions
   unsigned long long* dbg;  // diagnostic (ISTGCN_WGRAD_DBG): per-phase cycle sums of workgroup (0,0)
   int abl;               // diagnostic (ISTGCN_WGRAD_ABL): 1 = no tiles (fixed cost of a launch: setup + flush)
 };
@@ -1303,6 +1303,368 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   return launch_JT<T, 15, false>(P, grid_cap, stream);
 }
 
+// ======================================================================================================================
+// Wave-specialised graph-conv weight gradient (round 2): dW[k][c][i] += sum_p dz[p][c] * u_k[p][i],  u_k = A_k-aggregated x,
+// S[w][c] += sum_f dz[(f,w)][c].  16-bit storage, V <= 32, 64 x 64 channel block per workgroup, K <= 4.  ONE 8-wave
+// workgroup per CU, two phases per tile of 128 positions (F frames):
+//   A  all eight waves: aggregation of the staged x tile into the K images  (units = (frame, 32-channel tile, partition):
+//      x^T by ds_read_b64_tr_b16, A_k fragments from LDS, 2 MFMAs, convert, swizzled image rows)
+//   B  waves 0-3: contraction of the images with the dz tile (K MFMAs per k-step of 16 positions, compile-time operand
+//      offsets);  waves 4-7: x / dz tiles of tile k+1 registers -> LDS (double-buffered), tile k+2's loads, S column sums
+// The round-1 kernel did the same work on two 8-wave workgroups per CU, every wave through every phase in lock-step.
+// ======================================================================================================================
+template <typename T, int KT>
+__global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
+  using E = Elem<T>;
+  constexpr int EPL = E::EPL;
+  static_assert(EPL == 8, "16-bit storage only");
+  typedef typename E::frag frag_t;
+  constexpr int RB = CB * (int)sizeof(T);                  // bytes per sub-tile row (64)
+  constexpr int SLS = 64 + 1;                              // S_l row stride (odd: joints land in different banks)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][SLS]
+  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // [K][2][64][8] fragments of A_k
+  T* img = reinterpret_cast<T*>(smem + P.off_u);                                  // [2 sub][K][TR][CB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wave8 < 4;
+  const int ltid = tid & (WS_NROLE - 1);
+  const int V = P.V, K = P.ntaps;
+  const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
+  const int o0 = oblk * 64, i0 = iblk * 64;
+  const int dz_sub = TR * CB, x_sub = P.dz_rows * CB;      // elements per 32-channel sub-tile
+
+  for (int idx = tid; idx < V * SLS; idx += WS_NTH) S_l[idx] = 0.f;
+  // B-operand fragments of the adjacency: lane (w = lane&31, h = lane>>5), k-step s, element j = A[k][v = 16s + 8h + j][w]
+  for (int idx = tid; idx < K * 2 * 64; idx += WS_NTH) {
+    const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
+    const int w = ln & 31, h = ln >> 5;
+    frag_t fr;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const int v = 16 * sstep + 8 * h + j;
+      fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
+    }
+    *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
+  }
+  {
+    // zeros once: the x halves (the aggregation reads a 32-row range per frame: rows behind the tile must be finite and
+    // meet zero adjacency rows), the dz halves, the images (rows behind a short tile meet zero dz rows)
+    frag_t z;
+    zero_frag<T>(z);
+    T* x0 = reinterpret_cast<T*>(smem + P.off_dz);          // [dz0][dz1][x0][x1][img] are contiguous
+    const int nv = (int)((P.off_u - P.off_dz) / 16) + 2 * KT * dz_sub / EPL;
+    for (int i = tid; i < nv; i += WS_NTH) *reinterpret_cast<frag_t*>(x0 + i * EPL) = z;
+  }
+  __syncthreads();
+
+  const T* dzg = reinterpret_cast<const T*>(P.dz);
+  const T* xg = reinterpret_cast<const T*>(P.g);
+  const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
+  const int ntile = t_end > t_begin ? t_end - t_begin : 0;
+  struct TPos { int n, mq; };
+  auto tpos_first = [&]() __attribute__((always_inline)) { TPos c; c.n = t_begin / P.tiles_per_seq; c.mq = t_begin - c.n * P.tiles_per_seq; return c; };
+  auto tpos_next = [&](TPos c) __attribute__((always_inline)) { if (++c.mq == P.tiles_per_seq) { c.mq = 0; ++c.n; } return c; };
+  auto tile_nf = [&](const TPos& c) __attribute__((always_inline)) { return min(P.F, P.Tz - c.mq * P.F); };
+
+  // ---- phase A: aggregation, units dealt round-robin to the eight waves ----
+  const int a_grp = lane >> 4, a_h = a_grp >> 1, a_cblk = (a_grp & 1) * 16, a_q4 = (lane & 15) >> 2, a_pp = lane & 3;
+  const int a_w = lane & 31;
+  const int a_src = (8 * a_h + a_q4) * CB + a_cblk + 4 * a_pp;       // element offset in an x sub-tile (frame 0, k-step 0)
+  const int NC = 2 * K;                                              // unit columns (32-channel tile ct, partition kk)
+  const unsigned rcpNC = (65536u + NC - 1) / NC, rcpK = (65536u + K - 1) / K;
+  auto aggregate = [&](int half, int nf) __attribute__((always_inline)) {
+    const T* xs = reinterpret_cast<const T*>(smem + (half ? P.off_x1 : P.off_dz + 2 * 2 * dz_sub * (int)sizeof(T)));
+    const int nunit = nf * NC;
+    for (int u = wave8; u < nunit; u += 8) {
+      const int f = (int)(((unsigned)u * rcpNC) >> 16), c = u - f * NC;
+      const int ct = (int)(((unsigned)c * rcpK) >> 16), kk = c - ct * K;
+      const T* r0 = xs + ct * x_sub + f * V * CB + a_src;
+      const frag_t x0 = tr_pair<T>(r0, r0 + 4 * CB);
+      const frag_t x1 = tr_pair<T>(r0 + 16 * CB, r0 + 20 * CB);
+      const T* af = afrag + kk * (2 * 64 * EPL) + lane * EPL;
+      const frag_t b0 = *reinterpret_cast<const frag_t*>(af);
+      const frag_t b1 = *reinterpret_cast<const frag_t*>(af + 64 * EPL);
+      f32x16 d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[r] = 0.f;
+      mma_kgroup(d, x0, b0);
+      mma_kgroup(d, x1, b1);
+      if (a_w < V) {
+        // a lane owns one image row; rows are 64 bytes apart (what the contraction's transposed reads want), so sixteen
+        // lanes storing the same 16-byte block would share two banks: the block index is XOR-swizzled with row bits 1-2
+        const int row = f * V + a_w, sw = (row >> 1) & 3;
+        T* dst = img + ((ct * K + kk) * TR + row) * CB + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
+          store4(dst + 8 * (g ^ sw), v4);
+        }
+      }
+    }
+  };
+
+  f32x16 acc[KT];
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
+#define GSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+  if (is_compute) {
+    // =========================================== compute waves ===========================================
+    const int ot = wave8 & 1, it = wave8 >> 1;
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int coff = cblk + 4 * pp;
+    const int lrow = 8 * h + q;
+    // swizzled column offsets of this lane's two image rows (8h + q and + 4, mod 16, in every k-step)
+    const int coff_u0 = (((coff >> 3) ^ ((lrow >> 1) & 3)) << 3) + (coff & 7);
+    const int coff_u1 = (((coff >> 3) ^ (((lrow + 4) >> 1) & 3)) << 3) + (coff & 7);
+    // indicator fragments (B operand: lane (w = lane & 31, kg = lane >> 5) holds rows p = 16 ks + 8 kg + j, j = 0..7)
+    constexpr int NKS = TR / 16;
+    const bool s_wave = it == 0 && P.S != nullptr;
+    frag_t ind[NKS];
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int jj = 0; jj < EPL; ++jj) {
+        const int p = 16 * ks + 8 * (lane >> 5) + jj;
+        ind[ks][jj] = E::from_f((p % V) == (lane & 31) ? 1.f : 0.f);
+      }
+    }
+    TPos c = tpos_first();
+    ws_barrier();                                           // tile 0 staged
+    tlast = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < ntile; ++k) {
+      aggregate(k & 1, tile_nf(c));
+      c = tpos_next(c);
+      GSTAMP(0)
+      ws_barrier();                                         // A done: images complete
+      GSTAMP(1)
+      const unsigned char* ap = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + (ot * dz_sub + coff) * (int)sizeof(T) + lrow * RB;
+      const unsigned char* u0 = smem + P.off_u + (it * K * dz_sub + coff_u0) * (int)sizeof(T) + lrow * RB;
+      const unsigned char* u1 = smem + P.off_u + (it * K * dz_sub + coff_u1) * (int)sizeof(T) + (lrow + 4) * RB;
+      constexpr int NK = TR / 16;
+      frag_t a0, a1, b0[KT], b1[KT];
+      auto load_k = [&](int ks, frag_t& a, frag_t (&b)[KT]) __attribute__((always_inline)) {
+        a = tr_pair<T>(reinterpret_cast<const T*>(ap + ks * 16 * RB), reinterpret_cast<const T*>(ap + ks * 16 * RB + 4 * RB));
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const int jv = j < K ? j : 0;                     // padding partitions alias partition 0 (computed, never flushed)
+          b[j] = tr_pair<T>(reinterpret_cast<const T*>(u0 + jv * TR * RB + ks * 16 * RB), reinterpret_cast<const T*>(u1 + jv * TR * RB + ks * 16 * RB));
+        }
+      };
+      auto mma_k = [&](int ks, const frag_t& a, const frag_t (&b)[KT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < KT; ++j) mma_kgroup(acc[j], a, b[j]);
+        if (s_wave) mma_kgroup(accS, a, ind[ks]);
+      };
+      load_k(0, a0, b0);
+#pragma unroll
+      for (int ks = 0; ks < NK; ks += 2) {
+        load_k(ks + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(ks, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < NK) load_k(ks + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(ks + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      GSTAMP(2)
+      ws_barrier();                                         // B done: images free, tile k+1 staged
+      GSTAMP(3)
+    }
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 4; ++i) P.dbg[i] = tacc[i]; P.dbg[7] = (unsigned long long)ntile; }
+    if (s_wave && (lane & 31) < V) {
+      // D tile rows = output channel (registers), cols = joint (lanes) -> S_l[w][c] for the common flush below
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S_l[(lane & 31) * SLS + ot * CB + mfma_row(r, lane)] = accS[r];
+    }
+  } else {
+    // =========================================== memory waves ============================================
+    const int q = ltid & 7;                                 // this thread's channel vector of a 64-channel row (both tensors)
+    const int sub = q >> 2, ql = q & 3;
+    const bool zlive_q = o0 + q * EPL < P.Cout, xlive_q = i0 + q * EPL < P.Cin;
+    unsigned zoff[WS_UZ], xoff[WS_UZ];
+#pragma unroll
+    for (int u = 0; u < WS_UZ; ++u) {
+      zoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cout + q * EPL);
+      xoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cin + q * EPL);
+    }
+    // a constant 8 loads per tile (dead slots read the tile's first vector and are zeroed on commit)
+    auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[WS_UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
+      const bool valid = k < ntile;
+      const int rows = valid ? tile_nf(c) * V : 0;
+      const size_t pos0 = valid ? (size_t)(c.n * P.Tz + c.mq * P.F) * V : 0;
+      const T* zb = dzg + pos0 * P.Cout + (valid ? o0 : 0);
+      const T* xb = xg + pos0 * P.Cin + (valid ? i0 : 0);
+#pragma unroll
+      for (int u = 0; u < WS_UZ; ++u) {
+        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
+        RZ[u] = *reinterpret_cast<const u32x4*>(zb + ((zlive_q && r < rows) ? zoff[u] : 0u));
+        RX[u] = *reinterpret_cast<const u32x4*>(xb + ((xlive_q && r < rows) ? xoff[u] : 0u));
+      }
+    };
+    auto commit = [&](int k, const TPos& c, u32x4 (&RZ)[WS_UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
+      if (k >= ntile) return;
+      const int rows = tile_nf(c) * V;
+      T* dzs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_dz1 : P.off_dz)) + sub * dz_sub + ql * EPL;
+      T* xs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_x1 : P.off_dz + 2 * 2 * dz_sub * (int)sizeof(T))) + sub * x_sub + ql * EPL;
+#pragma unroll
+      for (int u = 0; u < WS_UZ; ++u) {
+        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
+        frag_t vz = __builtin_bit_cast(frag_t, RZ[u]), vx = __builtin_bit_cast(frag_t, RX[u]);
+        if (!(zlive_q && r < rows)) zero_frag<T>(vz);
+        if (!(xlive_q && r < rows)) zero_frag<T>(vx);
+        *reinterpret_cast<frag_t*>(dzs + r * CB) = vz;
+        *reinterpret_cast<frag_t*>(xs + r * CB) = vx;
+      }
+    };
+    u32x4 ZA[WS_UZ], XA[WS_UZ], ZB[WS_UZ], XB[WS_UZ];
+    const TPos c0 = tpos_first();
+    TPos ck = c0, c1 = tpos_next(c0), c2 = c1;
+    issue(0, c0, ZA, XA);
+    issue(1, c1, ZB, XB);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(0, c0, ZA, XA);
+    ws_barrier();                                           // tile 0 staged
+    tlast = __builtin_amdgcn_s_memtime();
+    auto iteration = [&](int k, u32x4 (&Zn)[WS_UZ], u32x4 (&Xn)[WS_UZ], u32x4 (&Zf)[WS_UZ], u32x4 (&Xf)[WS_UZ]) __attribute__((always_inline)) {
+      aggregate(k & 1, tile_nf(ck));                        // phase A, this role's share
+      GSTAMP(0)
+      ws_barrier();
+      GSTAMP(1)
+      c2 = tpos_next(c1);
+      issue(k + 2, c2, Zf, Xf);
+      __builtin_amdgcn_sched_barrier(0);
+      commit(k + 1, c1, Zn, Xn);
+      GSTAMP(2)
+      ck = c1; c1 = c2;
+      ws_barrier();
+      GSTAMP(4)
+    };
+    for (int k = 0; k < ntile; k += 2) {
+      iteration(k, ZB, XB, ZA, XA);
+      if (k + 1 < ntile) iteration(k + 1, ZA, XA, ZB, XB);
+    }
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) for (int i = 0; i < 5; ++i) P.dbg[8 + i] = tacc[i];
+  }
+#undef GSTAMP
+  __syncthreads();
+
+  // ---- flush (as the convolution variant; the aux slots are S[w][c] of this o-block, reported by i-block 0) ----
+  const bool aux_wg = iblk == 0;
+  if (P.ws) {
+    float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
+    if (is_compute) {
+      const int ot = wave8 & 1, it = wave8 >> 1;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (j < K) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+            if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[j][r];
+          }
+        }
+      }
+    } else if (aux_wg && P.S) {
+      float* aux = sl + (size_t)K * P.Cout * P.Cin;
+      for (int idx = ltid; idx < V * 64; idx += WS_NROLE) {
+        const int w = idx >> 6, cc = idx & 63;
+        if (o0 + cc < P.Cout) aux[w * P.Cout + o0 + cc] = S_l[w * SLS + cc];
+      }
+    }
+  } else {
+    if (is_compute) {
+      const int ot = wave8 & 1, it = wave8 >> 1;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (j < K) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+            if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[j][r]);
+          }
+        }
+      }
+    } else if (aux_wg && P.S) {
+      for (int idx = ltid; idx < V * 64; idx += WS_NROLE) {
+        const int w = idx >> 6, cc = idx & 63;
+        if (o0 + cc < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + cc, S_l[w * SLS + cc]);
+      }
+    }
+  }
+}
+
+template <typename T, int KT>
+int launch_gws(TwgParams& P, int grid_cap, hipStream_t stream) {
+  if constexpr (sizeof(T) != 2) return -1;
+  else {
+    static const int forced = [] { const char* e = getenv("ISTGCN_WGRAD_WS"); return e ? atoi(e) : -1; }();
+    if (forced == 0) return -1;
+    if (P.V > 32 || P.Cin % 8 || P.Cout % 8 || P.Cin < 64 || P.Cout < 64 || P.ntaps > KT) return -1;
+    P.n_iblk = ceil_div(P.Cin, 64);
+    const int n_oblk = ceil_div(P.Cout, 64);
+    const int esz = 2, K = P.ntaps;
+    P.dz_rows = (P.F - 1) * P.V + 32 > TR ? (P.F - 1) * P.V + 32 : TR;      // x sub-tile rows (32-row k-range of the last frame)
+    size_t off = 0;
+    P.off_S = (int)off; off += (size_t)P.V * 65 * 4;
+    off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)K * 2 * 64 * 16;
+    const size_t dzb = (size_t)2 * TR * CB * esz, xb = (size_t)2 * P.dz_rows * CB * esz;
+    off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += dzb;
+    P.off_dz1 = (int)off; off += dzb;
+    /* x half 0 sits right behind the dz halves */ off += xb;
+    P.off_x1 = (int)off; off += xb;
+    P.off_u = (int)off; off += (size_t)2 * K * TR * CB * esz;
+    if (off > 160 * 1024) return -1;
+    const int blocks = n_oblk * P.n_iblk;
+    auto kfn = gwg_ws_kernel<T, KT>;
+    static std::atomic<unsigned long long> optin{0};
+    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
+    if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, WS_NTH, off);
+    int gx = grid_cap / blocks;
+    if (gx < 1) gx = 1;
+    if (gx > P.total_tiles) gx = P.total_tiles;
+    const int n0 = K * P.Cout * P.Cin, n1 = P.V * P.Cout;
+    const int nsl = gx;
+    if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;
+    P.ws_slice = n0 + n1;
+    unsigned long long* dbuf = nullptr;
+    if (getenv("ISTGCN_WGRAD_DBG")) {
+      static unsigned long long* dbuf_s = nullptr;
+      if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
+      dbuf = dbuf_s;
+      (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
+      P.dbg = dbuf;
+    }
+    ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(WS_NTH), off, stream, P);
+    ISTGCN_CHECK_LAUNCH();
+    if (dbuf) {
+      unsigned long long h[16];
+      (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, stream);
+      (void)hipStreamSynchronize(stream);
+      fprintf(stderr, "gwgrad_ws dbg Cin=%d Cout=%d tiles/wg=%llu | compute: agg %llu barA %llu contract %llu barB %llu | memory: agg %llu barA %llu issue+commit %llu ssums %llu barB %llu\n",
+              P.Cin, P.Cout, h[7], h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11], h[12]);
+    }
+    if (P.ws) {
+      int ny = nsl / 16;
+      ny = ny < 1 ? 1 : (ny > 16 ? 16 : ny);
+      dim3 rgrid(ceil_div(n0 + (P.S ? n1 : 0), 1024), ny);
+      ISTGCN_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)P.ws, P.ws_slice, nsl, P.dW, n0,
+                    P.S, P.S ? n1 : 0);
+      ISTGCN_CHECK_LAUNCH();
+    }
+    return ISTGCN_OK;
+  }
+}
+
 template <typename T>
 int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.min_off = 0;
@@ -1310,6 +1672,11 @@ int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.Fin = P.F;
   P.tiles_per_seq = ceil_div(P.Tz, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
+  if (P.ntaps == 3) {
+    TwgParams Q = P;
+    const int rc = launch_gws<T, 3>(Q, grid_cap, stream);
+    if (rc >= 0) return rc;
+  }
   if (P.ntaps <= 1) return launch_JT<T, 1, true>(P, grid_cap, stream);
   if (P.ntaps <= 3) return launch_JT<T, 3, true>(P, grid_cap, stream);
   return launch_JT<T, 4, true>(P, grid_cap, stream);
