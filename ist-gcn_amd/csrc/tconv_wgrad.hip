@@ -1313,14 +1313,19 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
 //      offsets);  waves 4-7: x / dz tiles of tile k+1 registers -> LDS (double-buffered), tile k+2's loads, S column sums
 // The round-1 kernel did the same work on two 8-wave workgroups per CU, every wave through every phase in lock-step.
 // ======================================================================================================================
-template <typename T, int KT>
+template <typename T, int KT, int OTW>
 __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
+  // OTW = o-tiles per compute wave: the workgroup's channel block is (64 * OTW) x 64.  Two o-tiles halve how often an x
+  // block is aggregated (once per o-block) for layers with >= 128 output channels.
+  constexpr int OB = 64 * OTW;                             // output channels per workgroup
+  constexpr int NZQ = OB / 8;                              // 16-byte vectors per dz row
+  constexpr int UZ = TR * NZQ / WS_NROLE;                  // dz vectors per memory thread and tile
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
   static_assert(EPL == 8, "16-bit storage only");
   typedef typename E::frag frag_t;
   constexpr int RB = CB * (int)sizeof(T);                  // bytes per sub-tile row (64)
-  constexpr int SLS = 64 + 1;                              // S_l row stride (odd: joints land in different banks)
+  constexpr int SLS = OB + 1;                              // S_l row stride (odd: joints land in different banks)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][SLS]
   T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // [K][2][64][8] fragments of A_k
@@ -1331,8 +1336,9 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
   const int ltid = tid & (WS_NROLE - 1);
   const int V = P.V, K = P.ntaps;
   const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
-  const int o0 = oblk * 64, i0 = iblk * 64;
+  const int o0 = oblk * OB, i0 = iblk * 64;
   const int dz_sub = TR * CB, x_sub = P.dz_rows * CB;      // elements per 32-channel sub-tile
+  const int dz_half = 2 * OTW * dz_sub * (int)sizeof(T);   // bytes of one dz half ([2*OTW sub][TR][CB])
 
   for (int idx = tid; idx < V * SLS; idx += WS_NTH) S_l[idx] = 0.f;
   // B-operand fragments of the adjacency: lane (w = lane&31, h = lane>>5), k-step s, element j = A[k][v = 16s + 8h + j][w]
@@ -1353,7 +1359,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     frag_t z;
     zero_frag<T>(z);
     T* x0 = reinterpret_cast<T*>(smem + P.off_dz);          // [dz0][dz1][x0][x1][img] are contiguous
-    const int nv = (int)((P.off_u - P.off_dz) / 16) + 2 * KT * dz_sub / EPL;
+    const int nv = (int)((P.off_u - P.off_dz) / 16) + 2 * K * dz_sub / EPL;
     for (int i = tid; i < nv; i += WS_NTH) *reinterpret_cast<frag_t*>(x0 + i * EPL) = z;
   }
   __syncthreads();
@@ -1375,7 +1381,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
   const int NC = 2 * K;                                              // unit columns (32-channel tile ct, partition kk)
   const unsigned rcpNC = (65536u + NC - 1) / NC, rcpK = (65536u + K - 1) / K;
   auto aggregate = [&](int half, int nf) __attribute__((always_inline)) {
-    const T* xs = reinterpret_cast<const T*>(smem + (half ? P.off_x1 : P.off_dz + 2 * 2 * dz_sub * (int)sizeof(T)));
+    const T* xs = reinterpret_cast<const T*>(smem + (half ? P.off_x1 : P.off_dz + 2 * dz_half));
     const int nunit = nf * NC;
     for (int u = wave8; u < nunit; u += 8) {
       const int f = (int)(((unsigned)u * rcpNC) >> 16), c = u - f * NC;
@@ -1405,16 +1411,18 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     }
   };
 
-  f32x16 acc[KT];
+  f32x16 acc[OTW][KT];
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
 #define GSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
   if (is_compute) {
     // =========================================== compute waves ===========================================
     const int ot = wave8 & 1, it = wave8 >> 1;
 #pragma unroll
-    for (int j = 0; j < KT; ++j)
+    for (int o = 0; o < OTW; ++o)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[o][j][r] = 0.f;
     const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
     const int q = (lane & 15) >> 2, pp = lane & 3;
     const int coff = cblk + 4 * pp;
@@ -1426,9 +1434,11 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     constexpr int NKS = TR / 16;
     const bool s_wave = it == 0 && P.S != nullptr;
     frag_t ind[NKS];
-    f32x16 accS;
+    f32x16 accS[OTW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+    for (int o = 0; o < OTW; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accS[o][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
@@ -1446,23 +1456,29 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
       GSTAMP(0)
       ws_barrier();                                         // A done: images complete
       GSTAMP(1)
-      const unsigned char* ap = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + (ot * dz_sub + coff) * (int)sizeof(T) + lrow * RB;
+      // this wave's o-tiles are sub-tiles ot * OTW + o of the dz tile
+      const unsigned char* ap = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + (ot * OTW * dz_sub + coff) * (int)sizeof(T) + lrow * RB;
       const unsigned char* u0 = smem + P.off_u + (it * K * dz_sub + coff_u0) * (int)sizeof(T) + lrow * RB;
       const unsigned char* u1 = smem + P.off_u + (it * K * dz_sub + coff_u1) * (int)sizeof(T) + (lrow + 4) * RB;
       constexpr int NK = TR / 16;
-      frag_t a0, a1, b0[KT], b1[KT];
-      auto load_k = [&](int ks, frag_t& a, frag_t (&b)[KT]) __attribute__((always_inline)) {
-        a = tr_pair<T>(reinterpret_cast<const T*>(ap + ks * 16 * RB), reinterpret_cast<const T*>(ap + ks * 16 * RB + 4 * RB));
+      frag_t a0[OTW], a1[OTW], b0[KT], b1[KT];
+      auto load_k = [&](int ks, frag_t (&a)[OTW], frag_t (&b)[KT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 0; o < OTW; ++o)
+          a[o] = tr_pair<T>(reinterpret_cast<const T*>(ap + o * TR * RB + ks * 16 * RB), reinterpret_cast<const T*>(ap + o * TR * RB + ks * 16 * RB + 4 * RB));
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
           const int jv = j < K ? j : 0;                     // padding partitions alias partition 0 (computed, never flushed)
           b[j] = tr_pair<T>(reinterpret_cast<const T*>(u0 + jv * TR * RB + ks * 16 * RB), reinterpret_cast<const T*>(u1 + jv * TR * RB + ks * 16 * RB));
         }
       };
-      auto mma_k = [&](int ks, const frag_t& a, const frag_t (&b)[KT]) __attribute__((always_inline)) {
+      auto mma_k = [&](int ks, const frag_t (&a)[OTW], const frag_t (&b)[KT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < KT; ++j) mma_kgroup(acc[j], a, b[j]);
-        if (s_wave) mma_kgroup(accS, a, ind[ks]);
+        for (int o = 0; o < OTW; ++o) {
+#pragma unroll
+          for (int j = 0; j < KT; ++j) mma_kgroup(acc[o][j], a[o], b[j]);
+          if (s_wave) mma_kgroup(accS[o], a[o], ind[ks]);
+        }
       };
       load_k(0, a0, b0);
 #pragma unroll
@@ -1484,49 +1500,57 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     if (s_wave && (lane & 31) < V) {
       // D tile rows = output channel (registers), cols = joint (lanes) -> S_l[w][c] for the common flush below
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S_l[(lane & 31) * SLS + ot * CB + mfma_row(r, lane)] = accS[r];
+      for (int o = 0; o < OTW; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S_l[(lane & 31) * SLS + (ot * OTW + o) * CB + mfma_row(r, lane)] = accS[o][r];
     }
   } else {
     // =========================================== memory waves ============================================
-    const int q = ltid & 7;                                 // this thread's channel vector of a 64-channel row (both tensors)
-    const int sub = q >> 2, ql = q & 3;
-    const bool zlive_q = o0 + q * EPL < P.Cout, xlive_q = i0 + q * EPL < P.Cin;
-    unsigned zoff[WS_UZ], xoff[WS_UZ];
+    // thread maps: x rows are 8 vectors (64 channels) wide, dz rows NZQ vectors (64 * OTW channels)
+    const int qx = ltid & 7, rx0 = ltid >> 3;
+    const int qz = ltid & (NZQ - 1), rz0 = ltid / NZQ;
+    constexpr int RXS = WS_NROLE / 8, RZS = WS_NROLE / NZQ;   // rows per sweep
+    const bool zlive_q = o0 + qz * EPL < P.Cout, xlive_q = i0 + qx * EPL < P.Cin;
+    unsigned zoff[UZ], xoff[WS_UZ];
 #pragma unroll
-    for (int u = 0; u < WS_UZ; ++u) {
-      zoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cout + q * EPL);
-      xoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cin + q * EPL);
-    }
-    // a constant 8 loads per tile (dead slots read the tile's first vector and are zeroed on commit)
-    auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[WS_UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
+    for (int u = 0; u < UZ; ++u) zoff[u] = (unsigned)((rz0 + u * RZS) * P.Cout + qz * EPL);
+#pragma unroll
+    for (int u = 0; u < WS_UZ; ++u) xoff[u] = (unsigned)((rx0 + u * RXS) * P.Cin + qx * EPL);
+    // a constant UZ + 4 loads per tile (dead slots read the tile's first vector and are zeroed on commit)
+    auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
       const bool valid = k < ntile;
       const int rows = valid ? tile_nf(c) * V : 0;
       const size_t pos0 = valid ? (size_t)(c.n * P.Tz + c.mq * P.F) * V : 0;
       const T* zb = dzg + pos0 * P.Cout + (valid ? o0 : 0);
       const T* xb = xg + pos0 * P.Cin + (valid ? i0 : 0);
 #pragma unroll
-      for (int u = 0; u < WS_UZ; ++u) {
-        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-        RZ[u] = *reinterpret_cast<const u32x4*>(zb + ((zlive_q && r < rows) ? zoff[u] : 0u));
-        RX[u] = *reinterpret_cast<const u32x4*>(xb + ((xlive_q && r < rows) ? xoff[u] : 0u));
-      }
+      for (int u = 0; u < UZ; ++u)
+        RZ[u] = *reinterpret_cast<const u32x4*>(zb + ((zlive_q && rz0 + u * RZS < rows) ? zoff[u] : 0u));
+#pragma unroll
+      for (int u = 0; u < WS_UZ; ++u)
+        RX[u] = *reinterpret_cast<const u32x4*>(xb + ((xlive_q && rx0 + u * RXS < rows) ? xoff[u] : 0u));
     };
-    auto commit = [&](int k, const TPos& c, u32x4 (&RZ)[WS_UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
+    auto commit = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
       if (k >= ntile) return;
       const int rows = tile_nf(c) * V;
-      T* dzs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_dz1 : P.off_dz)) + sub * dz_sub + ql * EPL;
-      T* xs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_x1 : P.off_dz + 2 * 2 * dz_sub * (int)sizeof(T))) + sub * x_sub + ql * EPL;
+      T* dzs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_dz1 : P.off_dz)) + (qz >> 2) * dz_sub + (qz & 3) * EPL;
+      T* xs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_x1 : P.off_dz + 2 * dz_half)) + (qx >> 2) * x_sub + (qx & 3) * EPL;
+#pragma unroll
+      for (int u = 0; u < UZ; ++u) {
+        const int r = rz0 + u * RZS;
+        frag_t vz = __builtin_bit_cast(frag_t, RZ[u]);
+        if (!(zlive_q && r < rows)) zero_frag<T>(vz);
+        *reinterpret_cast<frag_t*>(dzs + r * CB) = vz;
+      }
 #pragma unroll
       for (int u = 0; u < WS_UZ; ++u) {
-        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-        frag_t vz = __builtin_bit_cast(frag_t, RZ[u]), vx = __builtin_bit_cast(frag_t, RX[u]);
-        if (!(zlive_q && r < rows)) zero_frag<T>(vz);
+        const int r = rx0 + u * RXS;
+        frag_t vx = __builtin_bit_cast(frag_t, RX[u]);
         if (!(xlive_q && r < rows)) zero_frag<T>(vx);
-        *reinterpret_cast<frag_t*>(dzs + r * CB) = vz;
         *reinterpret_cast<frag_t*>(xs + r * CB) = vx;
       }
     };
-    u32x4 ZA[WS_UZ], XA[WS_UZ], ZB[WS_UZ], XB[WS_UZ];
+    u32x4 ZA[UZ], XA[WS_UZ], ZB[UZ], XB[WS_UZ];
     const TPos c0 = tpos_first();
     TPos ck = c0, c1 = tpos_next(c0), c2 = c1;
     issue(0, c0, ZA, XA);
@@ -1535,7 +1559,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     commit(0, c0, ZA, XA);
     ws_barrier();                                           // tile 0 staged
     tlast = __builtin_amdgcn_s_memtime();
-    auto iteration = [&](int k, u32x4 (&Zn)[WS_UZ], u32x4 (&Xn)[WS_UZ], u32x4 (&Zf)[WS_UZ], u32x4 (&Xf)[WS_UZ]) __attribute__((always_inline)) {
+    auto iteration = [&](int k, u32x4 (&Zn)[UZ], u32x4 (&Xn)[WS_UZ], u32x4 (&Zf)[UZ], u32x4 (&Xf)[WS_UZ]) __attribute__((always_inline)) {
       aggregate(k & 1, tile_nf(ck));                        // phase A, this role's share
       GSTAMP(0)
       ws_barrier();
@@ -1565,19 +1589,21 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     if (is_compute) {
       const int ot = wave8 & 1, it = wave8 >> 1;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        if (j < K) {
+      for (int ow = 0; ow < OTW; ++ow)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-            if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[j][r];
+        for (int j = 0; j < KT; ++j) {
+          if (j < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = o0 + (ot * OTW + ow) * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+              if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[ow][j][r];
+            }
           }
         }
-      }
     } else if (aux_wg && P.S) {
       float* aux = sl + (size_t)K * P.Cout * P.Cin;
-      for (int idx = ltid; idx < V * 64; idx += WS_NROLE) {
-        const int w = idx >> 6, cc = idx & 63;
+      for (int idx = ltid; idx < V * OB; idx += WS_NROLE) {
+        const int w = idx / OB, cc = idx - w * OB;
         if (o0 + cc < P.Cout) aux[w * P.Cout + o0 + cc] = S_l[w * SLS + cc];
       }
     }
@@ -1585,47 +1611,50 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
     if (is_compute) {
       const int ot = wave8 & 1, it = wave8 >> 1;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        if (j < K) {
+      for (int ow = 0; ow < OTW; ++ow)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-            if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[j][r]);
+        for (int j = 0; j < KT; ++j) {
+          if (j < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = o0 + (ot * OTW + ow) * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+              if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[ow][j][r]);
+            }
           }
         }
-      }
     } else if (aux_wg && P.S) {
-      for (int idx = ltid; idx < V * 64; idx += WS_NROLE) {
-        const int w = idx >> 6, cc = idx & 63;
+      for (int idx = ltid; idx < V * OB; idx += WS_NROLE) {
+        const int w = idx / OB, cc = idx - w * OB;
         if (o0 + cc < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + cc, S_l[w * SLS + cc]);
       }
     }
   }
 }
 
-template <typename T, int KT>
-int launch_gws(TwgParams& P, int grid_cap, hipStream_t stream) {
+template <typename T, int KT, int OTW>
+int launch_gws_o(TwgParams& P, int grid_cap, hipStream_t stream) {
   if constexpr (sizeof(T) != 2) return -1;
   else {
     static const int forced = [] { const char* e = getenv("ISTGCN_WGRAD_WS"); return e ? atoi(e) : -1; }();
     if (forced == 0) return -1;
-    if (P.V > 32 || P.Cin % 8 || P.Cout % 8 || P.Cin < 64 || P.Cout < 64 || P.ntaps > KT) return -1;
+    if (P.V > 32 || P.Cin % 8 || P.Cout % 8 || P.Cin < 64 || P.Cout < 64 * OTW || P.ntaps > KT) return -1;
     P.n_iblk = ceil_div(P.Cin, 64);
-    const int n_oblk = ceil_div(P.Cout, 64);
+    const int n_oblk = ceil_div(P.Cout, 64 * OTW);
     const int esz = 2, K = P.ntaps;
     P.dz_rows = (P.F - 1) * P.V + 32 > TR ? (P.F - 1) * P.V + 32 : TR;      // x sub-tile rows (32-row k-range of the last frame)
     size_t off = 0;
-    P.off_S = (int)off; off += (size_t)P.V * 65 * 4;
+    P.off_S = (int)off; off += (size_t)P.V * (64 * OTW + 1) * 4;
     off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)K * 2 * 64 * 16;
-    const size_t dzb = (size_t)2 * TR * CB * esz, xb = (size_t)2 * P.dz_rows * CB * esz;
+    const size_t dzb = (size_t)2 * OTW * TR * CB * esz, xb = (size_t)2 * P.dz_rows * CB * esz;
     off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += dzb;
     P.off_dz1 = (int)off; off += dzb;
     /* x half 0 sits right behind the dz halves */ off += xb;
     P.off_x1 = (int)off; off += xb;
     P.off_u = (int)off; off += (size_t)2 * K * TR * CB * esz;
     if (off > 160 * 1024) return -1;
+    if (OTW == 2 && P.total_tiles * n_oblk * P.n_iblk < 2 * 256) return -1;   // too few tiles to keep every CU busy with wide blocks
     const int blocks = n_oblk * P.n_iblk;
-    auto kfn = gwg_ws_kernel<T, KT>;
+    auto kfn = gwg_ws_kernel<T, KT, OTW>;
     static std::atomic<unsigned long long> optin{0};
     if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
     if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, WS_NTH, off);
@@ -1663,6 +1692,16 @@ int launch_gws(TwgParams& P, int grid_cap, hipStream_t stream) {
     }
     return ISTGCN_OK;
   }
+}
+
+template <typename T, int KT>
+int launch_gws(TwgParams& P, int grid_cap, hipStream_t stream) {
+  if (P.Cout >= 128) {                                    // 128 x 64 blocks: each x block aggregated once per 128 output channels
+    TwgParams Q = P;
+    const int rc = launch_gws_o<T, KT, 2>(Q, grid_cap, stream);
+    if (rc >= 0) return rc;
+  }
+  return launch_gws_o<T, KT, 1>(P, grid_cap, stream);
 }
 
 template <typename T>
