@@ -223,7 +223,10 @@ def test_gcn_param_grads_golden(ops, golden, unit, ci, dt):
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(3, 64, 64, 23, 25, 3, False), (2, 64, 128, 11, 25, 3, False), (2, 128, 256, 9, 25, 3, False),
                                    (2, 256, 256, 7, 18, 3, True), (1, 3, 64, 300, 25, 3, False), (2, 64, 64, 12, 25, 4, True),
-                                   (2, 40, 24, 5, 15, 2, True)])
+                                   (2, 40, 24, 5, 15, 2, True),
+                                   # more tiles than workgroups (a workgroup walks several tiles); two input chunks with
+                                   # one output chunk (the wave-specialised gcn_bwd_data's non-resident weight path)
+                                   (40, 64, 64, 38, 25, 3, False), (12, 128, 64, 150, 25, 3, False)])
 def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
     NM, cin, cout, T, V, K, dense = shape
     gen = torch.Generator().manual_seed(hash(shape) & 0xFFFF)
@@ -257,3 +260,34 @@ def test_gcn_wgrad_random_vs_autograd(ops, shape, dt):
     assert diag(name + '_dW', dW.cpu().view_as(W), W.grad, tol) < tol
     assert diag(name + '_dA', dA.cpu(), A.grad * (A.detach() != 0), tol) < tol
     assert diag(name + '_S', S.cpu(), to_ntvc(dy).sum((0, 1)), tol) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('with_x,with_add', [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize('cin,cout', [(64, 64), (64, 256), (128, 128)])
+def test_gcn_bwd_data_optional_operands(ops, cin, cout, with_x, with_add, dt):
+    """The wave-specialised gcn_bwd_data issues the loads of absent operands (x / addend) from a dummy address to keep its
+    load counts fixed: the results must not depend on them (autograd of net/utils/tgcn.py:79-86)."""
+    NM, T, V, K = 3, 23, 25, 3
+    gen = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(NM, cin, T, V, generator=gen).to(dt).float()
+    dy = torch.randn(NM, cout, T, V, generator=gen).to(dt).float()
+    add = torch.randn(NM, cin, T, V, generator=gen).to(dt).float()
+    W = torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5
+    A = (torch.rand(K, V, V, generator=gen) * (torch.rand(K, V, V, generator=gen) < 0.12)).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    R.graph_einsum(torch.nn.functional.conv2d(xr, W), A).backward(dy)
+    d = dev()
+    cap = int((A != 0).sum())
+    dx, dA = ops.gcn_bwd_data(to_ntvc(dy).to(d, dt), A.detach().to(d), W.view(K, cout, cin).to(d),
+                              x=to_ntvc(x).to(d, dt) if with_x else None,
+                              addend=to_ntvc(add).to(d, dt) if with_add else None, want_dA=with_x, nnz_cap=cap)
+    torch.cuda.synchronize()
+    want = xr.grad + (add if with_add else 0)
+    name = 'gcnbwdopt_%dx%d_%d%d_%s' % (cin, cout, with_x, with_add, str(dt)[6:])
+    assert diag(name + '_dx', to_nctv(dx.float()), want, TOL[dt]) < TOL[dt]
+    if with_x:
+        assert diag(name + '_dA', dA.cpu(), A.grad * (A.detach() != 0), 1e-2) < 1e-2
+    else:
+        assert dA is None
