@@ -45,8 +45,8 @@ FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit G
           'istgcn_affine2': 'bn_bwd_apply'}
 
 
-PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'tconv_wgrad_kernel', 'istgcn_gcn_fwd': 'gcn_fwd_kernel',
-           'istgcn_gcn_bwd_data': 'gcn_bwd_kernel', 'istgcn_gcn_wgrad': 'tconv_wgrad_kernel',
+PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_fwd_kernel',
+           'istgcn_gcn_bwd_data': 'gcn_bwd_ws_kernel', 'istgcn_gcn_wgrad': 'gwg_ws_kernel',
            'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
            'istgcn_affine2': 'affine2_kernel'}
 

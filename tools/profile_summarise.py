@@ -12,7 +12,7 @@ OUT = os.path.join(ROOT, 'gpurun_out')
 
 def fam(name):
     n = name.replace('(anonymous namespace)::', '')
-    for key in ('tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
+    for key in ('twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
                 'block_out_bwd_kernel', 'affine2_kernel', 'bn_finalize_kernel', 'bn_bwd_coef_kernel', 'fold_fwd_kernel', 'fold_bwd_kernel',
                 'sgd_step_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
         if key in n:
