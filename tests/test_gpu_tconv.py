@@ -21,6 +21,8 @@ CASES = [
     (2, 64, 64, 23, 25, 9, 1), (2, 64, 128, 20, 25, 9, 2), (1, 128, 128, 31, 25, 15, 1), (2, 256, 256, 12, 18, 9, 1),
     (2, 16, 16, 16, 25, 3, 1), (2, 8, 8, 17, 25, 15, 2), (3, 11, 11, 9, 25, 9, 1), (1, 64, 64, 300, 25, 9, 1),
     (2, 128, 256, 30, 25, 15, 2),
+    # stride 2 with an odd input length and several tiles per sequence
+    (3, 64, 128, 61, 25, 9, 2), (2, 128, 256, 50, 25, 9, 2),
 ]
 
 
