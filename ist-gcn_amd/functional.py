@@ -237,6 +237,7 @@ class BlockCfg:
         self.pattern = pattern            # [K,V,V] fp32 sparsity pattern of the adjacency gradient (None: dense)
         self.packed = None                # dict of fragment-packed weights from the Model's PackPlan (None: pack per call)
         self.seed_epoch = None            # int64[1] device tensor added to the dropout seed at kernel run time (graph replay)
+        self.step_arena = None            # ops.StepArena of the current forward (the Model's one zero fill per step) or None
 
 
 class STGCNBlockFn(torch.autograd.Function):
@@ -297,6 +298,7 @@ class STGCNBlockFn(torch.autograd.Function):
         p = cfg.p_drop if training else 0.0
         out = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed, epoch=cfg.seed_epoch)
         ctx.cfg, ctx.training, ctx.seed, ctx.p = cfg, training, seed, p
+        ctx.step_arena = cfg.step_arena   # captured now: the next forward replaces cfg.step_arena before this backward runs
         ctx.save_for_backward(x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb)
         ctx.has_b = bterm is not None
         return out
@@ -333,7 +335,7 @@ class STGCNBlockFn(torch.autograd.Function):
             shapes.append((K, V, V))
         if cfg.residual == 'conv':
             shapes += [(1, cout, cin), (cout,)]
-        arena = ops.ZeroArena(shapes, x.device)
+        arena = ops.ZeroArena(shapes, x.device, parent=ctx.step_arena)
         buf_t = (arena.take(), arena.take())
         buf_g = (arena.take(), arena.take() if ctx.has_b else None)
         buf_A = arena.take() if need_A else None

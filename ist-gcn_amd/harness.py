@@ -65,12 +65,20 @@ class FlatSGD:
         self.P = torch.zeros(total, dtype=torch.float32, device=dev)
         self.G = torch.zeros(total, dtype=torch.float32, device=dev)
         self.M = torch.zeros(total, dtype=torch.float32, device=dev)
+        def view(buf, o, p):
+            flat = buf[o:o + p.numel()]
+            if getattr(p, '_istgcn_flat_layout', None) == 'tap_major' and p.dim() == 4 and p.shape[3] == 1:
+                # (Cout, Cin, k, 1) temporal-conv weight stored [k][Cout][Cin]: the layout its gradient is computed in, so
+                # AccumulateGrad takes the gradient as it is (same strides) instead of copying it into the Conv2d layout
+                co, ci, k, _ = p.shape
+                return flat.view(k, co, ci).permute(1, 2, 0).unsqueeze(-1)
+            return flat.view(p.shape)
         with torch.no_grad():
-            pviews = [self.P[o:o + p.numel()].view(p.shape) for p, o in zip(live, offs)]
-            torch._foreach_copy_(pviews, [p.data for p in live])
+            pviews = [view(self.P, o, p) for p, o in zip(live, offs)]
             for p, v in zip(live, pviews):
+                v.copy_(p.data)
                 p.data = v
-        self._gviews = [self.G[o:o + p.numel()].view(p.shape) for p, o in zip(live, offs)]
+        self._gviews = [view(self.G, o, p) for p, o in zip(live, offs)]
         self._live = live
         self._live_ids = {id(p) for p in live}
 

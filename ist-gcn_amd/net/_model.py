@@ -118,6 +118,9 @@ class STGCNBlock(nn.Module):
             self.tcn = nn.Sequential(nn.BatchNorm2d(c), nn.ReLU(inplace=True),
                                      nn.Conv2d(c, c, (kernel_size[0], 1), (stride, 1), pad),
                                      nn.BatchNorm2d(c), nn.Dropout(dropout, inplace=True))
+            # the weight-gradient kernel produces [tap][Cout][Cin]; a flat-buffer optimizer may store this parameter (and its
+            # gradient) tap-major so that autograd hands the gradient over without a layout copy (harness.FlatSGD)
+            self.tcn[2].weight._istgcn_flat_layout = 'tap_major'
         else:
             w = int(c ** 0.5) if self.tcn_kind == 'bneck' else c
             self.width = w
@@ -174,7 +177,7 @@ class STGCNBlock(nn.Module):
 
     # ---- engine entry: NTVC in, NTVC out -------------------------------------------------------
     def run(self, x, A_eff, mst=None, nnz_cap=None, bterm=_UNSET, pattern=None, seed_base=None, bump=True, packed=None,
-            seed_epoch=None):
+            seed_epoch=None, step_arena=None):
         """pattern: [K,V,V] fp32 sparsity pattern of the adjacency gradient (None = dense); seed_base: the Model's
         per-forward draw (None: drawn here); bump=False: the caller advances num_batches_tracked itself; packed: this
         block's fragment-packed weights from the Model's one-launch PackPlan (None: packed per call); seed_epoch: int64[1]
@@ -183,6 +186,7 @@ class STGCNBlock(nn.Module):
             self._gather(x, A_eff, mst, nnz_cap, bterm, pattern)
         cfg.packed = packed
         cfg.seed_epoch = seed_epoch
+        cfg.step_arena = step_arena       # ops.StepArena: one zero fill per step for all blocks' gradient accumulators
         bn1, bn2 = bns[0], bns[1]
         bufs = {'bn1': (bn1.running_mean, bn1.running_var), 'bn2': (bn2.running_mean, bn2.running_var)}
         if len(bns) > 2:
@@ -466,6 +470,13 @@ class STGCNModel(nn.Module):
         infer = (not self.training) and (not torch.is_grad_enabled())
         packed = None if infer else self._packed_weights(x)
         folds = None if infer else self._folded_all()
+        arena = None
+        if self.training and torch.is_grad_enabled():
+            # gradient accumulators of all blocks out of one zero-filled allocation, sized by what the last backward took
+            prev = self.__dict__.get('_step_arena')
+            hint = max(self.__dict__.get('_arena_hint', 0), prev.requested if prev is not None else 0)
+            self.__dict__['_arena_hint'] = hint
+            arena = self.__dict__['_step_arena'] = ops.StepArena(hint)
         for i, blk in enumerate(self.st_gcn_networks):
             mst = self.mstcn_importance[i] if self.tcn_kind != 'single' else None
             if infer:                      # folded BatchNorms, cached plans, 2-4 launches per block
@@ -476,13 +487,14 @@ class STGCNModel(nn.Module):
                 continue
             A_eff, bterm = folds[i] if folds is not None else self._folded(i, blk)
             x = blk.run(x, A_eff, mst, nnz_cap=cap, bterm=bterm, pattern=pat, seed_base=seed_base, bump=False,
-                        packed=packed[i], seed_epoch=self.__dict__.get('_seed_epoch'))
+                        packed=packed[i], seed_epoch=self.__dict__.get('_seed_epoch'), step_arena=arena)
         return x
 
     def forward(self, x):
         N, M = x.size(0), x.size(4)
         y = self._trunk(x)                                           # (NM, T', V, 256)
-        feat = y.float().mean(dim=(1, 2)).view(N, M, -1).mean(dim=1)   # global pooling, then persons
+        # global pooling (fp32 accumulation straight from the storage type: no fp32 copy of the activation), then persons
+        feat = y.mean(dim=(1, 2), dtype=torch.float32).view(N, M, -1).mean(dim=1)
         # fcn is a 1x1 Conv2d on a 1x1 map (st_gcnold.py:92-94) = a matrix product (a plain GEMM instead of a convolution
         # library's fallback kernels)
         return F.linear(feat, self.fcn.weight.view(self.fcn.weight.shape[0], -1), self.fcn.bias)

@@ -247,13 +247,34 @@ def conv_taps_bwd(k, stride, phase):
     return [(j, (phase + pad - j) // stride) for j in range(k) if (phase + pad - j) % stride == 0]
 
 
+class StepArena:
+    """One zero-filled fp32 allocation per training step for the gradient accumulators of ALL blocks (one fill launch
+    instead of one per block).  The size is the total the previous step asked for (`hint`); a request that does not fit
+    (first step, changed shapes) gets its own allocation."""
+
+    def __init__(self, hint=0):
+        self.hint, self.requested, self.buf, self.off = int(hint), 0, None, 0
+
+    def take(self, n, device):
+        self.requested += n
+        if self.buf is None and self.hint >= n:
+            self.buf = torch.zeros(self.hint, dtype=torch.float32, device=device)
+        if self.buf is not None and self.buf.device == device and self.off + n <= self.buf.numel():
+            v = self.buf[self.off:self.off + n]
+            self.off += n
+            return v
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 class ZeroArena:
     """One zero-filled fp32 allocation carved into the gradient buffers of a block's backward (one memset launch instead
-    of one per buffer).  `take(shape)` hands out consecutive 16-byte aligned views."""
+    of one per buffer; none at all when a StepArena `parent` provides the memory).  `take()` hands out consecutive
+    16-byte aligned views."""
 
-    def __init__(self, shapes, device):
+    def __init__(self, shapes, device, parent=None):
         self.sizes = [(int(torch.Size(sh).numel()) + 3) // 4 * 4 for sh in shapes]
-        self.buf = torch.zeros(sum(self.sizes), dtype=torch.float32, device=device)
+        total = sum(self.sizes)
+        self.buf = parent.take(total, device) if parent is not None else torch.zeros(total, dtype=torch.float32, device=device)
         self.shapes, self.i, self.off = list(shapes), 0, 0
 
     def take(self):
