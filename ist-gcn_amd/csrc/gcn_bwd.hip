@@ -632,29 +632,45 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
         gb_barrier();                                       // dxa written
         BSTAMP(2)
         // transposed aggregation on the matrix cores: D[i][v] = sum_k sum_w dxa_k[(f,w)][i] * A_k[v][w]
-        // two (frame, 32-channel) units at a time: their MFMA chains interleave
-        for (int pr = wave8; pr < ((P.abl & 8) ? 0 : F * 2); pr += 8) {
+        // two (frame, 32-channel) units at a time (their MFMA chains interleave); the odd unit out goes alone
+        for (int pr = wave8; pr < F * 2; pr += 8) {
           const bool two = pr + 4 < F * 2;
-          const int fa = pr >> 1, ct = pr & 1, fb = two ? (pr + 4) >> 1 : fa;
+          const int fa = pr >> 1, ct = pr & 1, fb = (pr + 4) >> 1;
           f32x16 d0, d1;
 #pragma unroll
           for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
           const int blk = (cblk >> 3) + (pp >> 1), inb = 8 * (pp & 1);
           T* const imgp = reinterpret_cast<T*>(smem + (par ? P.off_img + TR * RB : P.off_img));
+          // rows fV + 16*sstep + 8h + q4 (lo) and + 4 (hi: its swizzle differs in bit 1 of the block index)
+          auto unit_off = [&](int f, int sstep) __attribute__((always_inline)) {
+            const int rw = f * V + 16 * sstep + 8 * h + q4;
+            return (ct * TR + rw) * 64 + ((blk ^ ((rw >> 1) & 3)) << 4) + inb;
+          };
+          if (two) {
 #pragma unroll
-          for (int sstep = 0; sstep < 2; ++sstep) {
-            // rows fV + 16*sstep + 8h + q4 (lo) and + 4 (hi: its swizzle differs in bit 1 of the block index)
-            const int rwa = fa * V + 16 * sstep + 8 * h + q4, rwb = fb * V + 16 * sstep + 8 * h + q4;
-            const int oa = (ct * TR + rwa) * 64 + ((blk ^ ((rwa >> 1) & 3)) << 4) + inb;
-            const int ob = (ct * TR + rwb) * 64 + ((blk ^ ((rwb >> 1) & 3)) << 4) + inb;
+            for (int sstep = 0; sstep < 2; ++sstep) {
+              const int oa = unit_off(fa, sstep), ob = unit_off(fb, sstep);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-              const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
-              const unsigned char* ka = dxa + k * 2 * TR * 64;
-              const frag_t a0 = tr_pair<T>(reinterpret_cast<const T*>(ka + oa), reinterpret_cast<const T*>(ka + (oa ^ 32) + 256));
-              const frag_t a1 = tr_pair<T>(reinterpret_cast<const T*>(ka + ob), reinterpret_cast<const T*>(ka + (ob ^ 32) + 256));
-              mma_kgroup(d0, a0, bfr);
-              mma_kgroup(d1, a1, bfr);
+              for (int k = 0; k < K; ++k) {
+                const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
+                const unsigned char* ka = dxa + k * 2 * TR * 64;
+                const frag_t a0 = tr_pair<T>(reinterpret_cast<const T*>(ka + oa), reinterpret_cast<const T*>(ka + (oa ^ 32) + 256));
+                const frag_t a1 = tr_pair<T>(reinterpret_cast<const T*>(ka + ob), reinterpret_cast<const T*>(ka + (ob ^ 32) + 256));
+                mma_kgroup(d0, a0, bfr);
+                mma_kgroup(d1, a1, bfr);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int sstep = 0; sstep < 2; ++sstep) {
+              const int oa = unit_off(fa, sstep);
+#pragma unroll
+              for (int k = 0; k < K; ++k) {
+                const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
+                const unsigned char* ka = dxa + k * 2 * TR * 64;
+                const frag_t a0 = tr_pair<T>(reinterpret_cast<const T*>(ka + oa), reinterpret_cast<const T*>(ka + (oa ^ 32) + 256));
+                mma_kgroup(d0, a0, bfr);
+              }
             }
           }
           if (v < V) {

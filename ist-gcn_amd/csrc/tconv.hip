@@ -59,6 +59,9 @@ struct TconvParams {
   int tap_off[MAX_TAPS];
   // derived on the host
   int F, tiles_per_seq, total_tiles, CC, nch, NKG, MTtot, min_off, Fin;
+  // ceil(2^32 / d) for the two run-time divisors of the item decode (x / d == umulhi(x, magic) for x * d < 2^32, d > 1):
+  // a division by a run-time value is ~40 instructions, and the memory waves decode two items per iteration
+  unsigned tps_magic, nch_magic;
   int us_stride, out_stride, off_stat, off_u0, off_u1, off_o;
   int cin_pad;           // nch * CC: length of the LDS copies of the `pre` rows
   int abl;               // diagnostic ablation (ISTGCN_TCONV_ABL): 1 = no input loads, 2 = no MFMAs; results are then wrong
@@ -141,11 +144,12 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
   const int ntile_w = slot0 < slot_end ? (slot_end - slot0 + G8 - 1) / G8 : 0;
   const int nch = P.nch;
   const int total_items = ntile_w * nch;
+  auto udiv = [](int x, int d, unsigned magic) __attribute__((always_inline)) { return d == 1 ? x : (int)__umulhi((unsigned)x, magic); };
   auto tile_of = [&](int k) __attribute__((always_inline)) {
     Tile t;
     t.valid = k < ntile_w;
     const int tile = xcd * chunk + slot0 + (t.valid ? k : 0) * G8;
-    t.n = tile / P.tiles_per_seq;
+    t.n = udiv(tile, P.tiles_per_seq, P.tps_magic);
     t.m0 = (tile - t.n * P.tiles_per_seq) * P.F;
     t.nf = min(P.F, P.Mlog - t.m0);
     t.rows = t.nf * V;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     // ---- global loads of item j -> registers: all UL loads of a thread are in flight together, and they stay in flight
     //      while the previous tile's output image is streamed out (the loads are only waited for in `commit`) ----
     auto issue = [&](int j, u32x4 (&R)[UL]) __attribute__((always_inline)) {
-      const int k = j / nch, ch = j - k * nch;
+      const int k = udiv(j, nch, P.nch_magic), ch = j - k * nch;
       const Tile t = tile_of(k);
       const int cb = ch * P.CC;
       const bool qlive = t.valid && (q * EPL < P.Cin - cb);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     };
     // ---- registers of item j -> BatchNorm affine + ReLU -> LDS tile (zero rows outside the sequence / chunk) ----
     auto commit = [&](int j, u32x4 (&R)[UL], T* us) __attribute__((always_inline)) {
-      const int k = j / nch, ch = j - k * nch;
+      const int k = udiv(j, nch, P.nch_magic), ch = j - k * nch;
       const Tile t = tile_of(k);
       if (!t.valid) return;
       const int cb = ch * P.CC;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     bool pending = false;
     Tile pend = tile_of(0);
     auto iteration = [&](int it, u32x4 (&Rn)[UL], u32x4 (&Rf)[UL]) __attribute__((always_inline)) {    // Rn: item it+1, Rf: free -> item it+2
-      const int k = it / nch, ch = it - k * nch;
+      const int k = udiv(it, nch, P.nch_magic), ch = it - k * nch;
       u32x4 AV[AUXPF ? NR : 1];
       if (pending) aux_prefetch(pend, NPASS - 1, AV);       // oldest loads of the iteration: landed when the sweep starts
       __builtin_amdgcn_sched_barrier(0);
@@ -672,9 +676,11 @@ template <typename T>
 int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t stream) {
   P.F = G.F; P.CC = G.CC; P.nch = G.nch; P.NKG = G.NKG; P.MTtot = G.MTtot; P.min_off = G.min_off; P.Fin = G.Fin;
   P.us_stride = G.us_stride; P.out_stride = G.out_stride; P.off_stat = G.off_stat; P.cin_pad = G.nch * G.CC;
+  P.nch_magic = (unsigned)(((1ull << 32) + G.nch - 1) / (unsigned long long)G.nch);
   P.off_u0 = G.off_u0; P.off_u1 = G.off_u1; P.off_o = G.off_o;
   P.tiles_per_seq = ceil_div(P.Mlog, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
+  P.tps_magic = (unsigned)(((1ull << 32) + P.tiles_per_seq - 1) / (unsigned long long)P.tiles_per_seq);
   const size_t lds = G.lds;
   const char* e_abl = getenv("ISTGCN_TCONV_ABL");
   P.abl = e_abl ? atoi(e_abl) : 0;
