@@ -200,8 +200,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
         const int cb = cch * P.CCc;
         // this step's weight fragments first (L2), the dy chunk right behind them: one memory round trip for both
         load_weights(ich * P.nchc + cch);
-        stage_block<T, 4, VEC>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
-                               nullptr, nullptr, 0, tid, NTHREADS);
+        // (dy rows are whole 16-byte vectors whenever Cout is a multiple of the vector width, whatever Cin is: the 3-channel
+        //  first layer staged its 64-channel dy element by element under the kernel-wide VEC flag)
+        if (VEC || (P.Cout % EPL) == 0)
+          stage_block<T, 4, true>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
+                                  nullptr, nullptr, 0, tid, NTHREADS);
+        else
+          stage_block<T, 4, false>(dyg + pos0 * P.Cout + cb, (size_t)P.Cout, P.Cout - cb, dys, DS, TR, 0, rows, P.CCc / EPL,
+                                   nullptr, nullptr, 0, tid, NTHREADS);
         __syncthreads();
         {
           const T* brow = dys + (ph * 32 * NTW + (lane & 31)) * DS + (lane >> 5) * EPL;

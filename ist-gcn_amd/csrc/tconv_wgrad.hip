@@ -289,7 +289,10 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
     const size_t pos0 = (size_t)(n * P.Tz + m0) * V;
     {
       const T* src = dzg + pos0 * P.Cout + o0;
-      load_subtiles<T, UZ, VEC>(pz, src, (size_t)P.Cout, P.Cout - o0, TR, 0, rows, OT, 0, tid, NTH);
+      // (dz rows are whole 16-byte vectors whenever Cout is a multiple of the vector width, whatever Cin is: the 3-channel
+      //  first layer loaded its 64-channel dz element by element under the kernel-wide VEC flag)
+      if (VEC || (P.Cout % Elem<T>::EPL) == 0) load_subtiles<T, UZ, true>(pz, src, (size_t)P.Cout, P.Cout - o0, TR, 0, rows, OT, 0, tid, NTH);
+      else load_subtiles<T, UZ, false>(pz, src, (size_t)P.Cout, P.Cout - o0, TR, 0, rows, OT, 0, tid, NTH);
     }
     if constexpr (AGG) {
       const T* src = gg + pos0 * P.Cin + i0;
