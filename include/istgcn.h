@@ -211,6 +211,14 @@ int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
                    unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream);
 
+/* Global average pooling of the trunk output and its backward (net/st_gcnold.py:89-91: F.avg_pool2d over (T, V), then the
+ * mean over the M persons of a clip).  y [NM][P = T*V][C] in `dtype`.
+ * istgcn_pool_fwd: psum [NM][S][C] fp32 = sums of y over S row slices of every sequence (written, not accumulated); the
+ *   clip feature is the sum of its M*S partial rows divided by M*P.
+ * istgcn_pool_bwd: dy[nm][p][c] = scale * dfeat[nm / M][c] for all p (dfeat [NM/M][C] fp32; scale = 1/(M*P)). */
+int istgcn_pool_fwd(const void* y, float* psum, int NM, int P, int C, int S, int dtype, void* stream);
+int istgcn_pool_bwd(const float* dfeat, void* dy, int NM, int P, int C, int M, float scale, int dtype, void* stream);
+
 /* Input stage: the feeder's augmentation (feeder/tools.py:31-101) and the data_bn prologue (net/st_gcnold.py:74-80) on
  * the GPU.  raw [N][C][Traw][V][M] fp32 is the clip batch as the reference's DataLoader delivers it;
  *   shift [N] int or NULL: source frame of output frame t is t + shift[n], frames outside [0, Traw) are zero

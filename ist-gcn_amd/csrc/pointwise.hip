@@ -331,6 +331,61 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
   }
 }
 
+
+// Global average pooling of the trunk output (net/st_gcnold.py:89-91: F.avg_pool2d over (T, V), then the mean over the M
+// persons of a clip): partial SUMS over row slices, out[s][rows of slice][c] -> psum [S][seqs][C]; the caller adds the M*S
+// partial rows of a clip.  One workgroup = one (sequence, slice): lanes walk the channel vectors, row groups the rows.
+template <typename T, int VW>
+__global__ __launch_bounds__(NT) void pool_fwd_kernel(const T* y, float* psum, int P, int C, int S) {
+  __shared__ float red[NT * VW];
+  const int QC = C / VW;                       // channel vectors per row (<= NT, checked on the host)
+  const int nm = blockIdx.x, sl = blockIdx.y;
+  const int rg = threadIdx.x / QC, q = threadIdx.x - rg * QC, RG = NT / QC;
+  const int r_lo = (int)((long long)P * sl / S), r_hi = (int)((long long)P * (sl + 1) / S);
+  float acc[VW];
+#pragma unroll
+  for (int j = 0; j < VW; ++j) acc[j] = 0.f;
+  if (rg < RG) {
+    const T* base = y + ((size_t)nm * P) * C + q * VW;
+    for (int r = r_lo + rg; r < r_hi; r += RG) {
+      float v[VW];
+      load_vec<T, VW>(base + (size_t)r * C, v);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) acc[j] += v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VW; ++j) red[threadIdx.x * VW + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < QC) {
+    float tot[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) tot[j] = 0.f;
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int j = 0; j < VW; ++j) tot[j] += red[(g * QC + threadIdx.x) * VW + j];
+    float* o = psum + ((size_t)nm * S + sl) * C + threadIdx.x * VW;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) o[j] = tot[j];
+  }
+}
+
+// backward of the pooling: dy[nm][p][c] = scale * dfeat[nm / M][c] for every position p (broadcast store)
+template <typename T, int VW>
+__global__ __launch_bounds__(NT) void pool_bwd_kernel(const float* dfeat, T* dy, size_t rows, int P, int C, int M, float scale) {
+  const int QC = C / VW;
+  const size_t total = rows * QC;
+  for (size_t idx = (size_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (size_t)gridDim.x * NT) {
+    const size_t row = idx / QC;
+    const int q = (int)(idx - row * QC);
+    const size_t n = row / ((size_t)P * M);
+    float v[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) v[j] = scale * dfeat[n * C + q * VW + j];
+    store_vec<T, VW>(dy + idx * VW, v);
+  }
+}
+
 static inline int ew_grid(size_t items) {
   size_t g = (items + NT - 1) / NT;
   if (g > 2048) g = 2048;
@@ -436,6 +491,28 @@ extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, vo
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
   EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_pool_fwd(const void* y, float* psum, int NM, int P, int C, int S, int dtype, void* stream) {
+  if (!y || !psum || NM < 0 || P < 1 || C < 1 || S < 1 || S > P || !istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
+  if (NM == 0) return ISTGCN_OK;
+  int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
+  if (C / vw > NT) return ISTGCN_EINVAL;
+  const dim3 grid(NM, S);
+  EW_CASES(DISPATCH_VW(pool_fwd_kernel, ET, VWB, grid, (const ET*)y, psum, P, C, S));
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_pool_bwd(const float* dfeat, void* dy, int NM, int P, int C, int M, float scale, int dtype, void* stream) {
+  if (!dfeat || !dy || NM < 0 || P < 1 || C < 1 || M < 1 || (NM % M) != 0 || !istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
+  if (NM == 0) return ISTGCN_OK;
+  const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
+  const size_t rows = (size_t)NM * P;
+  const dim3 grid(ew_grid(rows * (C / vw)));
+  EW_CASES(DISPATCH_VW(pool_bwd_kernel, ET, VWB, grid, dfeat, (ET*)dy, rows, P, C, M, scale));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

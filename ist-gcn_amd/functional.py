@@ -378,6 +378,21 @@ class STGCNBlockFn(torch.autograd.Function):
                 dWr, dbr, dgr, dbetar, dWs, dbs, dWe, dbe)
 
 
+class PoolFn(torch.autograd.Function):
+    """Trunk output [N*M, T, V, C] -> clip features [N, C] fp32: F.avg_pool2d over (T, V), then the mean over the M persons
+    (net/st_gcnold.py:89-91).  Two launches forward (partial sums + one reduction), one backward (broadcast store)."""
+
+    @staticmethod
+    def forward(ctx, y, M):
+        ctx.meta = (tuple(y.shape), y.dtype, int(M))
+        return ops.pool_fwd(y.contiguous(), int(M))
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        shape, dtype, M = ctx.meta
+        return ops.pool_bwd(dfeat.float(), shape, dtype, M), None
+
+
 # --------------------------------------------------------------------------------------------------
 # input stage: (feeder augmentation +) data_bn + layout change
 # --------------------------------------------------------------------------------------------------

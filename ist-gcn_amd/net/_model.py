@@ -493,8 +493,8 @@ class STGCNModel(nn.Module):
     def forward(self, x):
         N, M = x.size(0), x.size(4)
         y = self._trunk(x)                                           # (NM, T', V, 256)
-        # global pooling (fp32 accumulation straight from the storage type: no fp32 copy of the activation), then persons
-        feat = y.mean(dim=(1, 2), dtype=torch.float32).view(N, M, -1).mean(dim=1)
+        # global pooling over (T, V) and the persons, fp32 accumulation straight from the storage type (csrc/pointwise.hip)
+        feat = Fn.PoolFn.apply(y, M)
         # fcn is a 1x1 Conv2d on a 1x1 map (st_gcnold.py:92-94) = a matrix product (a plain GEMM instead of a convolution
         # library's fallback kernels)
         return F.linear(feat, self.fcn.weight.view(self.fcn.weight.shape[0], -1), self.fcn.bias)

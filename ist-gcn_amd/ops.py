@@ -530,6 +530,34 @@ def affine2(d, x, abc, p_drop=0.0, seed=0, epoch=None):
     return out
 
 
+POOL_SLICES = 8
+
+
+def pool_fwd(y, M):
+    """Global average pooling (st_gcnold.py:89-91): y [N*M, T, V, C] -> feat [N, C] fp32 = mean over (T, V) and the M persons.
+    One kernel writes partial sums over POOL_SLICES row slices per sequence; one torch reduction adds a clip's M*S rows."""
+    NM, T, V, C = y.shape
+    assert y.is_contiguous() and NM % M == 0
+    S = min(POOL_SLICES, T * V)
+    psum = torch.empty((NM, S, C), dtype=torch.float32, device=y.device)
+    dv = _check_dev(y, psum)
+    _call('istgcn_pool_fwd', _ptr(y), _ptr(psum), NM, T * V, C, S, dtype_code(y), _stream(y),
+          work=(float(y.numel()), float(y.numel()) * _esz(y)), dev=dv)
+    return psum.view(NM // M, M * S, C).sum(1) * (1.0 / (M * T * V))
+
+
+def pool_bwd(dfeat, shape, dtype, M):
+    """dy [N*M, T, V, C] in `dtype` = dfeat[n] / (M*T*V) at every position (backward of pool_fwd)."""
+    NM, T, V, C = shape
+    dfeat = dfeat.contiguous()
+    assert dfeat.shape == (NM // M, C) and dfeat.dtype == torch.float32
+    dy = torch.empty(shape, dtype=dtype, device=dfeat.device)
+    dv = _check_dev(dfeat, dy)
+    _call('istgcn_pool_bwd', _ptr(dfeat), _ptr(dy), NM, T * V, C, M, ctypes.c_float(1.0 / (M * T * V)), dtype_code(dy),
+          _stream(dy), work=(float(dy.numel()), float(dy.numel()) * _esz(dy)), dev=dv)
+    return dy
+
+
 # ----------------------------------------------------------------------------------------------
 # parameter folds of the graph-conv unit (fold.hip)
 # ----------------------------------------------------------------------------------------------

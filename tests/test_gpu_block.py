@@ -627,3 +627,26 @@ def test_dataparallel_wrapper_runs_the_hip_path(ops):
     g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
     assert rel_err(out1, out0) < 1e-5
     assert rel_err(g1, g0) < 2e-3          # (fp32 atomics + isolated ReLU flips between two runs of the same path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(6, 2, 75, 25, 256), (4, 1, 13, 18, 64), (2, 2, 5, 25, 20), (3, 1, 2, 3, 7)])
+def test_pooling_matches_avg_pool_and_person_mean(ops, shape, dt):
+    """PoolFn = F.avg_pool2d over (T, V) + mean over the M persons (net/st_gcnold.py:89-91), forward and backward."""
+    from istgcn_amd import functional as Fn
+    N, M, T, V, C = shape
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(N * M, T, V, C, generator=g).to(dt)
+    w = torch.randn(N, C, generator=g)
+    yr = y.float().clone().requires_grad_(True)
+    ref = yr.mean(dim=(1, 2)).view(N, M, C).mean(dim=1)
+    (ref * w).sum().backward()
+    yd = y.to(dev()).detach().requires_grad_(True)
+    feat = Fn.PoolFn.apply(yd, M)
+    (feat * w.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    assert feat.dtype == torch.float32 and feat.shape == (N, C)
+    assert (feat.cpu() - ref.detach()).abs().max() < 2e-6 * max(1.0, float(T * V) ** 0.5)
+    want = yr.grad.to(dt).float()
+    assert (yd.grad.float().cpu() - want).abs().max() <= 1e-6 + 2.0 ** -7 * want.abs().max() * (0 if dt == torch.float32 else 1)
