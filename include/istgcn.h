@@ -200,13 +200,17 @@ int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, double count, co
  * istgcn_block_out_bwd: dres = dout * [out > 0] (the gradient of both the residual branch and, after dropout, of
  *   tcn.3); stats2 += (sum dres*mask, sum dres*mask*zhat); statsr += (sum dres, sum dres*rhat) when the residual
  *   branch has a BatchNorm (r = its input, coefr = its coef[4][C]); r == NULL otherwise.
- * istgcn_affine2: out = abc[0]*d*mask + abc[1]*x + abc[2]  (elementwise part of BatchNorm backward; x may be NULL). */
+ * istgcn_affine2: out = abc[0]*d*mask + abc[1]*x + abc[2]  (elementwise part of BatchNorm backward; x may be NULL).
+ * relu_mask (optional, both directions; only where istgcn_relu_mask_ok(C, dtype) == 1): [rows * C / vector width] bytes,
+ *   bit j of byte i = (element j of the i-th 16-byte vector of `out`, as stored, is > 0).  The forward writes it; given
+ *   to the backward it replaces the read of `out` (which may then be NULL): 1/16 of that tensor's bytes. */
+int istgcn_relu_mask_ok(int C, int dtype);
 int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
-                         long long rows, int C, float p_drop, unsigned long long seed,
+                         unsigned char* relu_mask, long long rows, int C, float p_drop, unsigned long long seed,
                          const unsigned long long* seed_epoch, int dtype, void* stream);
-int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
-                         const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
-                         long long rows, int C, float p_drop, unsigned long long seed,
+int istgcn_block_out_bwd(const void* dout, const void* out, const unsigned char* relu_mask, const void* z,
+                         const float* coef2, const void* r, const float* coefr, void* dres, double* stats2,
+                         double* statsr, int stats_rep, long long rows, int C, float p_drop, unsigned long long seed,
                          const unsigned long long* seed_epoch, int dtype, void* stream);
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
                    unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream);

@@ -83,6 +83,15 @@ __device__ static inline void store_vec(T* p, float (&f)[VW]) {
   }
 }
 
+// bit j = (f[j], rounded to the storage type, is > 0): the ReLU mask of a stored activation vector in one byte
+template <typename T, int VW>
+__device__ static inline unsigned relu_bits(const float (&f)[VW]) {
+  unsigned b = 0;
+#pragma unroll
+  for (int j = 0; j < VW; ++j) b |= (Elem<T>::to_f(Elem<T>::from_f(f[j])) > 0.f ? 1u : 0u) << j;
+  return b;
+}
+
 struct DropCfg {
   uint32_t thr; float inv_keep; uint32_t s0, s1; int on;
   // optional device-resident offset added to the seed when the kernel runs: lets a launch recorded ONCE in a hipGraph
@@ -171,7 +180,7 @@ __global__ void bn_bwd_coef_kernel(double* stats, int rep, int clear, double cou
 // (`fixed_q`); otherwise they are re-read per element (the generic path for odd channel counts).
 template <typename T, int VW>
 __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const float* coef2, const T* res, const float* coefr,
-                                                          T* out, size_t rows, int C, DropCfg D) {
+                                                          T* out, unsigned char* rmask, size_t rows, int C, DropCfg D) {
   uint32_t dk0, dk1;
   drop_key(D, dk0, dk1);
   const int QC = C / VW;
@@ -214,6 +223,7 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
       zv[j] = fmaxf(y, 0.f);
     }
     store_vec<T, VW>(out + e0, zv);
+    if (rmask) rmask[idx] = (unsigned char)relu_bits<T, VW>(zv);      // one byte per vector: the backward's [out > 0]
   }
 }
 
@@ -221,9 +231,10 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
 // HASR: the residual branch has its own BatchNorm (strided 1x1 conv, 2 of 10 blocks); a compile-time switch because the
 // second set of per-channel constants and sums costs 32 registers = one resident wave per SIMD (126 -> 94 VGPRs)
 template <typename T, int VW, bool HASR>
-__global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const T* z, const float* coef2,
-                                                          const T* r, const float* coefr, T* dres, double* stats2,
-                                                          double* statsr, int rep, size_t rows, int C, DropCfg D) {
+__global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const unsigned char* rmask, const T* z,
+                                                          const float* coef2, const T* r, const float* coefr, T* dres,
+                                                          double* stats2, double* statsr, int rep, size_t rows, int C,
+                                                          DropCfg D) {
   uint32_t dk0, dk1;
   drop_key(D, dk0, dk1);
   __shared__ float red[4][NT];
@@ -242,7 +253,14 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
     const size_t e0 = row * C + c0;
     float dv[VW], ov[VW], zv[VW], rv[VW], m[VW];
     load_vec<T, VW>(dout + e0, dv);
-    load_vec<T, VW>(out + e0, ov);
+    if (rmask) {
+      // the forward's one-byte ReLU mask of this vector instead of the 16-byte read of `out`
+      const unsigned bits = rmask[row * QC + q];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) ov[j] = (bits >> j) & 1u ? 1.f : 0.f;
+    } else {
+      load_vec<T, VW>(out + e0, ov);
+    }
     load_vec<T, VW>(z + e0, zv);
     if (HASR) load_vec<T, VW>(r + e0, rv);
     if (D.on) {
@@ -423,6 +441,14 @@ extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, doubl
   return ISTGCN_OK;
 }
 
+// 1 when the one-byte-per-vector ReLU mask is available for (C, dtype): forward and backward both use whole 16-byte
+// vectors (C a multiple of the vector width and the per-channel thread map of the backward divides the block)
+extern "C" int istgcn_relu_mask_ok(int C, int dtype) {
+  if (!istgcn_dtype_ok(dtype) || C < 1) return 0;
+  const int epl = dtype == 0 ? 4 : 8;
+  return (C % epl == 0 && C / epl <= NT && NT % (C / epl) == 0) ? 1 : 0;
+}
+
 // dtype dispatch of the element-wise kernels: cast every activation pointer to the element type and launch
 #define EW_CASES(BODY)                                           \
   do {                                                           \
@@ -437,25 +463,28 @@ extern "C" int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, doubl
   } while (0)
 
 extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const void* res, const float* coefr, void* out,
-                                    long long rows, int C, float p_drop, unsigned long long seed,
+                                    unsigned char* relu_mask, long long rows, int C, float p_drop, unsigned long long seed,
                                     const unsigned long long* seed_epoch, int dtype, void* stream) {
   if (!z || !coef2 || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
+  // the mask is one byte per WHOLE vector: both directions must use the vector map (istgcn_relu_mask_ok)
+  if (relu_mask && !istgcn_relu_mask_ok(C, dtype)) return ISTGCN_EINVAL;
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const dim3 grid(ew_grid((size_t)rows * (C / vw)));
   EW_CASES(DISPATCH_VW(block_out_fwd_kernel, ET, VWB, grid, (const ET*)z, coef2, (const ET*)res, coefr, (ET*)out,
-                       (size_t)rows, C, D));
+                       relu_mask, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }
 
-extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const void* z, const float* coef2, const void* r,
-                                    const float* coefr, void* dres, double* stats2, double* statsr, int stats_rep,
-                                    long long rows, int C, float p_drop, unsigned long long seed,
-                                    const unsigned long long* seed_epoch, int dtype, void* stream) {
-  if (!dout || !out || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
+extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const unsigned char* relu_mask, const void* z,
+                                    const float* coef2, const void* r, const float* coefr, void* dres, double* stats2,
+                                    double* statsr, int stats_rep, long long rows, int C, float p_drop,
+                                    unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream) {
+  if (!dout || (!out && !relu_mask) || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
+  if (relu_mask && !istgcn_relu_mask_ok(C, dtype)) return ISTGCN_EINVAL;
   if ((r != nullptr) != (coefr != nullptr) || (r && !statsr)) return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
   if (rows == 0) return ISTGCN_OK;
@@ -471,7 +500,7 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const voi
   const dim3 grid((int)g);
 #define BOB_LAUNCH(VWv, HR)                                                                                              \
   ISTGCN_LAUNCH((block_out_bwd_kernel<ET, VWv, HR>), grid, dim3(NT), 0, (hipStream_t)stream, (const ET*)dout, (const ET*)out,  \
-                (const ET*)z, coef2, (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D)
+                relu_mask, (const ET*)z, coef2, (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D)
   EW_CASES({
     if (vw == VWB) { if (r) BOB_LAUNCH(VWB, true); else BOB_LAUNCH(VWB, false); }
     else { if (r) BOB_LAUNCH(1, true); else BOB_LAUNCH(1, false); }

@@ -296,17 +296,18 @@ class STGCNBlockFn(torch.autograd.Function):
             res, cr = None, None
         # 4. BN2 + dropout + residual + ReLU
         p = cfg.p_drop if training else 0.0
-        out = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed, epoch=cfg.seed_epoch)
+        # (training: the ReLU mask of `out` as one byte per vector, so the backward does not read `out` again)
+        out, rmask = ops.block_out_fwd(z, coef2[:2].contiguous(), res, cr, p, seed, epoch=cfg.seed_epoch, want_mask=True)
         ctx.cfg, ctx.training, ctx.seed, ctx.p = cfg, training, seed, p
         ctx.step_arena = cfg.step_arena   # captured now: the next forward replaces cfg.step_arena before this backward runs
-        ctx.save_for_backward(x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb)
+        ctx.save_for_backward(x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb, rmask)
         ctx.has_b = bterm is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         cfg, training, seed, p = ctx.cfg, ctx.training, ctx.seed, ctx.p
-        (x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb) = ctx.saved_tensors
+        (x, A_eff, Wg3, g1, Wt, g2, Wr, gr, Ws, We, g, z, out, coef1, coef2, r, coefr, q, yb, rmask) = ctx.saved_tensors
         dt = x.dtype
         NM, T, V, cin = x.shape
         cout, s, k = cfg.cout, cfg.stride, cfg.ksize
@@ -316,7 +317,8 @@ class STGCNBlockFn(torch.autograd.Function):
             dout = dout.to(dt)
         pk = cfg.packed or {}
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
-        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True, epoch=cfg.seed_epoch)
+        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True, epoch=cfg.seed_epoch,
+                                             relu_mask=rmask)
         abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
         dz = ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)

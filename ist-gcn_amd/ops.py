@@ -489,20 +489,33 @@ def _epoch_ptr(epoch, like):
     return _ptr(epoch)
 
 
-def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0, epoch=None):
+def relu_mask_ok(C, dtype):
+    """Is the one-byte-per-vector ReLU mask available for this channel count / storage type (istgcn_relu_mask_ok)?"""
+    epl = 4 if dtype == torch.float32 else 8
+    return C % epl == 0 and C // epl <= 256 and 256 % (C // epl) == 0
+
+
+def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0, epoch=None, want_mask=False):
+    """-> out, or (out, relu_mask) with want_mask: relu_mask uint8 [rows*C/vector width] (None where relu_mask_ok is
+    False) lets block_out_bwd skip its read of `out`."""
     out = torch.empty_like(z)
-    dv = _check_dev(z, coef2, res, coefr, out)
+    C = z.shape[-1]
+    rmask = None
+    if want_mask and relu_mask_ok(C, z.dtype):
+        rmask = torch.empty(z.numel() // (4 if z.dtype == torch.float32 else 8), dtype=torch.uint8, device=z.device)
+    dv = _check_dev(z, coef2, res, coefr, out, rmask)
     if res is not None:
         assert res.shape == z.shape and res.dtype == z.dtype
-    _call('istgcn_block_out_fwd', _ptr(z), _ptr(coef2), _ptr(res), _ptr(coefr), _ptr(out), ctypes.c_longlong(_rows(z)),
-          z.shape[-1], ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
+    _call('istgcn_block_out_fwd', _ptr(z), _ptr(coef2), _ptr(res), _ptr(coefr), _ptr(out), _ptr(rmask),
+          ctypes.c_longlong(_rows(z)), C, ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z),
+          dtype_code(z), _stream(z),
           work=(3.0 * z.numel(), float(z.numel()) * (3 if res is not None else 2) * _esz(z)), dev=dv)
-    return out
+    return (out, rmask) if want_mask else out
 
 
-def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None):
+def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None, relu_mask=None):
     """-> (dres = dout*[out>0], stats2, statsr or None); scratch=True: the sums go to `stats_scratch` slots 0 / 1
-    (consume them with bn_bwd_coef(clear=True))."""
+    (consume them with bn_bwd_coef(clear=True)).  relu_mask: the forward's byte mask; `out` is then not read."""
     C = z.shape[-1]
     dres = torch.empty_like(z)
     if scratch:
@@ -511,12 +524,14 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
     else:
         st2 = new_stats(C, z.device)
         str_ = new_stats(C, z.device) if r is not None else None
-    assert dout.shape == z.shape == out.shape and dout.dtype == z.dtype
-    dv = _check_dev(dout, out, z, coef2, r, coefr, dres, st2, str_)
-    _call('istgcn_block_out_bwd', _ptr(dout), _ptr(out), _ptr(z), _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres),
-          _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C, ctypes.c_float(p_drop),
-          ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
-          work=(6.0 * z.numel(), float(z.numel()) * (5 if r is not None else 4) * _esz(z)), dev=dv)
+    assert dout.shape == z.shape and dout.dtype == z.dtype and (out is None or out.shape == z.shape)
+    assert out is not None or relu_mask is not None
+    dv = _check_dev(dout, out, relu_mask, z, coef2, r, coefr, dres, st2, str_)
+    nt = (4 if r is not None else 3) + (1.0 / 16 if relu_mask is not None else 1)
+    _call('istgcn_block_out_bwd', _ptr(dout), _ptr(None if relu_mask is not None else out), _ptr(relu_mask), _ptr(z),
+          _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres), _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C,
+          ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
+          work=(6.0 * z.numel(), float(z.numel()) * nt * _esz(z)), dev=dv)
     return dres, st2, str_
 
 

@@ -650,3 +650,35 @@ def test_pooling_matches_avg_pool_and_person_mean(ops, shape, dt):
     assert (feat.cpu() - ref.detach()).abs().max() < 2e-6 * max(1.0, float(T * V) ** 0.5)
     want = yr.grad.to(dt).float()
     assert (yd.grad.float().cpu() - want).abs().max() <= 1e-6 + 2.0 ** -7 * want.abs().max() * (0 if dt == torch.float32 else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('C,with_res', [(64, False), (256, True), (24, False)])
+def test_block_out_relu_mask_equals_reading_out(ops, C, with_res, dt):
+    """The forward's one-byte-per-vector ReLU mask makes the backward bit-identical to the one that reads `out`
+    (st_gcnold.py:201-203: relu(tcn(x) + res)); channel counts without a vector map get no mask."""
+    rows = 3 * 7 * 25
+    g = torch.Generator().manual_seed(C)
+    d = dev()
+    z = torch.randn(3, 7, 25, C, generator=g).to(d, dt)
+    res = torch.randn(3, 7, 25, C, generator=g).to(d, dt) if with_res else None
+    coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2,
+                        torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).to(d)
+    coefr = coef.flip(1).contiguous() if with_res else None
+    out, rmask = ops.block_out_fwd(z, coef[:2].contiguous(), res, None if coefr is None else coefr[:2].contiguous(), 0.3, 11,
+                                   want_mask=True)
+    assert (rmask is not None) == ops.relu_mask_ok(C, dt)
+    if rmask is None:
+        return
+    epl = 4 if dt == torch.float32 else 8
+    want = ((out.view(-1, epl) > 0).to(torch.int32) << torch.arange(epl, device=d, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(rmask, want)
+    dout = torch.randn(3, 7, 25, C, generator=g).to(d, dt)
+    a = ops.block_out_bwd(dout, out, z, coef, res, coefr, 0.3, 11)
+    b = ops.block_out_bwd(dout, None, z, coef, res, coefr, 0.3, 11, relu_mask=rmask)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and rows * C == out.numel()
+    assert (a[1] - b[1]).abs().max() <= 1e-9 * a[1].abs().max() + 1e-12
+    if with_res:
+        assert (a[2] - b[2]).abs().max() <= 1e-9 * a[2].abs().max() + 1e-12
