@@ -285,7 +285,8 @@ def save_model(model, path):
     """torchlight IO.save_model (io.py:101-107): CPU state dict with every `module.` removed from the keys -- a file the
     reference's own load_weights (and therefore its processors and demos) reads back."""
     from collections import OrderedDict
-    weights = OrderedDict([[''.join(k.split('module.')), v.cpu()] for k, v in model.state_dict().items()])
+    # (.contiguous(): parameters living in a flat optimizer buffer may be stored tap-major; the file holds plain tensors)
+    weights = OrderedDict([[''.join(k.split('module.')), v.cpu().contiguous()] for k, v in model.state_dict().items()])
     torch.save(weights, path)
     return path
 
