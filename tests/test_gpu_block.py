@@ -682,3 +682,42 @@ def test_block_out_relu_mask_equals_reading_out(ops, C, with_res, dt):
     assert (a[1] - b[1]).abs().max() <= 1e-9 * a[1].abs().max() + 1e-12
     if with_res:
         assert (a[2] - b[2]).abs().max() <= 1e-9 * a[2].abs().max() + 1e-12
+
+
+@pytest.mark.gpu
+def test_flat_sgd_tap_major_layout_and_checkpoint_round_trip(tmp_path):
+    """FlatSGD stores the temporal-conv weights [k][Cout][Cin] inside its flat buffers (the layout their gradient is computed
+    in; the parameter keeps the Conv2d shape).  Updates must equal torch.optim.SGD's on a contiguous twin, gradients must
+    arrive without a layout copy, and a checkpoint (torchlight io.py:101-107 / 57-90) must round-trip through plain tensors."""
+    from istgcn_amd import harness
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(16, 16, 9, 1, generator=g)
+    b0 = torch.randn(16, generator=g)
+    mk = lambda: (torch.nn.Parameter(w0.clone().to(d)), torch.nn.Parameter(b0.clone().to(d)))  # noqa: E731
+    (wa, ba), (wb, bb) = mk(), mk()
+    wa._istgcn_flat_layout = 'tap_major'
+    oa = harness.FlatSGD([wa, ba], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    ob = torch.optim.SGD([wb, bb], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    for step in range(3):
+        oa.zero_grad()
+        ob.zero_grad()
+        gw = torch.randn(9, 16, 16, generator=g).to(d)                 # what tconv_wgrad produces: [k][Cout][Cin]
+        gb = torch.randn(16, generator=g).to(d)
+        wa.grad, ba.grad = gw.permute(1, 2, 0).unsqueeze(-1), gb.clone()
+        wb.grad, bb.grad = gw.permute(1, 2, 0).unsqueeze(-1).contiguous(), gb.clone()
+        oa.step()
+        ob.step()
+        assert rel_err(wa, wb) < 2e-6 and rel_err(ba, bb) < 2e-6
+    assert wa.shape == (16, 16, 9, 1) and not wa.is_contiguous()
+    assert wa.data.view(16, 16, 9).permute(2, 0, 1).is_contiguous()    # what the packers and the gradient see
+    assert wa.grad.stride()[:3] == wa.stride()[:3]
+    mod = torch.nn.Module()
+    mod.w, mod.b = wa, ba
+    path = harness.save_model(mod, str(tmp_path / 'm.pt'))
+    sd = torch.load(path)
+    assert all(v.is_contiguous() for v in sd.values())
+    fresh = torch.nn.Module()
+    fresh.w, fresh.b = torch.nn.Parameter(torch.zeros(16, 16, 9, 1)), torch.nn.Parameter(torch.zeros(16))
+    harness.load_weights(fresh, path)
+    assert torch.equal(fresh.w.detach(), wa.detach().cpu()) and torch.equal(fresh.b.detach(), ba.detach().cpu())
