@@ -823,7 +823,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
         adv_item(ix);
         issue_rows(P.dA ? xg : nullptr, ix, XR);
         BSTAMP(3)
-        if (!(P.abl & 2)) store_half(0);                    // previous item's dx image, first half
+        store_half(0);                                      // previous item's dx image, first half
         BSTAMP(1)
         gb_barrier();                                       // dxa written, x tile staged
         BSTAMP(0)
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
           }
         }
         BSTAMP(4)
-        if (!(P.abl & 2)) store_half(2);
+        store_half(2);
         store_done();
         BSTAMP(1)
         spar = item_par;
