@@ -51,7 +51,9 @@ struct GcnFwdParams {
   int a_lds;             // the adjacency fits the work buffers: setup reads it from an LDS copy
   unsigned long long* dbg;  // diagnostic: per-phase cycle sums of workgroup 0 (ISTGCN_GCN_DBG)
   int abl;               // diagnostic ablation mask (ISTGCN_GCN_ABL; results are then wrong): 1 no aggregation, 2 no contraction,
-                         // 4 no image store, 8 no input loads / commit, 256 return at once (launch cost), 512 return after the setup
+                         // 256 return at once (launch cost), 512 return after the setup.  (The switches around the memory
+                         // waves' loads and stores are gone: a uniform branch around memory operations inside the loop makes
+                         // the compiler's wait counts path-dependent even when it is never taken.)
   int off_csr_v, off_csr_a, off_stat, off_rows, off_afrag, off_bterm, off_xs0, off_xs1, off_xa, off_o;  // LDS byte offsets
 };
 
@@ -670,34 +672,32 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
     //      The memory counter retires in order, so the wait in `commit` also covers the image stores of the PREVIOUS item
     //      (one whole item old by then) but never the stores of this one or the youngest prefetch. ----
     u32x4 RA[UL], RB[UL];
-    const bool ld = !(P.abl & 8);
     Cur c_it = cur_first();                                 // item it
     Cur c_cm = c_it;                                        // item it+1 (next commit)
     Cur c_is = c_it;                                        // item it+3 (next issue)
-    if (ld) {
-      issue(c_is, RA); cur_next(c_is);
-      issue(c_is, RB); cur_next(c_is);
-      __builtin_amdgcn_sched_barrier(0);
-      commit(c_cm, RA, xsbuf(0));
-      issue(c_is, RA); cur_next(c_is);
-    }
+    issue(c_is, RA); cur_next(c_is);
+    issue(c_is, RB); cur_next(c_is);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(c_cm, RA, xsbuf(0));
+    issue(c_is, RA); cur_next(c_is);
     cur_next(c_cm);
     lds_barrier();                                          // B1(0)
     tlast = __builtin_amdgcn_s_memtime();
     bool pending = false;
     int pend_n = 0, pend_tq = 0;
     auto iteration = [&](int it, u32x4 (&Rs)[UL]) __attribute__((always_inline)) {   // Rs: holds item it+1, refilled with it+3
-      if (ld && it + 1 < total_items) commit(c_cm, Rs, xsbuf((it + 1) & 1));
+      if (it + 1 < total_items) commit(c_cm, Rs, xsbuf((it + 1) & 1));
       __builtin_amdgcn_sched_barrier(0);
       STAMP(0)
-      if (pending) { if (!(P.abl & 4)) store_image(pend_n, pend_tq); pending = false; }
+      if (pending) { store_image(pend_n, pend_tq); pending = false; }
       __builtin_amdgcn_sched_barrier(0);
       STAMP(1)
       aggregate(xsbuf(it & 1), cur_nf(c_it), 4 + wave);
       STAMP(2)
       lds_barrier();                                        // B2
       STAMP(3)
-      if (ld) issue(c_is, Rs);
+      issue(c_is, Rs);                                      // (no run-time switch around the loads: a branch here would make the
+                                                            //  compiler's wait counts path-dependent, i.e. conservative)
       __builtin_amdgcn_sched_barrier(0);
       if (c_it.ch == nch - 1) { pending = true; pend_n = c_it.n; pend_tq = c_it.tq; }
       cur_next(c_it); cur_next(c_cm); cur_next(c_is);
