@@ -30,6 +30,16 @@ extern "C" {
 int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp, int* MTtot,
                         int* EPL);
 
+/* Register-chained layout (round 3, csrc/gcn_rc.hip): for 16-bit storage, Cin in {64,128,256}, Cout % 64 == 0, K <= 4 (and
+ * K*Cin*128 bytes <= 100 KB of LDS) the packed weights carry a SECOND section behind the one above, at element offset
+ * istgcn_gcn_rc_offset (-1: none; istgcn_gcn_rc_layout: 1 / 0):
+ *   element (((jt*K + k)*(Cin/16) + s)*64 + 32*h + c)*8 + e  holds  Wr[32*jt + c][k][16*s + 8*h + e]
+ * = the B operand fragments of H_k = x W_k^T (MFMA 32x32x16, channels in natural k order).  istgcn_gcn_fwd picks the
+ * register-chained kernel at launch when also V <= 32 and not (stats and addend) -- same arithmetic as
+ * net/utils/tgcn.py:79-86, GEMM first (the 1x1 Conv2d :79), then the einsum :86 on the accumulator tile in registers. */
+int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);
+long long istgcn_gcn_rc_offset(int Cin, int Cout, int K, int dtype);
+
 /* Graph-convolution unit  y[n,t*os,w,c] (+)= sum_k sum_v sum_i Wr[c][k][i] * A[k][v][w] * x[n,t*is,v,i]
  *                                            + bterm[w][c]           for t in [0, Tlog)
  * = ConvTemporalGraphical.forward  net/utils/tgcn.py:76-89  (1x1 Conv2d :79 then einsum :86), and with the

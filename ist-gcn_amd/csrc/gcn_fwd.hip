@@ -854,6 +854,19 @@ extern "C" int istgcn_gcn_fwd_v1(const void* x, const float* A, const void* Wp, 
                                  int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
                                  int in_t_stride, int out_t_stride, int nnz_cap, int dtype, int grid_cap, void* stream);
 extern "C" int istgcn_gcn_v1_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp, int* MTtot, int* EPL);
+// Register-chained kernel (gcn_rc.hip): 16-bit storage, 64/128/256 input channels, output channels a multiple of 64,
+// K <= 4, V <= 32.  Its weight layout is a second section of the packed buffer (istgcn_gcn_rc_offset), so the choice can
+// depend on launch-time arguments (V, stats + addend together) that the packer does not see.  ISTGCN_GCN_RC=0 disables it.
+extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);
+extern "C" long long istgcn_gcn_rc_offset(int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_gcn_fwd_rc(const void* x, const float* A, const void* Wq, const float* bterm, const void* addend,
+                                 void* y, double* stats, int stats_rep, int NM, int Tin, int Tout, int Tlog, int V,
+                                 int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int dtype, int grid_cap,
+                                 void* stream);
+static bool gcn_use_rc() {
+  const char* e = getenv("ISTGCN_GCN_RC");        // read per call: tools/gcn_exp.py A/B-times the two kernels in one process
+  return !e || atoi(e) != 0;
+}
 static bool gcn_use_v1(int dtype) {
   static const int forced = [] { const char* e = getenv("ISTGCN_GCN_V1"); return e ? atoi(e) : -1; }();
   if (forced == 0 || forced == 1) return forced == 1;
@@ -871,6 +884,12 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   if (Tlog > 0 && ((Tlog - 1) * in_t_stride >= Tin || (Tlog - 1) * out_t_stride >= Tout)) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;
   if (NM == 0 || Tlog == 0) return ISTGCN_OK;
+  if (gcn_use_rc() && V <= 32 && !(stats && addend) && istgcn_gcn_rc_layout(Cin, Cout, K, dtype)) {
+    const long long off = istgcn_gcn_rc_offset(Cin, Cout, K, dtype);
+    if (off >= 0)
+      return istgcn_gcn_fwd_rc(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 2, bterm, addend, y, stats, stats_rep, NM, Tin,
+                               Tout, Tlog, V, Cin, Cout, K, in_t_stride, out_t_stride, dtype, grid_cap, stream);
+  }
   if (gcn_use_v1(dtype))
     return istgcn_gcn_fwd_v1(x, A, Wp, bterm, addend, y, stats, stats_rep, status, NM, Tin, Tout, Tlog, V, Cin, Cout, K, in_t_stride,
                              out_t_stride, nnz_cap, dtype, grid_cap, stream);

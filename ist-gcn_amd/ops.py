@@ -117,7 +117,13 @@ def pack_gcn_weight_ref(wr, dtype):
     w = F.pad(w, (0, kkp - K * cce, 0, mttot * 32 - cout))
     nkg = kkp // (2 * epl)
     w = w.reshape(nch, mttot, 32, nkg, 2, epl).permute(0, 1, 3, 4, 2, 5)
-    return w.to(dtype).contiguous()
+    out = w.to(dtype).contiguous()
+    if _lib.load().istgcn_gcn_rc_layout(cin, cout, K, _DT[dtype]):
+        out = out.reshape(-1)
+        # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][8] = Wr[32 jt + c][k][16 s + 8 h + e]
+        q = wr.reshape(cout // 32, 32, K, cin // 16, 2, 8).permute(0, 2, 3, 4, 1, 5)
+        out = torch.cat([out, q.to(dtype).contiguous().reshape(-1)])
+    return out
 
 
 CHECK_NNZ = False        # debug / test switch: verify (with a host sync) that a reduced nnz_cap really covers nnz(A)

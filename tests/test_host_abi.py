@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), n
 
 
-def test_geometry_and_packing_agree():
+def test_geometry_and_packing_agree(lib):
     from istgcn_amd import ops
     for dt, epl in ((torch.float32, 4), (torch.bfloat16, 8)):
         for cin, cout, K in ((3, 64, 3), (64, 64, 3), (64, 128, 3), (256, 256, 3), (40, 24, 2), (64, 64, 4)):
@@ -47,7 +47,16 @@ def test_geometry_and_packing_agree():
             assert e == epl and cce % epl == 0 and nch * cce >= cin and kkp % (2 * epl) == 0 and kkp >= K * cce
             wr = torch.arange(cout * K * cin, dtype=torch.float32).view(cout, K, cin) % 251
             wp = ops.pack_gcn_weight(wr, dt)
-            assert wp.shape == (nch, mttot, kkp // (2 * epl), 2, 32, epl)
+            n_old = nch * mttot * kkp * 32
+            rc = lib.istgcn_gcn_rc_layout(cin, cout, K, ops._DT[dt])
+            assert wp.numel() == n_old + (K * cout * cin if rc else 0)
+            assert lib.istgcn_gcn_rc_offset(cin, cout, K, ops._DT[dt]) == (n_old if rc else -1)
+            if rc:
+                # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][e] = Wr[32 jt + c][k][16 s + 8 h + e]
+                q = wp.reshape(-1)[n_old:].view(cout // 32, K, cin // 16, 2, 32, 8)
+                for (c, k, i) in ((0, 0, 0), (cout - 1, K - 1, cin - 1), (cout // 2, K // 2, cin // 3)):
+                    assert float(q[c // 32, k, i // 16, (i % 16) // 8, c % 32, i % 8]) == float(wr[c, k, i].to(dt))
+            wp = wp.reshape(-1)[:n_old].view(nch, mttot, kkp // (2 * epl), 2, 32, epl)
             # spot-check the documented index map of include/istgcn.h
             for (c, k, i) in ((0, 0, 0), (cout - 1, K - 1, cin - 1), (cout // 2, K // 2, cin // 3)):
                 ch, il = divmod(i, cce)
