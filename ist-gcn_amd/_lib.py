@@ -106,7 +106,7 @@ def load():
         _lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise RuntimeError('cannot load %s: %s' % (LIB_PATH, e))
-    for name in ('istgcn_pack_gcn_elems', 'istgcn_pack_tconv_elems', 'istgcn_pack_gcn_bwd_elems', 'istgcn_gcn_rc_offset'):
+    for name in ('istgcn_pack_gcn_elems', 'istgcn_pack_tconv_elems', 'istgcn_pack_gcn_bwd_elems', 'istgcn_gcn_rc_offset', 'istgcn_gcn_bwd_rc_offset'):
         getattr(_lib, name).restype = ctypes.c_longlong          # element counts; every other entry returns int
     return _lib
 

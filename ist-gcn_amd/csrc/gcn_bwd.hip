@@ -1031,6 +1031,14 @@ extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int*
   return ISTGCN_OK;
 }
 
+// Register-chained kernel (gcn_rc_bwd.hip): 16-bit storage, 64/128/256 output channels, input channels a multiple of
+// 64, V <= 32; its weights are a second section of Wb.  ISTGCN_GCN_RC=0 disables it.
+extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
+extern "C" long long istgcn_gcn_bwd_rc_offset(int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_gcn_bwd_data_rc(const void* dy, const void* x, const float* A, const float* pattern, const void* Wq,
+                                      const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
+                                      int K, int dtype, int grid_cap, void* stream);
+
 extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
                                    const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
                                    int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
@@ -1040,6 +1048,15 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   if (nnz_cap < 1 || nnz_cap > K * V * V || (dA && nnz_cap > 16 * NTHREADS)) return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
+  {
+    const char* e = getenv("ISTGCN_GCN_RC");
+    if ((!e || atoi(e) != 0) && V <= 32 && !(dA && Cout > 128 && !getenv("ISTGCN_RC_SPLIT")) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype)) {
+      const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
+      if (off >= 0)
+        return istgcn_gcn_bwd_data_rc(dy, x, A, pattern, reinterpret_cast<const char*>(Wb) + (size_t)off * 2, addend, dx, dA, NM, T, V,
+                                      Cin, Cout, K, dtype, grid_cap, stream);
+    }
+  }
   GbdParams P{};
   P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;

@@ -18,6 +18,7 @@ extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const 
 extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* nchi, int* CCc, int* nchc,
                                        int* KKp, int* EPL);
 extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
 
 namespace {
 
@@ -105,6 +106,7 @@ struct PackGcnBwd {
   const float* src; void* dst;
   long long s_k, s_c, s_i;     // element strides of W3[k][c][i]
   int Cin, Cout, K, CCi, nchi, CCc, nchc, NKGc, MTK;
+  int rc;                      // the register-chained layout of gcn_rc_bwd.hip follows
 };
 
 template <typename T>
@@ -114,7 +116,24 @@ template <typename T>
 __device__ static inline void pack_gcn_bwd_body(const PackGcnBwd& P, int idx) {
   constexpr int EPL = Elem<T>::EPL;
   const int total = P.nchi * P.nchc * P.NKGc * P.MTK * 2 * 32;
-  if (idx >= total) return;
+  if (idx >= total) {
+    // register-chained section [it][k][s][lane][8]: lane (c = lane & 31, h = lane >> 5) of fragment (it, k, s) holds
+    // W3[k][16 s + 8 h + e][32 it + p(c)], p = c with bits 2 and 3 swapped (see gcn_rc_bwd.hip)
+    if (!P.rc) return;
+    const int r = idx - total, SO = P.Cout / 16;
+    if (r >= P.K * (P.Cin / 32) * SO * 64) return;
+    const int lane = r & 63;
+    int f = r >> 6;
+    const int s = f % SO; f /= SO;
+    const int k = f % P.K; const int it = f / P.K;
+    const int cl = lane & 31;
+    const int i = 32 * it + ((cl & ~12) | ((cl & 4) << 1) | ((cl & 8) >> 1)), c0 = 16 * s + 8 * (lane >> 5);
+    typename Elem<T>::frag v;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f(e < 8 ? P.src[k * P.s_k + (c0 + e) * P.s_c + i * P.s_i] : 0.f);
+    *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
+    return;
+  }
   int t = idx;
   const int r = t % 32; t /= 32;
   const int h = t % 2; t /= 2;
@@ -198,9 +217,10 @@ extern "C" int istgcn_pack_job_gcn_bwd(void* rec, const float* src, long long s_
   if (istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
   PackJob J{};
   J.kind = 2;
-  J.u.b = PackGcnBwd{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32};
+  const int rc = istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype);
+  J.u.b = PackGcnBwd{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32, rc};
   *reinterpret_cast<PackJob*>(rec) = J;
-  return ceil_div(nchi * nchc * J.u.b.NKGc * J.u.b.MTK * 2 * 32, 256);
+  return ceil_div(nchi * nchc * J.u.b.NKGc * J.u.b.MTK * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0), 256);
 }
 
 extern "C" int istgcn_pack_batch(const void* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, int dtype,
@@ -274,6 +294,14 @@ extern "C" int istgcn_pack_tconv(const float* src, long long s_t, long long s_o,
 extern "C" long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype) {
   int cci, nchi, ccc, nchc, kkp, epl;
   if (Cin < 1 || Cout < 1 || istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
+  return (long long)nchi * nchc * ccc * kkp + (istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) ? (long long)K * Cout * Cin : 0);
+}
+
+// Element offset of the register-chained section inside the packed weights of istgcn_gcn_bwd_data, or -1 if there is none.
+extern "C" long long istgcn_gcn_bwd_rc_offset(int Cin, int Cout, int K, int dtype) {
+  int cci, nchi, ccc, nchc, kkp, epl;
+  if (Cin < 1 || Cout < 1 || !istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype)) return -1;
+  if (istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
   return (long long)nchi * nchc * ccc * kkp;
 }
 
@@ -282,8 +310,9 @@ extern "C" int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_
   if (!src || !dst || Cin < 1 || Cout < 1) return ISTGCN_EINVAL;
   int cci, nchi, ccc, nchc, kkp, epl;
   if (int rc = istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return rc;
-  PackGcnBwd P{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32};
-  const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32;
+  const int rc = istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype);
+  PackGcnBwd P{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32, rc};
+  const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0);
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_bwd_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);

@@ -1748,6 +1748,23 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
 }
 
 // Graph-conv weight gradient: same kernel, the K "taps" being the K adjacency partitions (aggregated images of x).
+// The partial-sum reduce as its own entry for the register-chained graph-conv weight gradient (gcn_rc_wgrad.hip):
+// d0[e] += sum_s ws[s*slice + e] for e < n0, d1[e - n0] likewise for the n1 entries behind.
+extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1,
+                                   void* stream) {
+  int ny = nsl / 16;
+  ny = ny < 1 ? 1 : (ny > 16 ? 16 : ny);
+  dim3 rgrid(ceil_div(n0 + (d1 ? n1 : 0), 1024), ny);
+  ISTGCN_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), 0, (hipStream_t)stream, ws, slice, nsl, d0, n0, d1, d1 ? n1 : 0);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_gcn_wgrad_rc_ok(int V, int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_gcn_wgrad_rc(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,
+                                   int Cin, int Cout, int K, int dtype, int grid_cap, float* ws, long long ws_floats,
+                                   void* stream);
+
 extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,
                                 int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, float* ws,
                                 long long ws_floats, void* stream) {
@@ -1756,6 +1773,11 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
   if (nnz_cap < 1 || nnz_cap > K * V * V) return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
+  {
+    const char* e = getenv("ISTGCN_GCN_RC");        // 0: the round-2 kernels (A/B timing, tools/gcn_exp.py)
+    if ((!e || atoi(e) != 0) && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
+      return istgcn_gcn_wgrad_rc(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, dtype, grid_cap, ws, ws_floats, stream);
+  }
   TwgParams P{};
   P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
   P.NM = NM; P.Tin = T; P.Tz = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = K; P.in_mul = 1;

@@ -361,7 +361,16 @@ def pack_gcn_wb_ref(w3, dtype):
     w = F.pad(w, (0, 0, 0, 0, 0, kkp - K * cci))
     nkg = ccc // (2 * epl)
     w = w.reshape(nchi, kkp // 32, 32, nchc, nkg, 2, epl).permute(0, 3, 4, 1, 5, 2, 6)
-    return w.to(dtype).contiguous()
+    out = w.to(dtype).contiguous()
+    if _lib.load().istgcn_gcn_bwd_rc_layout(cin, cout, K, _DT[dtype]):
+        # register-chained section (csrc/gcn_rc_bwd.hip): [it][k][s][h][c][8] = W3[k][16 s + 8 h + e][32 it + p(c)],
+        # p(c) = c with bits 2 and 3 swapped
+        cs = torch.arange(32)
+        pc = (cs & ~12) | ((cs & 4) << 1) | ((cs & 8) >> 1)
+        q = w3.reshape(K, cout // 16, 2, 8, cin // 32, 32)[..., pc]            # [k][s][h][e][it][c]
+        q = q.permute(4, 0, 1, 2, 5, 3)                                        # [it][k][s][h][c][e]
+        out = torch.cat([out.reshape(-1), q.to(dtype).contiguous().reshape(-1)])
+    return out
 
 
 def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None, wb=None):
