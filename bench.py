@@ -45,10 +45,21 @@ FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit G
           'istgcn_affine2': 'bn_bwd_apply'}
 
 
-PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_fwd_kernel',
-           'istgcn_gcn_bwd_data': 'gcn_bwd_ws_kernel', 'istgcn_gcn_wgrad': 'gwg_ws_kernel',
+PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
+           'istgcn_gcn_bwd_data': 'gcn_rc_bwd_kernel', 'istgcn_gcn_wgrad': 'gcn_rc_wgrad_kernel',
            'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
            'istgcn_affine2': 'affine2_kernel'}
+# BASELINE.json configs[i-1] -> (model, storage type, clips per GPU): the reference's own arithmetic per config (fp32 for
+# configs 1/3/4 -- SURVEY 8a; config 2 bf16, config 5 fp16); --dtype / --batch on the command line override.
+CONFIGS = {1: ('st_gcnold', 'f32', 2), 2: ('st_gcn_msgcn', 'bf16', 64), 3: ('st_gcn_mstcn_1x1', 'f32', 256),
+           4: ('st_gcn_multi3_fix_3A_mstcn', 'f32', 64), 5: ('st_gcn_mstcn_1x1_deep', 'f16', 128)}
+
+
+def pmc_file(model, dtype, batch):
+    """Counter summary of tools/profile_bench.sh for exactly this workload, or None: the newest round's file wins."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_%s_%s_b%d_pmc.json' % (model, dtype, batch))))
+    return hits[-1] if hits else None
 
 
 def cpu_baseline(model_tag, T, seconds_budget=25.0):
@@ -88,8 +99,24 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '4')
-    proc = subprocess.run(cmd, env=env)
-    return proc.returncode
+    # a rank that dies (or hangs in a collective) must not leave the launcher waiting forever: bounded run, own process
+    # group so that the whole tree can be ended, non-zero exit either way
+    limit = float(os.environ.get('ISTGCN_BENCH_TIMEOUT', '1500'))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        sys.stderr.write('bench.py: the %d-rank run exceeded %.0f s; ending its process group\n' % (n, limit))
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+            proc.wait(timeout=20)
+        except Exception:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except Exception:
+                pass
+        return 124
 
 
 def main():
@@ -97,9 +124,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('ISTGCN_BENCH_DTYPE', 'bf16'), choices=['bf16', 'f16', 'f32'])
-    ap.add_argument('--model', default='st_gcn_msgcn', choices=sorted(MODELS))
-    ap.add_argument('--batch', type=int, default=64, help='clips per GPU')
+    ap.add_argument('--config', type=int, default=None, choices=sorted(CONFIGS),
+                    help='BASELINE.json configs[i-1]: model, storage type and clips per GPU of that configuration (default: 2)')
+    ap.add_argument('--dtype', default=os.environ.get('ISTGCN_BENCH_DTYPE'), choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--model', default=None, choices=sorted(MODELS))
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
@@ -111,6 +140,12 @@ def main():
     ap.add_argument('--loss-scale', type=float, default=None,
                     help='static loss scale of the backward pass (default: 65536 for f16 storage, 1 otherwise)')
     args = ap.parse_args()
+    cm, cd, cb = CONFIGS[args.config or 2]
+    args.model = args.model or cm
+    if args.config is None and args.model != cm:
+        cd, cb = ('f16', 128) if args.model.endswith('deep') else ('bf16', 64)
+    args.dtype = args.dtype or cd
+    args.batch = args.batch or cb
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
@@ -244,13 +279,13 @@ def main():
     # prescribes; summary committed under profiles/) -- only for the configuration they were collected on
     roof['traffic'] = None
     roof['algorithmic_bytes_per_launch'] = round(nbytes / n)
-    pmc_file = os.path.join(ROOT, 'profiles', 'r02_final_bf16_pmc.json')
-    if dt == torch.bfloat16 and args.model == 'st_gcn_msgcn' and B == 64 and os.path.exists(pmc_file):
-        pmc = json.load(open(pmc_file))['kernels'].get(PMC_KEY.get(dom, ''))
+    pf = pmc_file(args.model, args.dtype, B)
+    if pf and T == (600 if args.model.endswith('deep') else 300):
+        pmc = json.load(open(pf))['kernels'].get(PMC_KEY.get(dom, ''))
         if pmc:
             roof['traffic'] = pmc.get('hbm_bytes_avg')
             roof['mfma_util'] = pmc.get('mfma_util')
-            roof['pmc_source'] = 'profiles/r02_final_bf16_pmc.json'
+            roof['pmc_source'] = os.path.relpath(pf, ROOT)
     roof['kernel'] = FAMILY.get(dom, dom)
     roof['launches'] = n
     roof['avg_launch_ms'] = round(secs / n * 1e3, 4)

@@ -6,15 +6,16 @@
                            over the 32 shader engines, each with 32 SIMDs, the MFMA counter over all 1024 SIMDs."""
 import collections, csv, glob, json, os, shutil, sys
 O, tag = sys.argv[1], sys.argv[2]
+BENCH_ARGS = ' '.join(sys.argv[3:])
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 
 
 def fam(name):
     n = name.replace('(anonymous namespace)::', '')
-    for key in ('twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
+    for key in ('gcn_rc_fwd_kernel', 'gcn_rc_bwd_kernel', 'gcn_rc_wgrad_kernel', 'twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
                 'block_out_bwd_kernel', 'affine2_kernel', 'bn_finalize_kernel', 'bn_bwd_coef_kernel', 'fold_fwd_kernel', 'fold_bwd_kernel',
-                'sgd_step_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
+                'sgd_step_kernel', 'pool_fwd_kernel', 'pool_bwd_kernel', 'tcn_fold_fwd_kernel', 'tcn_fold_bwd_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
         if key in n:
             return key if key != 'pack_' else 'pack kernels'
     return 'other (framework)'
@@ -38,7 +39,7 @@ fetch, nf = counters('fetch')
 write, nw = counters('write')
 sq, ns = counters('sq')
 res = {'command': 'rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} -- python3 bench.py --steps 4 --warmup 2 '
-                  '(bf16 default workload, four separate passes)',
+                  '--no-cpu-baseline %s (four separate passes)' % BENCH_ARGS,
        'units': 'FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; hbm_bytes = 2*FETCH*1024 + WRITE*1024 per launch',
        'kernels': {}}
 for k in sorted(set(fetch) | set(write) | set(sq)):
