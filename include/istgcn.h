@@ -269,9 +269,11 @@ int istgcn_input_bwd(const float* raw, const int* shift, const double* move, con
  *   g' = grad_scale*g + weight_decay*p;  m = momentum*m + g';  p -= lr*(nesterov ? g' + momentum*m : m)
  * params / grads / momentum_buf: n floats each, 16-byte aligned (views of the host's three flat buffers; grads is the
  * buffer the data-parallel all-reduce ran on).  grad_scale folds the 1/world of a SUM all-reduce and the 1/loss_scale
- * of float16 training into the update.  momentum_buf starts at zero (first step: m = g', as torch initialises it). */
+ * of float16 training into the update.  momentum_buf starts at zero (first step: m = g', as torch initialises it).
+ * found_inf (device int or NULL): set to 1 if any gradient element is inf / NaN; such elements leave their parameter
+ * and momentum untouched (torch.optim.SGD would write the NaN into both for good). */
 int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
-                    float weight_decay, int nesterov, float grad_scale, void* stream);
+                    float weight_decay, int nesterov, float grad_scale, int* found_inf, void* stream);
 
 /* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);

@@ -8,6 +8,10 @@
 //   m  = momentum * m + g'                          (m starts at zero: the first step gives m = g', as torch does)
 //   p -= lr * (nesterov ? g' + momentum * m : m)
 //
+// Non-finite gradients (an overflowed float16 activation gradient under a static loss scale, which an all-reduce then
+// spreads to every rank) are never applied: an element whose gradient is inf / NaN keeps its parameter and momentum and
+// raises *found_inf, which the host polls when it chooses to (harness.FlatSGD.check_overflow halves the loss scale).
+//
 // HBM-bound: 3 reads + 2 writes of 4 bytes per parameter (12.6 MB of parameters for config 2 -> ~63 MB per step).
 #include "common.hpp"
 
@@ -15,7 +19,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, long long n, float lr, float momentum,
-                                                       float wd, int nesterov, float gscale) {
+                                                       float wd, int nesterov, float gscale, int* __restrict__ found_inf) {
+  bool bad = false;
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -25,8 +30,12 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gg = gscale * gv[j] + wd * pv[j];
-      mv[j] = momentum * mv[j] + gg;
-      pv[j] -= lr * (nesterov ? gg + momentum * mv[j] : mv[j]);
+      const bool ok = __builtin_isfinite(gv[j]);
+      bad |= !ok;
+      const float mn = momentum * mv[j] + gg;
+      const float pn = pv[j] - lr * (nesterov ? gg + momentum * mn : mn);
+      mv[j] = ok ? mn : mv[j];
+      pv[j] = ok ? pn : pv[j];
     }
     reinterpret_cast<f32x4*>(p)[i] = pv;
     reinterpret_cast<f32x4*>(m)[i] = mv;
@@ -36,15 +45,19 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
   if (t < n) {
     const float gg = gscale * g[t] + wd * p[t];
     const float mm = momentum * m[t] + gg;
-    m[t] = mm;
-    p[t] -= lr * (nesterov ? gg + momentum * mm : mm);
+    if (__builtin_isfinite(g[t])) {
+      m[t] = mm;
+      p[t] -= lr * (nesterov ? gg + momentum * mm : mm);
+    } else bad = true;
   }
+  if (found_inf && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(found_inf, 1);
 }
 
 }  // namespace
 
 extern "C" int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr,
-                               float momentum, float weight_decay, int nesterov, float grad_scale, void* stream) {
+                               float momentum, float weight_decay, int nesterov, float grad_scale, int* found_inf,
+                               void* stream) {
   if (!params || !grads || !momentum_buf || n < 0) return ISTGCN_EINVAL;
   if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum_buf) & 15) return ISTGCN_EINVAL;   // 16-byte vectors
   if (n == 0) return ISTGCN_OK;
@@ -52,7 +65,7 @@ extern "C" int istgcn_sgd_step(float* params, const float* grads, float* momentu
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   ISTGCN_LAUNCH(sgd_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr,
-                momentum, weight_decay, nesterov, grad_scale);
+                momentum, weight_decay, nesterov, grad_scale, found_inf);
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
 }

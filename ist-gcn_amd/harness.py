@@ -33,6 +33,8 @@ class FlatSGD:
         self.sync = None
         self._update = update_fn
         self.P = self.G = self.M = None
+        self.found_inf = None              # int32[1] on the device: raised by a non-finite gradient (see check_overflow)
+        self._pending_M = None             # momentum loaded before the layout existed (load_state_dict on a fresh optimizer)
         self._live, self._gviews, self._late = [], [], {}
 
     def attach_sync(self, sync):
@@ -80,6 +82,7 @@ class FlatSGD:
                 p.data = v
         self._gviews = [view(self.G, o, p) for p, o in zip(live, offs)]
         self._live = live
+        self._pptrs = [p.data_ptr() for p in live]
         self._live_ids = {id(p) for p in live}
 
     @property
@@ -90,7 +93,18 @@ class FlatSGD:
     def step(self):
         if self.P is None:
             self._build()
+            if self._pending_M is not None:        # exact resume: the momentum goes in BEFORE the first update
+                if self._pending_M.numel() != self.M.numel():
+                    raise RuntimeError('FlatSGD.load_state_dict: the saved momentum does not match this model\'s live parameters')
+                self.M.copy_(self._pending_M)
+                self._pending_M = None
         src, dst = [], []
+        for p, pp in zip(self._live, self._pptrs):
+            if p.data_ptr() != pp:
+                # .half()/.float()/.to(device)/`p.data = ...` after the layout was fixed: the update would go to an orphaned
+                # flat buffer and the model would silently stop learning
+                raise RuntimeError('FlatSGD: a parameter no longer aliases the flat buffer (was the model moved or cast '
+                                   'after the first step?); create a new optimizer')
         for p, gv in zip(self._live, self._gviews):
             g = p.grad
             if g is None:
@@ -109,8 +123,12 @@ class FlatSGD:
         upd = self._update
         if upd is None:
             from . import ops
-            upd = ops.sgd_step
-        upd(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale)
+            if self.found_inf is None:
+                self.found_inf = torch.zeros(1, dtype=torch.int32, device=self.P.device)
+            ops.sgd_step(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale,
+                         found_inf=self.found_inf)
+        else:
+            upd(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale)
         for p in self.params:                                        # slow path: first gradient after the layout was fixed
             if p.grad is not None and id(p) not in self._live_ids:
                 g = p.grad.float() * scale
@@ -123,6 +141,17 @@ class FlatSGD:
                 self._late[id(p)] = buf
                 p.data.add_(g + grp['momentum'] * buf if grp['nesterov'] else buf, alpha=-grp['lr'])
 
+    def check_overflow(self, backoff=0.5):
+        """Host poll (one sync) of the non-finite flag the update kernel raises: True if any gradient element since the
+        last poll was inf / NaN (those elements were skipped, parameters and momentum stayed finite).  With a loss scale
+        in use (float16 storage) the scale is multiplied by `backoff`, as a dynamic loss scaler would."""
+        if self.found_inf is None or int(self.found_inf.item()) == 0:
+            return False
+        self.found_inf.zero_()
+        if self.loss_scale != 1.0:
+            self.loss_scale = max(1.0, self.loss_scale * backoff)
+        return True
+
     def state_dict(self):
         return {'momentum': None if self.M is None else self.M.clone(), 'param_groups': [
             {k: v for k, v in g.items() if k != 'params'} for g in self.param_groups], 'loss_scale': self.loss_scale}
@@ -133,8 +162,11 @@ class FlatSGD:
         self.loss_scale = sd.get('loss_scale', 1.0)
         if sd.get('momentum') is not None:
             if self.M is None:
-                raise RuntimeError('FlatSGD.load_state_dict: run one step first (the flat layout is fixed by it)')
-            self.M.copy_(sd['momentum'])
+                # the flat layout is fixed by the first step's gradients: keep the momentum and put it in place right after
+                # the layout is built, before that step's update (no throw-away step, the resume is exact)
+                self._pending_M = sd['momentum'].detach().clone()
+            else:
+                self.M.copy_(sd['momentum'])
 
 
 def make_optimizer(model, optimizer='SGD', base_lr=0.1, nesterov=True, weight_decay=1e-4, loss_scale=1.0):
@@ -231,6 +263,8 @@ class GraphedStep:
         with torch.cuda.stream(self.stream):
             self.graph.replay()
             self.opt.step()                                # (all-reduce of the flat gradient buffer,) one-launch update
+        from . import ops
+        ops.bump_weights_epoch()                           # the replay wrote BatchNorm running statistics (no Python ran)
         if cur != self.stream:
             cur.wait_stream(self.stream)
         return self.loss

@@ -157,12 +157,14 @@ class STGCNBlock(nn.Module):
     def infer(self, x, fold_fn, key_extra=(), mst=None, nnz_cap=None):
         """x NTVC -> block output, eval-mode semantics, nothing saved for a backward pass.  `fold_fn()` -> (A_eff, bterm)
         is only called when the cached plan is stale: the plan (folded + fragment-packed weights, Fn.build_infer_plan)
-        is keyed on the version counters of every tensor it was built from, so load_state_dict / an optimiser step /
-        `.to()` rebuild it and a steady-state eval pass launches only the block's 2-4 kernels."""
+        is keyed on the data pointers and version counters of every tensor it was built from AND on ops.weights_epoch(),
+        which every writer that bypasses the version counters bumps (the one-launch optimizer update, the running-
+        statistics update of a training forward, a hipGraph replay): load_state_dict / an optimiser step / `.to()` /
+        a replayed step rebuild it, and a steady-state eval pass launches only the block's 2-4 kernels."""
         tensors = [t for t in list(self.parameters()) + list(self.buffers()) if t is not None] + list(key_extra)
         if mst is not None:
             tensors.append(mst)
-        key = (x.dtype, x.device, nnz_cap) + tuple((t.data_ptr(), t._version) for t in tensors)
+        key = (x.dtype, x.device, nnz_cap, ops.weights_epoch()) + tuple((t.data_ptr(), t._version) for t in tensors)
         cache = self.__dict__.get('_infer_cache')
         if cache is None or cache[0] != key:
             A_eff, bterm = fold_fn()
@@ -426,7 +428,7 @@ class STGCNModel(nn.Module):
         """Every weight pack of the trunk in ONE launch per forward (they were ~46 launches per step): the plan is rebuilt
         when a parameter's storage moved (an optimizer re-pointing `.data` into its flat buffer, `.to()`), the launch is
         repeated every forward because the optimizer has updated the weights in between."""
-        ptrs = tuple(p.data_ptr() for p in self.parameters())
+        ptrs = tuple((p.data_ptr(), p.stride()) for p in self.parameters())
         key = (x.dtype, x.device, x.shape[2], ptrs)
         ent = self.__dict__.get('_pack_plan')
         if ent is None or ent[0] != key:

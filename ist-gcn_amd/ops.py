@@ -126,6 +126,21 @@ def pack_gcn_weight_ref(wr, dtype):
     return out
 
 
+# Weights epoch: the inference plans of net/_model.py (folded + fragment-packed weights, BatchNorm running statistics)
+# are cached; tensor version counters cannot see writers that go through raw pointers (istgcn_sgd_step, the running-
+# statistics update inside istgcn_bn_finalize) or that run no Python at all (hipGraph replays).  Every such writer bumps
+# this process-wide counter and the plan cache keys on it (over-invalidation only costs a rebuild).
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
+
+
 CHECK_NNZ = False        # debug / test switch: verify (with a host sync) that a reduced nnz_cap really covers nnz(A)
 
 
@@ -395,6 +410,11 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
         nnz_cap = K * V * V
     if pattern is not None:
         assert pattern.shape == (K, V, V) and pattern.dtype == torch.float32
+    if want_dA and V > 32 and nnz_cap > 4096:
+        # the round-2 kernel keeps one slot per pattern entry in LDS (16 per thread of a 256-thread workgroup); the
+        # register-chained kernel (V <= 32) has no such limit
+        raise RuntimeError('istgcn_gcn_bwd_data: the adjacency gradient of a graph with V = %d > 32 joints supports at most '
+                           '4096 pattern entries (got nnz_cap = %d): pass a sparser `pattern`' % (V, nnz_cap))
     dv = _check_dev(dy, x, A, pattern, wb, addend, dx, dA)
     _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(pattern), _ptr(wb), _ptr(addend), _ptr(dx),
           _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
@@ -474,6 +494,8 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
           ctypes.c_float(eps), int(bool(training)), _ptr(coef), C, _stream(gamma), dev=dv)
     if clear and stats is not None:
         _scratch_consumed(stats)
+    if training:
+        bump_weights_epoch()              # running_mean / running_var were written through raw pointers
     return coef
 
 
@@ -679,15 +701,17 @@ def tcn_fold_bwd(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, scale):
 # ----------------------------------------------------------------------------------------------
 # optimizer (optim.hip)
 # ----------------------------------------------------------------------------------------------
-def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0):
-    """istgcn_sgd_step over three flat fp32 buffers of equal length (in place on params / momentum_buf)."""
+def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0, found_inf=None):
+    """istgcn_sgd_step over three flat fp32 buffers of equal length (in place on params / momentum_buf).  found_inf:
+    int32[1] device tensor raised by a non-finite gradient (those elements are not applied) or None."""
     n = params.numel()
     assert grads.numel() == n and momentum_buf.numel() == n
     assert params.dtype == grads.dtype == momentum_buf.dtype == torch.float32
-    dv = _check_dev(params, grads, momentum_buf)
+    dv = _check_dev(params, grads, momentum_buf, found_inf)
     _call('istgcn_sgd_step', _ptr(params), _ptr(grads), _ptr(momentum_buf), ctypes.c_longlong(n), ctypes.c_float(lr),
           ctypes.c_float(momentum), ctypes.c_float(weight_decay), int(bool(nesterov)), ctypes.c_float(grad_scale),
-          _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)
+          _ptr(found_inf), _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)
+    bump_weights_epoch()                  # parameters written through raw pointers: cached inference plans are stale
 
 
 # ----------------------------------------------------------------------------------------------
@@ -747,9 +771,9 @@ def input_bwd(raw, dout, coef, stats, shift=None, move=None, T=None):
 class PackPlan:
     """A table of weight-pack jobs (graph-conv weights, temporal-conv taps forward and per data-gradient phase,
     graph-conv backward weights) that one launch executes: `add_*` registers a job and returns its persistent
-    destination tensor, `run()` launches (building / uploading the job table on first use).  The parameter views are
-    kept alive and their data pointers recorded: `stale()` tells when a parameter moved (optimizer re-pointing `.data`,
-    `.to()`), in which case the owner builds a new plan."""
+    destination tensor, `run()` launches (building / uploading the job table on first use).  The job table holds raw
+    pointers into the parameters: the OWNER decides when a plan is stale (net/_model.py keys its plan on every parameter's
+    data pointer and strides and builds a new one when a parameter moved -- optimizer re-pointing `.data`, `.to()`)."""
 
     def __init__(self, dtype, device):
         self.dtype, self.device = dtype, device
@@ -786,9 +810,6 @@ class PackPlan:
         dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
         self.jobs.append((2, w3, dst, None))
         return dst
-
-    def stale(self):
-        return self._table is not None and any(src.data_ptr() != ptr for (_, src, _, _), ptr in zip(self.jobs, self._ptrs))
 
     def _build(self):
         lib = _lib.load()

@@ -65,6 +65,23 @@ class _Conv(nn.Module):
             self.bn = nn.BatchNorm2d(cout)
 
 
+class RefMSTCN(nn.Module):
+    """net/utils/ms_tcn.py:5-52 (dead code upstream): BatchNorm -> ReLU -> conv_b -> the SAME BatchNorm ->
+    Dropout; conv_a / conv_c are declared and never used, `mstcn_importance` is ignored (ms_tcn.py:44-49)."""
+
+    def __init__(self, out_channels, kernel_size_a, kernel_size_b, kernel_size_c, dropout, stride=1):
+        super().__init__()
+        c = out_channels
+        self.batchnorm2d = nn.BatchNorm2d(c)
+        for name, k in (('conv_a', kernel_size_a), ('conv_b', kernel_size_b), ('conv_c', kernel_size_c)):
+            setattr(self, name, nn.Conv2d(c, c, (k, 1), (stride, 1), ((k - 1) // 2, 0)))
+        self.p = dropout
+
+    def forward(self, x, mstcn_importance=None):
+        x = self.conv_b(F.relu(self.batchnorm2d(x)))             # ms_tcn.py:42-45
+        return F.dropout(self.batchnorm2d(x), self.p, self.training)   # :50-51
+
+
 class RefGCN(nn.Module):
     def __init__(self, unit, cin, cout, K):
         super().__init__()

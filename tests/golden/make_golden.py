@@ -351,8 +351,32 @@ def g7_feeder_tools():
     save('feeder_g7.npz', **out)
 
 
+# ----------------------------------------------------------------------------- G8 MSTCN (dead upstream)
+def g8_mstcn():
+    """net/utils/ms_tcn.py:41-52: BatchNorm -> ReLU -> conv_b -> the SAME BatchNorm -> Dropout.  Train mode (dropout 0:
+    batch statistics twice, running statistics updated twice) and eval mode, two shapes (stride 1 and 2)."""
+    from net.utils.ms_tcn import MSTCN
+    out = {}
+    for ci, (N, C, T, V, stride) in enumerate([(2, 16, 12, 25, 1), (3, 32, 15, 18, 2)]):
+        m = MSTCN(C, 3, 9, 15, 0.0, stride=stride)
+        sd = det_fill_(m.state_dict())
+        m.load_state_dict(sd)
+        x = det_tensor('g8.x.%d' % ci, (N, C, T, V))
+        imp = torch.ones(3)
+        m.eval()
+        with torch.no_grad():
+            out['c%d.eval' % ci] = m(x.clone(), imp)
+        m.train()
+        with torch.no_grad():
+            out['c%d.train' % ci] = m(x.clone(), imp)
+        out['c%d.running_mean' % ci] = m.batchnorm2d.running_mean
+        out['c%d.running_var' % ci] = m.batchnorm2d.running_var
+        out['c%d.shape' % ci] = np.asarray([N, C, T, V, stride])
+    save('mstcn_g8.npz', **out)
+
+
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7']
+    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7', 'g8']
     if 'g1' in what:
         g1_graph()
     if 'g2' in what:
@@ -365,3 +389,5 @@ if __name__ == '__main__':
         g6_extract_feature()
     if 'g7' in what:
         g7_feeder_tools()
+    if 'g8' in what:
+        g8_mstcn()

@@ -108,10 +108,13 @@ def test_blocks_golden(golden, kind, dt):
     # 16-bit storage: relative L2 (ReLU-mask flips on 576-position fixtures); float16 has 3 more mantissa bits than bfloat16
     # (gradients: one ReLU-mask flip on these 576-position fixtures moves a BatchNorm-bias gradient entry by O(1) whatever
     #  the 16-bit format -- measured 0.11 in float16 -- so both formats share the gradient gate; outputs are 4x tighter)
-    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (2e-2, 0.15), torch.float16: (5e-3, 0.15)}[dt]
+    # measured round 3 (max over all fixtures, gpurun_out/err16_measured.txt): bf16 outputs .0062, gradients .149; fp16 outputs
+    # 8.3e-4, gradients .058 -> gates at <= 2x
+    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (1.25e-2, 0.15), torch.float16: (1.7e-3, 0.12)}[dt]
     if dt != torch.float32 and kind == 'st_gcn_mstcn_1x1':
         # the fixture's bottleneck is int(sqrt(16)) = 4 channels wide: 16-bit storage of a 4-channel tensor is mostly noise
-        tol_g = 0.4 if dt == torch.bfloat16 else 0.2
+        # (measured .259 / .045)
+        tol_g = 0.4 if dt == torch.bfloat16 else 0.09
 
     for b in bases:
         t = lambda k: torch.from_numpy(g[b + k])  # noqa: E731
@@ -236,18 +239,21 @@ def test_model_bf16_storage_close_to_fp32(golden, tag):
         loss = F.cross_entropy(logits, lab)
         loss.backward()
         grads[dt] = ([None if p.grad is None else p.grad.double().flatten() for p in m.parameters()], logits.detach(), float(loss))
+    from gpu_util import gate16
     g32, g16 = grads[torch.float32], grads[torch.bfloat16]
-    assert l2rel(g16[1], g['train_logits']) < 3e-2
+    gl, gg, gc = BF16_MODEL_GATE.get(tag, (3e-2, 0.25, 0.2))
+    assert gate16('model_bf16 %s train logits rel-L2 vs reference' % tag, l2rel(g16[1], g['train_logits']), gl)
     assert abs(g16[2] - float(g['train_loss'])) < 5e-2
     a = torch.cat([t for t in g32[0] if t is not None])
     b = torch.cat([t for t in g16[0] if t is not None])
     assert torch.isfinite(b).all()
-    assert float((a - b).norm() / a.norm()) < 0.25
+    assert gate16('model_bf16 %s whole-gradient rel-L2 vs fp32 HIP' % tag, float((a - b).norm() / a.norm()), gg)
     top = max(float(t.norm()) for t in g32[0] if t is not None)
+    worst = 0.0
     for ta, tb in zip(g32[0], g16[0]):
         if ta is not None and float(ta.norm()) > 1e-2 * top:
-            cos = float((ta * tb).sum() / (ta.norm() * tb.norm()))
-            assert cos > 0.8, cos
+            worst = max(worst, 1.0 - float((ta * tb).sum() / (ta.norm() * tb.norm())))
+    assert gate16('model_bf16 %s worst (1 - cosine) over sizeable parameter gradients' % tag, worst, gc)
 
 
 def test_extract_feature_shapes():
@@ -395,6 +401,53 @@ def test_flat_sgd_kernel_matches_torch_sgd():
         assert rel_err(c, dd) < 1e-6
 
 
+def test_flat_sgd_skips_non_finite_gradients_and_resumes_exactly():
+    """(a) an inf / NaN gradient element (an overflowed float16 activation gradient) leaves its parameter and
+    momentum untouched and raises the flag check_overflow() polls, which backs the loss scale off; (b) load_state_dict on
+    a fresh optimizer puts the momentum in place before the first update: a resumed run continues bit for bit."""
+    from istgcn_amd import harness
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    init = [torch.randn(33, generator=g), torch.randn(4, 5, generator=g)]
+    grads = [[torch.randn(t.shape, generator=g) for t in init] for _ in range(4)]
+    pa = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    oa = harness.FlatSGD(pa, lr=0.1, loss_scale=1024.0)
+    for p, gr in zip(pa, grads[0]):
+        p.grad = (gr * 1024.0).to(d)
+    pa[0].grad[5] = float('inf')
+    pa[1].grad[2, 3] = float('nan')
+    oa.step()
+    assert torch.isfinite(oa.P).all() and torch.isfinite(oa.M).all()
+    assert float(pa[0][5]) == float(init[0][5]) and float(pa[1][2, 3]) == float(init[1][2, 3])     # skipped elements
+    assert float(pa[0][6]) != float(init[0][6])                                                       # the rest was applied
+    assert oa.check_overflow() and oa.loss_scale == 512.0 and not oa.check_overflow()
+    # exact resume: two steps, save, two more  ==  two steps, save | fresh optimizer + load, two more
+    def run(resume):
+        ps = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+        o = harness.FlatSGD(ps, lr=0.1)
+        for s in range(4):
+            if resume and s == 2:
+                sd = o.state_dict()
+                ps = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+                o = harness.FlatSGD(ps, lr=0.1)
+                o.load_state_dict(sd)
+            for p, gr in zip(ps, grads[s]):
+                p.grad = gr.clone().to(d)
+            o.step()
+        return [p.detach().clone() for p in ps]
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
+    # a parameter re-pointed after the layout was fixed is an error, not a silent no-op
+    pb = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+    ob = harness.FlatSGD(pb, lr=0.1)
+    for p, gr in zip(pb, grads[0]):
+        p.grad = gr.clone().to(d)
+    ob.step()
+    pb[0].data = pb[0].data.clone()
+    with pytest.raises(RuntimeError):
+        ob.step()
+
+
 def test_dropout_seed_reproducible_and_fresh_per_forward():
     """the dropout key comes from torch's CPU generator (reproducible under manual_seed, new on every
     forward, also on throw-away nn.DataParallel-style replicas), not from id(self) / a per-object call counter."""
@@ -513,13 +566,15 @@ def test_model_fp16_storage_close_to_fp32(golden, tag):
         sc = 1.0 / LS if dt == torch.float16 else 1.0
         grads[dt] = ([None if p.grad is None else p.grad.double().flatten() * sc for p in m.parameters()],
                      logits.detach(), float(loss))
+    from gpu_util import gate16
     g32, g16 = grads[torch.float32], grads[torch.float16]
-    assert l2rel(g16[1], g['train_logits']) < 5e-3
+    gl, gg = FP16_MODEL_GATE.get(tag, (5e-3, 0.08))
+    assert gate16('model_fp16 %s train logits rel-L2 vs reference' % tag, l2rel(g16[1], g['train_logits']), gl)
     assert abs(g16[2] - float(g['train_loss'])) < 1e-2
     a = torch.cat([t for t in g32[0] if t is not None])
     b = torch.cat([t for t in g16[0] if t is not None])
     assert torch.isfinite(b).all()
-    assert float((a - b).norm() / a.norm()) < 0.08
+    assert gate16('model_fp16 %s whole-gradient rel-L2 vs fp32 HIP' % tag, float((a - b).norm() / a.norm()), gg)
     # eval logits at the full clip shape (T=600 for the deep model)
     m, nc = _model(tag, torch.float16)
     m.eval()
@@ -529,14 +584,32 @@ def test_model_fp16_storage_close_to_fp32(golden, tag):
     assert l2rel(y, g['eval_logits']) < 5e-3
 
 
-@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-def test_full_batch_step_16bit_vs_fp32_hip(dt):
-    """BASELINE config 2 at its real size -- st_gcn_msgcn, 64 clips (NM = 128), T=300 -- one training step in 16-bit
-    storage against the SAME step of the fp32 HIP path (itself pinned to the reference by the G4 tests): the only test
-    that runs the whole model with every workgroup of every kernel resident, apart from bench.py."""
+# 16-bit whole-model gates per model: (logits rel-L2, whole-gradient rel-L2[, worst 1 - cosine]); measured values are
+# appended to gpurun_out/err16_measured.txt by every run, the gates sit at <= 2x those
+# measured round 3 (bf16: logits .0025/.0023/.0024, gradient .098/.172/.121, 1-cos .060/.088/.098; fp16: logits 4.0e-4/2.8e-4,
+# gradient .055/.036)
+BF16_MODEL_GATE = {'st_gcn_msgcn': (5e-3, 0.2, 0.125), 'st_gcn_multi3_fix_3A_mstcn': (5e-3, 0.25, 0.18),
+                   'st_gcn_mstcn_1x1': (5e-3, 0.25, 0.2)}
+FP16_MODEL_GATE = {'st_gcn_mstcn_1x1_deep': (8e-4, 0.08), 'st_gcn_msgcn': (6e-4, 0.072)}
+FULL_BATCH = [('st_gcn_msgcn', 64, 300, torch.bfloat16), ('st_gcn_msgcn', 64, 300, torch.float16),
+              ('st_gcn_multi3_fix_3A_mstcn', 64, 300, torch.bfloat16), ('st_gcn_mstcn_1x1', 256, 300, torch.bfloat16)]
+# measured (gpurun_out/err16_measured.txt, round 3): logits rel-L2 1.2e-3 / 1.5e-4 / 1.1e-3 / 1.2e-3, whole-gradient
+# rel-L2 .089 / .032 / .098 / .158 -> gates at <= 2x
+FULL_BATCH_GATE = {('st_gcn_msgcn', torch.bfloat16): (2.4e-3, 0.18), ('st_gcn_msgcn', torch.float16): (3.1e-4, 0.064),
+                   ('st_gcn_multi3_fix_3A_mstcn', torch.bfloat16): (2.2e-3, 0.2), ('st_gcn_mstcn_1x1', torch.bfloat16): (2.4e-3, 0.3)}
+
+
+@pytest.mark.parametrize('tag,batch,T,dt', FULL_BATCH, ids=['%s_b%d_%s' % (t, b, str(d_)[6:]) for t, b, _, d_ in FULL_BATCH])
+def test_full_batch_step_16bit_vs_fp32_hip(tag, batch, T, dt):
+    """BASELINE configs 2, 4 and 3 at their real sizes -- st_gcn_msgcn and st_gcn_multi3_fix_3A_mstcn with 64 clips (NM =
+    128), st_gcn_mstcn_1x1 on 18-joint skeletons with 256 clips (NM = 512), T = 300 -- one training step in 16-bit
+    storage against the SAME step of the fp32 HIP path (itself pinned to the reference by the G4 tests): the tests that
+    run whole models with every workgroup of every kernel resident, apart from bench.py."""
     from istgcn_amd import harness
-    gargs, nc = MODEL_CFG['st_gcn_msgcn']
-    mod = importlib.import_module('istgcn_amd.net.st_gcn_msgcn')
+    from gpu_util import gate16
+    gargs, nc = MODEL_CFG[tag]
+    Vj = 18 if gargs['layout'] == 'openpose' else 25
+    mod = importlib.import_module('istgcn_amd.net.' + tag)
     res = {}
     for d_ in (torch.float32, dt):
         torch.manual_seed(0)
@@ -544,8 +617,8 @@ def test_full_batch_step_16bit_vs_fp32_hip(dt):
         m.apply(harness.weights_init)
         m.to(dev()).train()
         gen = torch.Generator().manual_seed(11)
-        x = torch.randn(64, 3, 300, 25, 2, generator=gen).to(dev())
-        y = torch.randint(0, nc, (64,), generator=gen).to(dev())
+        x = torch.randn(batch, 3, T, Vj, 2, generator=gen).to(dev())
+        y = torch.randint(0, nc, (batch,), generator=gen).to(dev())
         ls = 65536.0 if d_ == torch.float16 else 1.0
         logits = m(x)
         loss = F.cross_entropy(logits, y)
@@ -555,13 +628,14 @@ def test_full_batch_step_16bit_vs_fp32_hip(dt):
         del m, x, logits, loss
         torch.cuda.empty_cache()
     (l32, loss32, g32), (l16, loss16, g16) = res[torch.float32], res[dt]
-    tol_l, tol_g = (3e-2, 0.25) if dt == torch.bfloat16 else (5e-3, 0.08)
-    assert float((l16 - l32).norm() / l32.norm()) < tol_l
+    tol_l, tol_g = FULL_BATCH_GATE[(tag, dt)]
+    name = 'full_batch_step %s b%d %s' % (tag, batch, str(dt)[6:])
+    assert gate16(name + ' logits rel-L2 vs fp32 HIP', float((l16 - l32).norm() / l32.norm()), tol_l)
     assert abs(loss16 - loss32) < 2e-2
     a = torch.cat([t for t in g32 if t is not None])
     b = torch.cat([t for t in g16 if t is not None])
     assert torch.isfinite(b).all()
-    assert float((a - b).norm() / a.norm()) < tol_g
+    assert gate16(name + ' whole-gradient rel-L2 vs fp32 HIP', float((a - b).norm() / a.norm()), tol_g)
 
 
 @pytest.mark.gpu

@@ -126,3 +126,132 @@ def test_weight_gradients_are_additive_over_batch_shards(ops, graph_A, NM, T, C,
     dxb, dAb = ops.gcn_bwd_data(dz[h:].contiguous(), A, W3, x=g[h:].contiguous(), want_dA=True, nnz_cap=cap)
     assert torch.equal(dx[:h], dxa) and torch.equal(dx[h:], dxb)
     assert ((dA - (dAa + dAb)).abs().max() / dA.abs().max()) < tol
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 3: the shapes BASELINE configs 3 / 4 / 5 add to config 2 -- 15-tap folded Inception-TCN (net/st_gcn_multi3_fix_3A_mstcn.py:
+# 160-180,212-215), stride-2 blocks (9 and 15 taps), V = 18 at NM = 512 (config 3, net/st_gcn_mstcn_1x1.py on Kinetics
+# skeletons), the sqrt(C) bottleneck trio of net/st_gcn_mstcn_1x1_deep.py:253-269 at NM = 256, T = 600 in float16
+# ------------------------------------------------------------------------------------------------------------------
+TCONV_CASES = [pytest.param(nm, t, c, k, s_, dt, id='nm%d_t%d_c%d_k%d_s%d_%s' % (nm, t, c, k, s_, str(dt)[6:]))
+               for (nm, t, c, k, s_) in ((128, 300, 64, 15, 1), (128, 150, 128, 15, 1), (128, 75, 256, 15, 1),
+                                         (128, 300, 128, 9, 2), (128, 300, 128, 15, 2), (128, 150, 256, 9, 2))
+               for dt in (torch.bfloat16, torch.float32)]
+
+
+@pytest.mark.parametrize('NM,T,C,k,stride,dt', TCONV_CASES)
+def test_tconv_15tap_and_stride2_full_size(ops, NM, T, C, k, stride, dt):
+    """forward: sequence independence (bit-exact batch slices) and epilogue BatchNorm sums == sums of the stored output;
+    data gradient (one launch per output phase): sequence independence; weight gradient: additive over batch halves."""
+    from istgcn_amd import functional as Fn
+    d = dev()
+    taps, in_mul = ops.conv_taps_fwd(k, stride)
+    Tz = (T - 1) // stride + 1
+    x = _randn(NM, T, V, C, seed=31, dt=dt)
+    Wc = _randn(C, C, k, 1, seed=32, dt=torch.float32, scale=(C * k) ** -0.5)
+    Wt = Wc.view(C, C, k).permute(2, 0, 1)
+    wp = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
+    bias = _randn(C, seed=33, dt=torch.float32, scale=0.1)
+    pre = torch.stack([0.5 + torch.rand(C, generator=torch.Generator().manual_seed(34)),
+                       0.3 * torch.randn(C, generator=torch.Generator().manual_seed(35))]).to(d)
+    st = ops.new_stats(C, d)
+    z = ops.tconv(x, wp, C, taps, bias=bias, pre=pre, pre_relu=True, stats=st, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+    torch.cuda.synchronize()
+    for lo, hi in ((0, 2), (63, 65), (NM - 1, NM)):
+        zs = ops.tconv(x[lo:hi].contiguous(), wp, C, taps, bias=bias, pre=pre, pre_relu=True, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+        assert torch.equal(zs, z[lo:hi]), 'sequence independence broken for [%d:%d)' % (lo, hi)
+    zf = z.double()
+    s = st.sum(0)
+    tol = 1e-6 if dt == torch.float32 else 1e-5
+    assert ((s[0] - zf.sum((0, 1, 2))).abs().max() / zf.abs().sum((0, 1, 2)).max()) < tol
+    assert ((s[1] - (zf * zf).sum((0, 1, 2))).abs().max() / (zf * zf).sum((0, 1, 2)).max()) < tol
+    # data gradient of the same convolution (autograd of the Conv2d): per output phase, slices independent
+    dz = _randn(NM, Tz, V, C, seed=36, dt=dt, scale=0.1)
+    dx = Fn._conv_bwd_data(dz, Wt, k, stride, T, C, V)
+    for lo, hi in ((0, 1), (NM - 2, NM)):
+        dxs = Fn._conv_bwd_data(dz[lo:hi].contiguous(), Wt, k, stride, T, C, V)
+        assert torch.equal(dxs, dx[lo:hi])
+    # weight gradient additive over batch halves (workspace / atomic flush with every workgroup resident)
+    h = NM // 2
+    dW, db = ops.tconv_wgrad(dz, x, taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    dWa, dba = ops.tconv_wgrad(dz[:h].contiguous(), x[:h].contiguous(), taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    dWb, dbb = ops.tconv_wgrad(dz[h:].contiguous(), x[h:].contiguous(), taps, in_mul=in_mul, pre=pre, pre_relu=True)
+    assert ((dW - (dWa + dWb)).abs().max() / dW.abs().max()) < 2e-5
+    assert ((db - (dba + dbb)).abs().max() / db.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_gcn_unit_config3_full_size(ops, dt):
+    """Config 3's graph-conv layers: openpose skeleton (V = 18), 256 clips x 2 persons -> NM = 512, T = 300, 64 channels:
+    forward slices + BatchNorm sums, data gradient slices + additive adjacency gradient, additive weight gradient."""
+    from istgcn_amd.net.utils.graph import Graph
+    d = dev()
+    A = torch.tensor(Graph('openpose', 'spatial').A, dtype=torch.float32, device=d)
+    V18, NM, T, C = 18, 512, 300, 64
+    cap = int((A != 0).sum())
+    x = _randn(NM, T, V18, C, seed=41, dt=dt)
+    dy = _randn(NM, T, V18, C, seed=42, dt=dt, scale=0.1)
+    W3 = _randn(K, C, C, seed=43, dt=torch.float32, scale=C ** -0.5)
+    wp = ops.pack_gcn_weight(W3.permute(1, 0, 2), dt)
+    st = ops.new_stats(C, d)
+    y = ops.gcn_forward(x, A, wp, C, stats=st, nnz_cap=cap)
+    for lo, hi in ((0, 1), (255, 258), (NM - 3, NM)):
+        assert torch.equal(ops.gcn_forward(x[lo:hi].contiguous(), A, wp, C, nnz_cap=cap), y[lo:hi])
+    yf, s = y.double(), st.sum(0)
+    tol = 1e-6 if dt == torch.float32 else 1e-5
+    assert ((s[0] - yf.sum((0, 1, 2))).abs().max() / yf.abs().sum((0, 1, 2)).max()) < tol
+    assert ((s[1] - (yf * yf).sum((0, 1, 2))).abs().max() / (yf * yf).sum((0, 1, 2)).max()) < tol
+    h = NM // 2
+    dx, dA = ops.gcn_bwd_data(dy, A, W3, x=x, want_dA=True, nnz_cap=cap)
+    dxa, dAa = ops.gcn_bwd_data(dy[:h].contiguous(), A, W3, x=x[:h].contiguous(), want_dA=True, nnz_cap=cap)
+    dxb, dAb = ops.gcn_bwd_data(dy[h:].contiguous(), A, W3, x=x[h:].contiguous(), want_dA=True, nnz_cap=cap)
+    assert torch.equal(dx[:h], dxa) and torch.equal(dx[h:], dxb)
+    assert ((dA - (dAa + dAb)).abs().max() / dA.abs().max()) < 2e-5
+    gW, S = ops.gcn_wgrad(dy, x, A, nnz_cap=cap)
+    gWa, Sa = ops.gcn_wgrad(dy[:h].contiguous(), x[:h].contiguous(), A, nnz_cap=cap)
+    gWb, Sb = ops.gcn_wgrad(dy[h:].contiguous(), x[h:].contiguous(), A, nnz_cap=cap)
+    assert ((gW - (gWa + gWb)).abs().max() / gW.abs().max()) < 2e-5
+    assert ((S - (Sa + Sb)).abs().max() / S.abs().max()) < 2e-5
+
+
+def test_bottleneck_trio_config5_full_size(ops):
+    """Config 5's temporal unit at its first-stage size (128 clips x 2 persons -> NM = 256, T = 600, float16): the 1x1
+    C -> sqrt(C) projection behind BatchNorm + ReLU, the 15-tap conv at width 8, the 1x1 sqrt(C) -> C expansion with
+    BatchNorm sums (net/st_gcn_mstcn_1x1_deep.py:253-269): slices bit-exact, sums == stored output, gradients additive."""
+    d = dev()
+    dt = torch.float16
+    NM, T, C, w = 256, 600, 64, 8
+    g_ = _randn(NM, T, V, C, seed=51, dt=dt)
+    pre = torch.stack([0.5 + torch.rand(C, generator=torch.Generator().manual_seed(52)),
+                       0.3 * torch.randn(C, generator=torch.Generator().manual_seed(53))]).to(d)
+    Ws = _randn(w, C, seed=54, dt=torch.float32, scale=C ** -0.5)
+    Wt = _randn(15, w, w, seed=55, dt=torch.float32, scale=(15 * w) ** -0.5)
+    We = _randn(C, w, seed=56, dt=torch.float32, scale=w ** -0.5)
+    bs, bt, be = (_randn(n, seed=57 + i, dt=torch.float32, scale=0.1) for i, n in enumerate((w, w, C)))
+    taps, in_mul = ops.conv_taps_fwd(15, 1)
+    ws = ops.pack_tconv_weight(Ws.view(1, w, C), V, [0], 1, dt)
+    wt = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
+    we = ops.pack_tconv_weight(We.view(1, C, w), V, [0], 1, dt)
+
+    def trio(gin, stats=None):
+        q = ops.tconv(gin, ws, w, [0], bias=bs, pre=pre, pre_relu=True, Tout=T, Mlog=T)
+        yb = ops.tconv(q, wt, w, taps, bias=bt, Tout=T, Mlog=T, in_mul=in_mul)
+        return q, yb, ops.tconv(yb, we, C, [0], bias=be, stats=stats, Tout=T, Mlog=T)
+    st = ops.new_stats(C, d)
+    q, yb, z = trio(g_, st)
+    for lo, hi in ((0, 1), (127, 130), (NM - 2, NM)):
+        qs, ybs, zs = trio(g_[lo:hi].contiguous())
+        assert torch.equal(qs, q[lo:hi]) and torch.equal(ybs, yb[lo:hi]) and torch.equal(zs, z[lo:hi])
+    zf, s = z.double(), st.sum(0)
+    assert ((s[0] - zf.sum((0, 1, 2))).abs().max() / zf.abs().sum((0, 1, 2)).max()) < 1e-5
+    assert ((s[1] - (zf * zf).sum((0, 1, 2))).abs().max() / (zf * zf).sum((0, 1, 2)).max()) < 1e-5
+    # weight gradients of the three convolutions: additive over batch halves
+    dz = _randn(NM, T, V, C, seed=60, dt=dt, scale=0.1)
+    dq = _randn(NM, T, V, w, seed=61, dt=dt, scale=0.1)
+    h = NM // 2
+    for (dzz, gin, tp, kw) in ((dz, yb, [0], {}), (dq, q, taps, {}), (dq, g_, [0], dict(pre=pre, pre_relu=True))):
+        dW, db = ops.tconv_wgrad(dzz, gin, tp, in_mul=1, **kw)
+        dWa, dba = ops.tconv_wgrad(dzz[:h].contiguous(), gin[:h].contiguous(), tp, in_mul=1, **kw)
+        dWb, dbb = ops.tconv_wgrad(dzz[h:].contiguous(), gin[h:].contiguous(), tp, in_mul=1, **kw)
+        assert ((dW - (dWa + dWb)).abs().max() / dW.abs().max()) < 2e-5
+        assert ((db - (dba + dbb)).abs().max() / db.abs().max()) < 2e-5

@@ -191,3 +191,18 @@ def test_model_eval_logits_full_clip(tag, golden):
     x = det_tensor('g4.x.' + tag, tuple(int(s) for s in g['eval_shape']))
     with torch.no_grad():
         assert rel_err(m(x), g['eval_logits']) < 1e-4
+
+
+@pytest.mark.parametrize('ci', range(2))
+def test_mstcn_oracle_matches_reference(ci, golden):
+    """G8: net/utils/ms_tcn.py:41-52 (BatchNorm -> ReLU -> conv_b -> the same BatchNorm -> Dropout), eval and train mode."""
+    g = golden('mstcn_g8.npz')
+    N, C, T, V, stride = [int(v) for v in g['c%d.shape' % ci]]
+    m = R.RefMSTCN(C, 3, 9, 15, 0.0, stride=stride)
+    m.load_state_dict(det_fill_(m.state_dict()))
+    x = det_tensor('g8.x.%d' % ci, (N, C, T, V))
+    with torch.no_grad():
+        assert rel_err(m.eval()(x), g['c%d.eval' % ci]) < 1e-5
+        assert rel_err(m.train()(x), g['c%d.train' % ci]) < 1e-5
+    assert rel_err(m.batchnorm2d.running_mean, g['c%d.running_mean' % ci]) < 1e-5
+    assert rel_err(m.batchnorm2d.running_var, g['c%d.running_var' % ci]) < 1e-5
