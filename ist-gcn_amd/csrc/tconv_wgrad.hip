@@ -1726,6 +1726,11 @@ int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int istgcn_tconv_wgrad_rc_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype);
+extern "C" int istgcn_tconv_wgrad_rc(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, float* dbias,
+                                     int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
+                                     int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats, void* stream);
+
 extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW,
                                   float* dbias, int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps,
                                   const int* tap_off, int in_mul, int dtype, int grid_cap, float* ws,
@@ -1735,6 +1740,20 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
     return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || Tz == 0) return ISTGCN_OK;
+  {
+    // frame-tiled kernel (tconv_rc_wgrad.hip): consecutive taps, stride 1 or 2, 64-channel blocks, 16-bit storage.  Measured
+    // (tools/twg_exp.py, bf16, NM = 128): it wins where the round-2 kernels have no wave-specialised form for the 9-tap
+    // stride-2 layers (128 ch T=300: 307 -> 265 us, 256 ch T=150: 537 -> 478); at stride 1 twg_ws is 5-8 % faster (the
+    // 32-row frame tiles cost 28 % more matrix work than its 125-of-128-row tiles), and the 16-tap variant has no
+    // registers left for its staging pipeline -- those stay with the round-2 kernels.
+    // ISTGCN_TWG_RC=0: round-2 kernels everywhere (A/B timing); =2: the frame-tiled kernel wherever it applies
+    const char* e = getenv("ISTGCN_TWG_RC");
+    const int mode = e ? atoi(e) : 1;
+    if (mode != 0 && istgcn_tconv_wgrad_rc_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype) &&
+        (mode == 2 || (in_mul == 2 && ntaps <= 10)))
+      return istgcn_tconv_wgrad_rc(dz, g, pre, pre_relu, dW, dbias, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype,
+                                   grid_cap, ws, ws_floats, stream);
+  }
   TwgParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;
   P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps; P.in_mul = in_mul;
