@@ -30,7 +30,7 @@ extern "C" {
 int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nch, int* KKp, int* MTtot,
                         int* EPL);
 
-/* Register-chained layout (round 3, csrc/gcn_rc.hip): for 16-bit storage, Cin in {64,128,256}, Cout % 64 == 0, K <= 4 (and
+/* Register-chained layout (round 3, csrc/gcn_rc.hip): for 16-bit storage, Cin in {3 (zero-padded to 16),64,128,256}, Cout % 64 == 0, K <= 4 (and
  * K*Cin*128 bytes <= 100 KB of LDS) the packed weights carry a SECOND section behind the one above, at element offset
  * istgcn_gcn_rc_offset (-1: none; istgcn_gcn_rc_layout: 1 / 0):
  *   element (((jt*K + k)*(Cin/16) + s)*64 + 32*h + c)*8 + e  holds  Wr[32*jt + c][k][16*s + 8*h + e]

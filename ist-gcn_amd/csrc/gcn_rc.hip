@@ -38,11 +38,13 @@ struct RcFwdParams {
 // S = Cin / 16 (k-steps of the channel contraction), NCP = 64-channel pairs per workgroup slice (waves of a workgroup:
 // 8 / NCP frame workers x NCP pairs), PF2 = the next frame's operand registers are a second set (else the loads reuse
 // the set right after the frame's last contraction MFMA and the epilogue covers their latency).
-template <typename T, int S, int K, int NCP, bool PF2, bool ADD>
+template <typename T, int S, int K, int NCP, bool PF2, bool ADD, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_fwd_kernel(const RcFwdParams P) {
   using E = Elem<T>;
   typedef typename E::frag frag_t;
-  constexpr int CIN = 16 * S;
+  constexpr int CIN = 16 * S;                                // contraction extent (k-steps x 16)
+  constexpr int CROW = CN ? CN : CIN;                        // channels of a row in memory (CN: the 3-channel first layer)
+  static_assert(CN == 0 || (S == 1 && CN <= 4), "narrow input: one k-step, at most four 16-bit loads per lane");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int WVEC = NCP * 2 * K * S * 64;                 // 16-byte vectors of the weight slice
   u32x4* wl = reinterpret_cast<u32x4*>(smem);
@@ -64,12 +66,12 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_fwd_kernel(const RcFwdParams
   //      from global memory the compiler predicates each of the ~80 scalar loads and waits for them one by one.) ----
   {
     const u32x4* wg = reinterpret_cast<const u32x4*>(P.Wq) + (size_t)slice * WVEC;
-    constexpr int NWI = WVEC / RC_NTH;                       // WVEC is a multiple of 512 (2 * S * 64 >= 512)
+    constexpr int NWI = (WVEC + RC_NTH - 1) / RC_NTH;
     u32x4 wv[NWI];
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) wv[i] = wg[tid + i * RC_NTH];
+    for (int i = 0; i < NWI; ++i) wv[i] = wg[min(tid + i * RC_NTH, WVEC - 1)];
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) wl[tid + i * RC_NTH] = wv[i];
+    for (int i = 0; i < NWI; ++i) if (tid + i * RC_NTH < WVEC) wl[tid + i * RC_NTH] = wv[i];
     for (int i = tid; i < 2 * 64 * NCP; i += RC_NTH) stat[i] = 0.f;
   }
   float* Asc = reinterpret_cast<float*>(img_all);            // [K][V][V]
@@ -110,17 +112,27 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_fwd_kernel(const RcFwdParams
   const T* xg = reinterpret_cast<const T*>(P.x);
   T* yg = reinterpret_cast<T*>(P.y);
   const T* addg = reinterpret_cast<const T*>(P.addend);
-  const unsigned xfrm_b = (unsigned)(V * CIN) * 2u, yfrm_b = (unsigned)(V * P.Cout) * 2u;   // bytes of one frame
+  const unsigned xfrm_b = (unsigned)(V * CROW) * 2u, yfrm_b = (unsigned)(V * P.Cout) * 2u;  // bytes of one frame
   const u32x4* wlane = wl + (size_t)cp * (2 * K * S * 64) + lane;         // fragment (jt, k, s) at + ((jt*K + k)*S + s)*64
   uint32_t* img = img_all + wave8 * (IMG_BYTES / 4);
-  const unsigned xoff = (unsigned)(c * CIN + 8 * h) * 2u;                 // byte offset of this lane's row vector in a frame
-  const size_t in_seq = (size_t)P.Tin * V * CIN, in_frm = (size_t)P.in_t_stride * V * CIN;
+  // byte offset of this lane's row vector in a frame (narrow rows: lane half 0 holds the whole row, half 1 reads past
+  // the descriptor = zeros)
+  const unsigned xoff = CN ? (h == 0 ? (unsigned)(c * CN) * 2u : 0x7ffffff0u) : (unsigned)(c * CIN + 8 * h) * 2u;
+  const size_t in_seq = (size_t)P.Tin * V * CROW, in_frm = (size_t)P.in_t_stride * V * CROW;
   const size_t out_seq = (size_t)P.Tout * V * P.Cout, out_frm = (size_t)P.out_t_stride * V * P.Cout;
 
   auto loadx = [&](int n, int t, u32x4 (&xf)[S]) __attribute__((always_inline)) {
     const rsrc_t r = make_rsrc(xg + (size_t)n * in_seq + (size_t)t * in_frm, xfrm_b);     // wave-uniform
+    if constexpr (CN) {
+      // 2 * CN-byte rows: element-wise 16-bit loads (only 2-byte aligned), packed into the one k-step's fragment
+      uint32_t e[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int s = 0; s < S; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u * s, 0, 0);
+      for (int j = 0; j < CN; ++j) e[j] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, xoff + 2u * j, 0, 0);
+      xf[0] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u};
+    } else {
+#pragma unroll
+      for (int s = 0; s < S; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u * s, 0, 0);
+    }
   };
 
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -271,9 +283,9 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_fwd_kernel(const RcFwdParams
   }
 }
 
-template <typename T, int S, int K, int NCP, bool PF2, bool ADD>
+template <typename T, int S, int K, int NCP, bool PF2, bool ADD, int CN>
 int rc_fwd_launch2(RcFwdParams P, int grid_cap, hipStream_t stream) {
-  auto kfn = gcn_rc_fwd_kernel<T, S, K, NCP, PF2, ADD>;
+  auto kfn = gcn_rc_fwd_kernel<T, S, K, NCP, PF2, ADD, CN>;
   const size_t lds = (size_t)NCP * 2 * K * S * 64 * 16 + 8 * IMG_BYTES + 2 * 64 * NCP * 4;
   if (lds > 160 * 1024) return ISTGCN_EINVAL;
   static std::atomic<unsigned long long> optin{0};
@@ -293,32 +305,34 @@ int rc_fwd_launch2(RcFwdParams P, int grid_cap, hipStream_t stream) {
   return ISTGCN_OK;
 }
 
-template <typename T, int S, int K, int NCP, bool PF2>
+template <typename T, int S, int K, int NCP, bool PF2, int CN>
 int rc_fwd_launch(const RcFwdParams& P, int grid_cap, hipStream_t stream) {
   if constexpr ((size_t)K * 16 * S * 64 * NCP * 2 > 100 * 1024) return ISTGCN_EINVAL;
   else {
-    if (P.addend) return rc_fwd_launch2<T, S, K, NCP, PF2, true>(P, grid_cap, stream);
-    return rc_fwd_launch2<T, S, K, NCP, PF2, false>(P, grid_cap, stream);
+    if constexpr (CN == 0) {
+      if (P.addend) return rc_fwd_launch2<T, S, K, NCP, PF2, true, 0>(P, grid_cap, stream);
+    } else if (P.addend) return ISTGCN_EINVAL;
+    return rc_fwd_launch2<T, S, K, NCP, PF2, false, CN>(P, grid_cap, stream);
   }
 }
 
-template <typename T, int S, int K>
+template <typename T, int S, int K, int CN = 0>
 int rc_fwd_ncp(const RcFwdParams& P, int grid_cap, hipStream_t stream) {
   // channel pairs per workgroup: the slice's weights (K * Cin * 64 * NCP 16-bit elements) must fit LDS next to the images
   constexpr bool two = (size_t)K * 16 * S * 128 * 2 <= 100 * 1024;
   if constexpr (two) {
-    if (P.Cout % 128 == 0) return rc_fwd_launch<T, S, K, 2, (S <= 8)>(P, grid_cap, stream);
+    if (P.Cout % 128 == 0) return rc_fwd_launch<T, S, K, 2, (S <= 8), CN>(P, grid_cap, stream);
   }
-  return rc_fwd_launch<T, S, K, 1, (S <= 8)>(P, grid_cap, stream);
+  return rc_fwd_launch<T, S, K, 1, (S <= 8), CN>(P, grid_cap, stream);
 }
 
-template <typename T, int S>
+template <typename T, int S, int CN = 0>
 int rc_fwd_k(const RcFwdParams& P, int K, int grid_cap, hipStream_t stream) {
   switch (K) {
-    case 1: return rc_fwd_ncp<T, S, 1>(P, grid_cap, stream);
-    case 2: return rc_fwd_ncp<T, S, 2>(P, grid_cap, stream);
-    case 3: return rc_fwd_ncp<T, S, 3>(P, grid_cap, stream);
-    case 4: return rc_fwd_ncp<T, S, 4>(P, grid_cap, stream);
+    case 1: return rc_fwd_ncp<T, S, 1, CN>(P, grid_cap, stream);
+    case 2: return rc_fwd_ncp<T, S, 2, CN>(P, grid_cap, stream);
+    case 3: return rc_fwd_ncp<T, S, 3, CN>(P, grid_cap, stream);
+    case 4: return rc_fwd_ncp<T, S, 4, CN>(P, grid_cap, stream);
   }
   return ISTGCN_EINVAL;
 }
@@ -326,6 +340,7 @@ int rc_fwd_k(const RcFwdParams& P, int K, int grid_cap, hipStream_t stream) {
 template <typename T>
 int rc_fwd_T(const RcFwdParams& P, int Cin, int K, int grid_cap, hipStream_t stream) {
   switch (Cin) {
+    case 3: return rc_fwd_k<T, 1, 3>(P, K, grid_cap, stream);     // the models' first layer (net/st_gcnold.py:44: in_channels = 3)
     case 64: return rc_fwd_k<T, 4>(P, K, grid_cap, stream);
     case 128: return rc_fwd_k<T, 8>(P, K, grid_cap, stream);
     case 256: return rc_fwd_k<T, 16>(P, K, grid_cap, stream);
@@ -339,7 +354,7 @@ int rc_fwd_T(const RcFwdParams& P, int Cin, int K, int grid_cap, hipStream_t str
 // round-2 one?  (istgcn.h)
 extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype) {
   if (dtype != 1 && dtype != 2) return 0;
-  if (Cin != 64 && Cin != 128 && Cin != 256) return 0;
+  if (Cin != 3 && Cin != 64 && Cin != 128 && Cin != 256) return 0;
   if (Cout < 64 || Cout % 64 != 0 || K < 1 || K > 4) return 0;
   if ((size_t)K * Cin * 64 * 2 > 100 * 1024) return 0;
   return 1;
@@ -350,7 +365,7 @@ extern "C" int istgcn_gcn_fwd_rc(const void* x, const float* A, const void* Wq, 
                                  void* y, double* stats, int stats_rep, int NM, int Tin, int Tout, int Tlog, int V,
                                  int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int dtype, int grid_cap,
                                  void* stream) {
-  if (!istgcn_gcn_rc_layout(Cin, Cout, K, dtype) || V > 32 || (stats && addend)) return ISTGCN_EINVAL;
+  if (!istgcn_gcn_rc_layout(Cin, Cout, K, dtype) || V > 32 || (stats && addend) || (Cin == 3 && addend)) return ISTGCN_EINVAL;
   RcFwdParams P{};
   P.x = x; P.Wq = Wq; P.A = A; P.bterm = bterm; P.addend = addend; P.y = y; P.stats = stats;
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Tlog = Tlog; P.V = V; P.Cout = Cout;

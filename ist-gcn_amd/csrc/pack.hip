@@ -40,7 +40,7 @@ __device__ static inline void pack_gcn_body(const PackGcn& P, int idx) {
     // register-chained section [jt][k][s][lane][8]: lane (c = lane & 31, h = lane >> 5) of fragment (jt, k, s) holds
     // Wr[32 jt + c][k][16 s + 8 h + e] -- the B operand of H_k = x W_k^T with the channels in natural k order
     if (!P.rc) return;
-    const int r = idx - total, S = P.Cin / 16;
+    const int r = idx - total, S = (P.Cin + 15) / 16;       // (the 3-channel first layer: one zero-padded k-step)
     if (r >= P.K * (P.Cout / 32) * S * 64) return;
     const int lane = r & 63;
     int f = r >> 6;
@@ -49,7 +49,7 @@ __device__ static inline void pack_gcn_body(const PackGcn& P, int idx) {
     const int o = 32 * jt + (lane & 31), i0 = 16 * s + 8 * (lane >> 5);
     typename Elem<T>::frag v;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f(e < 8 ? P.src[o * P.s_o + k * P.s_k + (i0 + e) * P.s_i] : 0.f);
+    for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f((e < 8 && i0 + e < P.Cin) ? P.src[o * P.s_o + k * P.s_k + (i0 + e) * P.s_i] : 0.f);
     *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
     return;
   }
@@ -189,7 +189,7 @@ extern "C" int istgcn_pack_job_gcn(void* rec, const float* src, long long s_o, l
   const int rc = istgcn_gcn_rc_layout(Cin, Cout, K, dtype);
   J.u.g = PackGcn{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot, rc};
   *reinterpret_cast<PackJob*>(rec) = J;
-  return ceil_div(nch * mttot * J.u.g.NKG * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0), 256);
+  return ceil_div(nch * mttot * J.u.g.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / 8 : 0), 256);
 }
 
 extern "C" int istgcn_pack_job_tconv(void* rec, const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,
@@ -237,7 +237,7 @@ extern "C" int istgcn_pack_batch(const void* jobs_dev, const int* block_start_de
 extern "C" long long istgcn_pack_gcn_elems(int Cin, int Cout, int K, int dtype) {
   int cce, nch, kkp, mttot, epl;
   if (Cin < 1 || Cout < 1 || K < 1 || istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return -1;
-  return (long long)nch * mttot * kkp * 32 + (istgcn_gcn_rc_layout(Cin, Cout, K, dtype) ? (long long)K * Cout * Cin : 0);
+  return (long long)nch * mttot * kkp * 32 + (istgcn_gcn_rc_layout(Cin, Cout, K, dtype) ? (long long)K * Cout * round_up(Cin, 16) : 0);
 }
 
 // Element offset of the register-chained section inside the packed graph-conv weights, or -1 if there is none.
@@ -255,7 +255,7 @@ extern "C" int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, l
   if (int rc = istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return rc;
   const int rc = istgcn_gcn_rc_layout(Cin, Cout, K, dtype);
   PackGcn P{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot, rc};
-  const int total = nch * mttot * P.NKG * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0);
+  const int total = nch * mttot * P.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / 8 : 0);
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);

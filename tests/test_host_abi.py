@@ -49,11 +49,11 @@ def test_geometry_and_packing_agree(lib):
             wp = ops.pack_gcn_weight(wr, dt)
             n_old = nch * mttot * kkp * 32
             rc = lib.istgcn_gcn_rc_layout(cin, cout, K, ops._DT[dt])
-            assert wp.numel() == n_old + (K * cout * cin if rc else 0)
+            assert wp.numel() == n_old + (K * cout * ((cin + 15) // 16 * 16) if rc else 0)
             assert lib.istgcn_gcn_rc_offset(cin, cout, K, ops._DT[dt]) == (n_old if rc else -1)
             if rc:
                 # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][e] = Wr[32 jt + c][k][16 s + 8 h + e]
-                q = wp.reshape(-1)[n_old:].view(cout // 32, K, cin // 16, 2, 32, 8)
+                q = wp.reshape(-1)[n_old:].view(cout // 32, K, (cin + 15) // 16, 2, 32, 8)
                 for (c, k, i) in ((0, 0, 0), (cout - 1, K - 1, cin - 1), (cout // 2, K // 2, cin // 3)):
                     assert float(q[c // 32, k, i // 16, (i % 16) // 8, c % 32, i % 8]) == float(wr[c, k, i].to(dt))
             wp = wp.reshape(-1)[:n_old].view(nch, mttot, kkp // (2 * epl), 2, 32, epl)
