@@ -81,7 +81,9 @@ int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* 
 /* Register-chained layout of Wb (round 3, csrc/gcn_rc_bwd.hip): for 16-bit storage, Cout in {64,128,256}, Cin % 64 == 0,
  * K <= 4 (K*Cout*128 bytes <= 100 KB) a second section follows at element offset istgcn_gcn_bwd_rc_offset (-1: none):
  *   element (((it*K + k)*(Cout/16) + s)*64 + 32*h + c)*8 + e  holds  W[k][16*s + 8*h + e][32*it + p(c)],
- *   p(c) = c with bits 2 and 3 swapped.  istgcn_gcn_bwd_data uses the register-chained kernel when also V <= 32. */
+ *   p(c) = c with bits 2 and 3 swapped.  istgcn_gcn_bwd_data uses the register-chained kernel when also V <= 32.
+ * Cin = 3, Cout = 64 (the models' first layer, whose input needs no gradient) also has the section (one zero-padded
+ * 32-channel tile); for it dx may be NULL: only dA is computed. */
 int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
 long long istgcn_gcn_bwd_rc_offset(int Cin, int Cout, int K, int dtype);
 int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,

@@ -1042,7 +1042,7 @@ extern "C" int istgcn_gcn_bwd_data_rc(const void* dy, const void* x, const float
 extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
                                    const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
                                    int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
-  if (!dy || !A || !Wb || !dx) return ISTGCN_EINVAL;
+  if (!dy || !A || !Wb || (!dx && !dA)) return ISTGCN_EINVAL;
   if (dA && !x) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
   if (nnz_cap < 1 || nnz_cap > K * V * V || (dA && nnz_cap > 16 * NTHREADS)) return ISTGCN_EINVAL;
@@ -1050,13 +1050,15 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   if (NM == 0 || T == 0) return ISTGCN_OK;
   {
     const char* e = getenv("ISTGCN_GCN_RC");
-    if ((!e || atoi(e) != 0) && V <= 32 && !(dA && Cout > 128 && !getenv("ISTGCN_RC_SPLIT")) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype)) {
+    if ((!e || atoi(e) != 0) && V <= 32 && !(dA && Cout > 128 && !getenv("ISTGCN_RC_SPLIT")) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
+        (Cin != 3 ? dx != nullptr : (!dx && dA && !addend))) {
       const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
       if (off >= 0)
         return istgcn_gcn_bwd_data_rc(dy, x, A, pattern, reinterpret_cast<const char*>(Wb) + (size_t)off * 2, addend, dx, dA, NM, T, V,
                                       Cin, Cout, K, dtype, grid_cap, stream);
     }
   }
+  if (!dx) return ISTGCN_EINVAL;          // dx == NULL (adjacency gradient only) exists for the 16-bit first layer only; callers allocate dx otherwise
   GbdParams P{};
   P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;

@@ -36,8 +36,12 @@ __device__ static inline int perm23(int c) { return (c & ~12) | ((c & 4) << 1) |
 
 // SO = Cout / 16 (k-steps of the contraction over output channels), NCT = 32-channel tiles of dx per workgroup slice,
 // DA / ADD = with the adjacency gradient / with an addend, SPLIT = dx and dA on separate waves (see below).
-template <typename T, int SO, int K, int NCT, bool DA, bool ADD, bool SPLIT>
+template <typename T, int SO, int K, int NCT, bool DA, bool ADD, bool SPLIT, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams P) {
+  // CN != 0: the models' first layer (CN = 3 input channels, net/st_gcnold.py:44).  Its input needs no gradient, so only
+  // the adjacency gradient is computed (no dx chain, no image, no stores): one zero-padded 32-channel tile per frame,
+  // x rows read with 16-bit loads.
+  static_assert(CN == 0 || (NCT == 1 && DA && !ADD && !SPLIT && CN <= 4), "narrow input: dA only");
   using E = Elem<T>;
   typedef typename E::frag frag_t;
   constexpr int COUT = 16 * SO;
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   const unsigned dyfrm_b = (unsigned)(V * COUT) * 2u, xfrm_b = (unsigned)(V * Cin) * 2u;
   const u32x4* wlane = wl + (size_t)itl * (K * SO * 64) + lane;            // fragment (k, s) at + (k*SO + s)*64
   const unsigned dyoff = (unsigned)(c * COUT + 8 * h) * 2u;                // this lane's row vector of a dy frame (bytes)
-  const unsigned xoff = (unsigned)(c * Cin + 32 * it + 8 * h) * 2u;        // ... of an x frame, this wave's channel tile
+  // ... of an x frame, this wave's channel tile (narrow rows: lane half 0 holds the whole row, half 1 reads zeros)
+  const unsigned xoff = CN ? (h == 0 ? (unsigned)(c * CN) * 2u : 0x7ffffff0u) : (unsigned)(c * Cin + 32 * it + 8 * h) * 2u;
   const size_t dy_frm = (size_t)V * COUT, x_frm = (size_t)V * Cin;
   uint32_t* img = img_all + wave8 * (BIMG_BYTES / 4);
   const int pc = perm23(c);                                   // channel (within the tile) of MFMA column c
@@ -111,8 +116,16 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   };
   auto load_x = [&](int fn, int ft, u32x4 (&f)[2]) __attribute__((always_inline)) {
     const rsrc_t r = make_rsrc(xg + ((size_t)fn * P.T + ft) * x_frm, xfrm_b);
-    f[0] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff, 0, 0);
-    f[1] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u, 0, 0);
+    if constexpr (CN) {
+      uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < CN; ++j) e[j] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, xoff + 2u * j, 0, 0);
+      f[0] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u};
+      f[1] = u32x4{0u, 0u, 0u, 0u};
+    } else {
+      f[0] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff, 0, 0);
+      f[1] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u, 0, 0);
+    }
   };
 
   f32x16 Z[K];
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
 #pragma unroll
           for (int q = 0; q < 4; ++q) ht[s][q] = pack2<T>(HT[8 * s + 2 * q], HT[8 * s + 2 * q + 1]);
         mma_kgroup(Z[k], __builtin_bit_cast(frag_t, ht[0]), __builtin_bit_cast(frag_t, xf[0]));
-        mma_kgroup(Z[k], __builtin_bit_cast(frag_t, ht[1]), __builtin_bit_cast(frag_t, xf[1]));
+        if constexpr (CN == 0) mma_kgroup(Z[k], __builtin_bit_cast(frag_t, ht[1]), __builtin_bit_cast(frag_t, xf[1]));
       }
     }
     if constexpr (DX) {
@@ -260,7 +273,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   };
   typedef std::true_type yes;
   typedef std::false_type no;
-  if constexpr (!DA) walk(yes{}, no{}, yes{});
+  if constexpr (CN != 0) walk(no{}, yes{}, yes{});
+  else if constexpr (!DA) walk(yes{}, no{}, yes{});
   else if constexpr (!SPLIT) walk(yes{}, yes{}, std::integral_constant<bool, (SO <= 4)>{});
   else {
     if (role == 0) walk(yes{}, no{}, yes{});
@@ -295,18 +309,18 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   }
 }
 
-template <typename T, int SO, int K, int NCT, bool DA, bool ADD>
+template <typename T, int SO, int K, int NCT, bool DA, bool ADD, int CN = 0>
 int rc_bwd_launch(RcBwdParams P, int grid_cap, hipStream_t stream) {
   // 256 output channels: 64 operand registers of dy next to the 48 of dA^T do not fit one wave -> roles on separate waves
-  constexpr bool SPLIT = DA && SO > 8;
-  auto kfn = gcn_rc_bwd_kernel<T, SO, K, NCT, DA, ADD, SPLIT>;
+  constexpr bool SPLIT = DA && SO > 8 && CN == 0;
+  auto kfn = gcn_rc_bwd_kernel<T, SO, K, NCT, DA, ADD, SPLIT, CN>;
   size_t lds = (size_t)NCT * K * SO * 64 * 16 + 8 * BIMG_BYTES + (size_t)K * 2 * 64 * 16;
   if (DA && (size_t)(SPLIT ? 4 : 8) * K * 32 * 32 * 4 > lds) lds = (size_t)(SPLIT ? 4 : 8) * K * 32 * 32 * 4;
   if (lds > 160 * 1024) return ISTGCN_EINVAL;
   static std::atomic<unsigned long long> optin{0};
   if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
   int res = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, RC_NTH, lds);
-  P.gy = P.Cin / (32 * NCT);
+  P.gy = CN ? 1 : P.Cin / (32 * NCT);
   int G = res / P.gy / 8 * 8;
   if (G < 8) G = 8;
   const long long frames = (long long)P.NM * P.T;
@@ -355,7 +369,20 @@ int rc_bwd_k(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
 }
 
 template <typename T>
+int rc_bwd_first_layer(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
+  if (P.Cout != 64 || !P.dA || P.addend || P.dx) return ISTGCN_EINVAL;
+  switch (K) {
+    case 1: return rc_bwd_launch<T, 4, 1, 1, true, false, 3>(P, grid_cap, stream);
+    case 2: return rc_bwd_launch<T, 4, 2, 1, true, false, 3>(P, grid_cap, stream);
+    case 3: return rc_bwd_launch<T, 4, 3, 1, true, false, 3>(P, grid_cap, stream);
+    case 4: return rc_bwd_launch<T, 4, 4, 1, true, false, 3>(P, grid_cap, stream);
+  }
+  return ISTGCN_EINVAL;
+}
+
+template <typename T>
 int rc_bwd_T(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
+  if (P.Cin == 3) return rc_bwd_first_layer<T>(P, K, grid_cap, stream);
   switch (P.Cout) {
     case 64: return rc_bwd_k<T, 4>(P, K, grid_cap, stream);
     case 128: return rc_bwd_k<T, 8>(P, K, grid_cap, stream);
@@ -370,6 +397,7 @@ int rc_bwd_T(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
 extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype) {
   if (dtype != 1 && dtype != 2) return 0;
   if (Cout != 64 && Cout != 128 && Cout != 256) return 0;
+  if (Cin == 3 && Cout == 64 && K >= 1 && K <= 4) return 1;          // first layer: adjacency gradient only (dx == NULL)
   if (Cin < 64 || Cin % 64 != 0 || K < 1 || K > 4) return 0;
   if ((size_t)K * Cout * 64 * 2 > 100 * 1024) return 0;
   return 1;

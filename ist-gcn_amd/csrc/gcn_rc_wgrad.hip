@@ -34,7 +34,9 @@ constexpr int WG_FBT = 4;                 // frames per batch (all frame groups 
 
 // CT = 32-channel tiles of dy per workgroup block (2 or 4); the block's input side is always 64 channels (two tiles).
 // Waves: (ct, input tile) pairs x FG frame groups, FG = 8 / (2 CT).
-template <typename T, int K, int CT>
+// CN != 0: the models' 3-channel first layer -- x rows are 2*CN bytes, read with 16-bit loads into channel vector 0 of
+// the (otherwise zero) 64-channel image.
+template <typename T, int K, int CT, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParams P) {
   using E = Elem<T>;
   typedef typename E::frag frag_t;
@@ -98,6 +100,12 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
     gx_off[j] = v < V ? (unsigned)(((f * V + v) * Cin + ib * 64 + 8 * q) * 2) : 0x7ffffff0u;
     lx_off[j] = f * XFRM + v * XROW + ((q ^ (4 * ((v >> 1) & 1))) * 8);
   }
+  if constexpr (CN != 0) {
+    // narrow rows: thread idx < 4 * 32 owns (frame idx >> 5, row idx & 31) and fills channel vector 0; the rest load nothing
+    const int v = tid & 31, f = tid >> 5;
+    gx_off[0] = (tid < WG_FBT * 32 && v < V) ? (unsigned)((f * V + v) * CN * 2) : 0x7ffffff0u;
+    lx_off[0] = (tid < WG_FBT * 32) ? f * XFRM + v * XROW + ((0 ^ (4 * ((v >> 1) & 1))) * 8) : -1;
+  }
 #pragma unroll
   for (int j = 0; j < NITD; ++j) {
     const int idx = tid + j * RC_NTH;
@@ -115,15 +123,26 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
     const int nfr = (int)min((long long)WG_FBT, F - g0);
     const rsrc_t r0 = make_rsrc(xg + g0 * V * Cin, (unsigned)(nfr * V * Cin) * 2u);
     const rsrc_t r1 = make_rsrc(dyg + g0 * V * Cout, (unsigned)(nfr * V * Cout) * 2u);
+    if constexpr (CN != 0) {
+      uint32_t e[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < NITX; ++j) rx[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, gx_off[j], 0, 0);
+      for (int j = 0; j < CN; ++j) e[j] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r0, gx_off[0] + 2u * j, 0, 0);
+      rx[0] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u};
+    } else {
+#pragma unroll
+      for (int j = 0; j < NITX; ++j) rx[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, gx_off[j], 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < NITD; ++j) rd[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, gd_off[j], 0, 0);
   };
   auto commit = [&](int half, u32x4 (&rx)[NITX], u32x4 (&rd)[NITD]) __attribute__((always_inline)) {
     T* bufp = lds + half * BUF;
+    if constexpr (CN != 0) {
+      if (lx_off[0] >= 0) *reinterpret_cast<u32x4*>(bufp + lx_off[0]) = rx[0];
+    } else {
 #pragma unroll
-    for (int j = 0; j < NITX; ++j) *reinterpret_cast<u32x4*>(bufp + lx_off[j]) = rx[j];
+      for (int j = 0; j < NITX; ++j) *reinterpret_cast<u32x4*>(bufp + lx_off[j]) = rx[j];
+    }
 #pragma unroll
     for (int j = 0; j < NITD; ++j) *reinterpret_cast<u32x4*>(bufp + ld_off[j]) = rd[j];
   };
@@ -222,15 +241,18 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
   if (fg == 0) {
     const int n0 = K * Cout * Cin;
     const int crow = cb * 32 * CT + 32 * ct, icol = ib * 64 + 32 * itl + c;
+    const bool col_ok = icol < Cin;                           // (the 3-channel first layer: 3 of the 64 columns exist)
     if (P.ws) {
       float* sl = P.ws + (size_t)grp * P.ws_slice;
+      if (col_ok) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-          sl[((size_t)k * Cout + crow + r) * Cin + icol] = acc[k][i];
-        }
+          for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sl[((size_t)k * Cout + crow + r) * Cin + icol] = acc[k][i];
+          }
+      }
       if (itl == 0 && ib == 0 && P.S && c < V) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -239,13 +261,15 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
         }
       }
     } else {
+      if (col_ok) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-          atomicAdd(P.dW + ((size_t)k * Cout + crow + r) * Cin + icol, acc[k][i]);
-        }
+          for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(P.dW + ((size_t)k * Cout + crow + r) * Cin + icol, acc[k][i]);
+          }
+      }
       if (itl == 0 && ib == 0 && P.S && c < V) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -257,9 +281,9 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
   }
 }
 
-template <typename T, int K, int CT>
+template <typename T, int K, int CT, int CN = 0>
 int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
-  auto kfn = gcn_rc_wgrad_kernel<T, K, CT>;
+  auto kfn = gcn_rc_wgrad_kernel<T, K, CT, CN>;
   constexpr int FG = 8 / (2 * CT);
   size_t lds = (size_t)2 * WG_FBT * (32 * 64 + 32 * 32 * CT) * 2 + (size_t)K * 32 * 32 * 4;
   const size_t redb = FG == 2 ? (size_t)2 * CT * (K + 1) * 16 * 64 * 4 : 0;
@@ -268,7 +292,7 @@ int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
   static std::atomic<unsigned long long> optin{0};
   if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
   int res = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, RC_NTH, lds);
-  P.nib = P.Cin / 64;
+  P.nib = CN ? 1 : P.Cin / 64;
   P.gy = P.nib * (P.Cout / (32 * CT));
   int G = res / P.gy / 8 * 8;
   if (G < 8) G = 8;
@@ -293,6 +317,7 @@ int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
 
 template <typename T, int K>
 int rc_wg_ct(const RcWgParams& P, int grid_cap, hipStream_t stream) {
+  if (P.Cin == 3) return rc_wg_launch<T, K, 2, 3>(P, grid_cap, stream);
   if (P.Cout % 128 == 0) return rc_wg_launch<T, K, 4>(P, grid_cap, stream);
   return rc_wg_launch<T, K, 2>(P, grid_cap, stream);
 }
@@ -311,7 +336,8 @@ int rc_wg_k(const RcWgParams& P, int K, int grid_cap, hipStream_t stream) {
 }  // namespace
 
 extern "C" int istgcn_gcn_wgrad_rc_ok(int V, int Cin, int Cout, int K, int dtype) {
-  return (dtype == 1 || dtype == 2) && V <= 32 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K >= 1 && K <= 4;
+  return (dtype == 1 || dtype == 2) && V <= 32 && ((Cin >= 64 && Cin % 64 == 0) || Cin == 3) && Cout >= 64 && Cout % 64 == 0 &&
+         K >= 1 && K <= 4;
 }
 
 extern "C" int istgcn_gcn_wgrad_rc(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,

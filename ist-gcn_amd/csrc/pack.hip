@@ -121,7 +121,7 @@ __device__ static inline void pack_gcn_bwd_body(const PackGcnBwd& P, int idx) {
     // W3[k][16 s + 8 h + e][32 it + p(c)], p = c with bits 2 and 3 swapped (see gcn_rc_bwd.hip)
     if (!P.rc) return;
     const int r = idx - total, SO = P.Cout / 16;
-    if (r >= P.K * (P.Cin / 32) * SO * 64) return;
+    if (r >= P.K * ((P.Cin + 31) / 32) * SO * 64) return;   // (the 3-channel first layer: one zero-padded tile)
     const int lane = r & 63;
     int f = r >> 6;
     const int s = f % SO; f /= SO;
@@ -130,7 +130,7 @@ __device__ static inline void pack_gcn_bwd_body(const PackGcnBwd& P, int idx) {
     const int i = 32 * it + ((cl & ~12) | ((cl & 4) << 1) | ((cl & 8) >> 1)), c0 = 16 * s + 8 * (lane >> 5);
     typename Elem<T>::frag v;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f(e < 8 ? P.src[k * P.s_k + (c0 + e) * P.s_c + i * P.s_i] : 0.f);
+    for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f((e < 8 && i < P.Cin) ? P.src[k * P.s_k + (c0 + e) * P.s_c + i * P.s_i] : 0.f);
     *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
     return;
   }
@@ -220,7 +220,7 @@ extern "C" int istgcn_pack_job_gcn_bwd(void* rec, const float* src, long long s_
   const int rc = istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype);
   J.u.b = PackGcnBwd{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32, rc};
   *reinterpret_cast<PackJob*>(rec) = J;
-  return ceil_div(nchi * nchc * J.u.b.NKGc * J.u.b.MTK * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0), 256);
+  return ceil_div(nchi * nchc * J.u.b.NKGc * J.u.b.MTK * 2 * 32 + (rc ? K * Cout * round_up(Cin, 32) / 8 : 0), 256);
 }
 
 extern "C" int istgcn_pack_batch(const void* jobs_dev, const int* block_start_dev, int njobs, int total_blocks, int dtype,
@@ -294,7 +294,7 @@ extern "C" int istgcn_pack_tconv(const float* src, long long s_t, long long s_o,
 extern "C" long long istgcn_pack_gcn_bwd_elems(int Cin, int Cout, int K, int dtype) {
   int cci, nchi, ccc, nchc, kkp, epl;
   if (Cin < 1 || Cout < 1 || istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return -1;
-  return (long long)nchi * nchc * ccc * kkp + (istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) ? (long long)K * Cout * Cin : 0);
+  return (long long)nchi * nchc * ccc * kkp + (istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) ? (long long)K * Cout * round_up(Cin, 32) : 0);
 }
 
 // Element offset of the register-chained section inside the packed weights of istgcn_gcn_bwd_data, or -1 if there is none.
@@ -312,7 +312,7 @@ extern "C" int istgcn_pack_gcn_bwd(const float* src, long long s_k, long long s_
   if (int rc = istgcn_gcn_bwd_geometry(Cin, Cout, K, dtype, &cci, &nchi, &ccc, &nchc, &kkp, &epl)) return rc;
   const int rc = istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype);
   PackGcnBwd P{src, dst, s_k, s_c, s_i, Cin, Cout, K, cci, nchi, ccc, nchc, ccc / (2 * epl), kkp / 32, rc};
-  const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32 + (rc ? K * Cout * Cin / 8 : 0);
+  const int total = nchi * nchc * P.NKGc * P.MTK * 2 * 32 + (rc ? K * Cout * round_up(Cin, 32) / 8 : 0);
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_bwd_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_bwd_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);

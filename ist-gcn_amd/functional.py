@@ -366,8 +366,10 @@ class STGCNBlockFn(torch.autograd.Function):
             pat, cap = cfg.pattern, cfg.nnz_cap
             if need_A and pat is None:
                 pat, cap = torch.ones_like(A_eff), A_eff.numel()
+            # (first block: the input needs no gradient -- only the adjacency gradient is computed where the kernel has that form)
             dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cap, dA_out=buf_A,
-                                      pattern=pat, wb=pk.get('wb'))
+                                      pattern=pat, wb=pk.get('wb'),
+                                      want_dx=ctx.needs_input_grad[4] or cfg.residual == 'conv')
         if cfg.residual == 'conv':
             abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training, clear=True)
             dr = ops.affine2(dres, r, abcr)

@@ -383,13 +383,24 @@ def pack_gcn_wb_ref(w3, dtype):
         # p(c) = c with bits 2 and 3 swapped
         cs = torch.arange(32)
         pc = (cs & ~12) | ((cs & 4) << 1) | ((cs & 8) >> 1)
-        q = w3.reshape(K, cout // 16, 2, 8, cin // 32, 32)[..., pc]            # [k][s][h][e][it][c]
+        cpad = (cin + 31) // 32 * 32                       # (the 3-channel first layer: one zero-padded tile)
+        q = F.pad(w3, (0, cpad - cin)).reshape(K, cout // 16, 2, 8, cpad // 32, 32)[..., pc]            # [k][s][h][e][it][c]
         q = q.permute(4, 0, 1, 2, 5, 3)                                        # [it][k][s][h][c][e]
         out = torch.cat([out.reshape(-1), q.to(dtype).contiguous().reshape(-1)])
     return out
 
 
-def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None, wb=None):
+def first_layer_da_only(cin, cout, K, dtype, V):
+    """Can istgcn_gcn_bwd_data skip dx (dx = NULL) for this shape?  The models' 3-channel first layer in 16-bit storage: its
+    input needs no gradient, only the adjacency gradient does (csrc/gcn_rc_bwd.hip, narrow variant)."""
+    import os
+    if os.environ.get('ISTGCN_GCN_RC', '1') == '0':        # (A/B switch of the library: round-2 kernels only)
+        return False
+    return cin == 3 and V <= 32 and dtype != torch.float32 and bool(_lib.load().istgcn_gcn_bwd_rc_layout(cin, cout, K, _DT[dtype]))
+
+
+def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None, wb=None,
+                 want_dx=True):
     """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None).  pattern [K,V,V] fp32 (non-zero = entry whose
     gradient is wanted; None = the non-zeros of A): pass the constant adjacency of A = B * importance so that an
     importance value of exactly 0 keeps its gradient, or ones for a dense learnable A (autograd of tgcn.py:86)."""
@@ -397,14 +408,16 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
     K, cout2, Cin = w3.shape
     assert cout2 == Cout and A.shape == (K, V, V) and A.dtype == torch.float32
     dev = dy.device
-    dx = torch.empty((NM, T, V, Cin), dtype=dy.dtype, device=dev)
+    if not want_dx and not (want_dA and addend is None and first_layer_da_only(Cin, Cout, K, dy.dtype, V)):
+        want_dx = True                   # the dx-less form exists for the 16-bit first layer only
+    dx = torch.empty((NM, T, V, Cin), dtype=dy.dtype, device=dev) if want_dx else None
     dA = None
     if want_dA:
-        assert x is not None and x.shape == dx.shape and x.dtype == dy.dtype
+        assert x is not None and x.shape == (NM, T, V, Cin) and x.dtype == dy.dtype
         dA = dA_out if dA_out is not None else torch.zeros((K, V, V), dtype=torch.float32, device=dev)
         assert dA.shape == (K, V, V) and dA.dtype == torch.float32 and dA.is_contiguous()
     if addend is not None:
-        assert addend.shape == dx.shape and addend.dtype == dy.dtype
+        assert addend.shape == (NM, T, V, Cin) and addend.dtype == dy.dtype
     if wb is None:
         wb = pack_gcn_wb(w3, dy.dtype)
     if nnz_cap is None:

@@ -291,3 +291,31 @@ def test_gcn_bwd_data_optional_operands(ops, cin, cout, with_x, with_add, dt):
         assert diag(name + '_dA', dA.cpu(), A.grad * (A.detach() != 0), 1e-2) < 1e-2
     else:
         assert dA is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_first_layer_adjacency_gradient_without_dx(ops, dt):
+    """The models' first layer (3 input channels, net/st_gcnold.py:44) needs the adjacency gradient but no input gradient:
+    istgcn_gcn_bwd_data with dx = NULL (16-bit storage) must give the same dA as the full call and as autograd."""
+    NM, cin, cout, T, V, K = 5, 3, 64, 37, 25, 3
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(NM, cin, T, V, generator=gen).to(dt).float()
+    dy = torch.randn(NM, cout, T, V, generator=gen).to(dt).float()
+    W = torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5
+    A = (torch.rand(K, V, V, generator=gen) * (torch.rand(K, V, V, generator=gen) < 0.12)).requires_grad_(True)
+    R.graph_einsum(torch.nn.functional.conv2d(x, W), A).backward(dy)
+    d = dev()
+    cap = int((A != 0).sum())
+    args = (to_ntvc(dy).to(d, dt), A.detach().to(d), W.view(K, cout, cin).to(d))
+    dx0, dA0 = ops.gcn_bwd_data(*args, x=to_ntvc(x).to(d, dt), nnz_cap=cap)
+    dx1, dA1 = ops.gcn_bwd_data(*args, x=to_ntvc(x).to(d, dt), nnz_cap=cap, want_dx=False)
+    torch.cuda.synchronize()
+    assert dx0 is not None and dx1 is None
+    ref = A.grad * (A.detach() != 0)
+    assert diag('first_layer_dA_full_%s' % str(dt)[6:], dA0.cpu(), ref, 1e-2) < 1e-2
+    assert diag('first_layer_dA_only_%s' % str(dt)[6:], dA1.cpu(), ref, 1e-2) < 1e-2
+    # float32 storage has no dx-less form: the request is ignored, dx is computed as before
+    dx2, _ = ops.gcn_bwd_data(to_ntvc(dy).to(d), A.detach().to(d), W.view(K, cout, cin).to(d), x=to_ntvc(x).to(d),
+                              nnz_cap=cap, want_dx=False)
+    assert dx2 is not None

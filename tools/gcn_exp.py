@@ -24,7 +24,7 @@ for cin, cout, T in ((3, 64, 300), (64, 64, 300), (64, 128, 300), (128, 128, 150
     bterm = torch.randn(V, cout, device=d)
     st = ops.new_stats(cout, d)
     fns = {'fwd': lambda: ops.gcn_forward(x, A, wp, cout, bterm=bterm, stats=st, nnz_cap=cap),
-           'bwd': lambda: ops.gcn_bwd_data(dy, A, W3, x=x, addend=x if cin == cout else None, nnz_cap=cap),
+           'bwd': lambda: ops.gcn_bwd_data(dy, A, W3, x=x, addend=x if cin == cout else None, nnz_cap=cap, want_dx=cin != 3),
            'wgrad': lambda: ops.gcn_wgrad(dy, x, A, nnz_cap=cap)}
     fn = fns[which]
     res = {}
