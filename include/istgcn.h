@@ -34,7 +34,9 @@ int istgcn_gcn_geometry(int Cin, int Cout, int K, int dtype, int* CCeff, int* nc
  * K*Cin*128 bytes <= 100 KB of LDS) the packed weights carry a SECOND section behind the one above, at element offset
  * istgcn_gcn_rc_offset (-1: none; istgcn_gcn_rc_layout: 1 / 0):
  *   element (((jt*K + k)*(Cin/16) + s)*64 + 32*h + c)*8 + e  holds  Wr[32*jt + c][k][16*s + 8*h + e]
- * = the B operand fragments of H_k = x W_k^T (MFMA 32x32x16, channels in natural k order).  istgcn_gcn_fwd picks the
+ * = the B operand fragments of H_k = x W_k^T (MFMA 32x32x16, channels in natural k order).  float32 storage (Cin in
+ * {64,128,256}, K <= 3; csrc/gcn_rc_f32.hip, MFMA 32x32x2 f32): element ((((jt*K + k)*(Cin/64) + q)*8 + s4)*64 + 32*h + c)*4 + e
+ * holds Wr[32*jt + c][k][64*q + 32*h + 4*s4 + e].  istgcn_gcn_fwd picks the
  * register-chained kernel at launch when also V <= 32 and not (stats and addend) -- same arithmetic as
  * net/utils/tgcn.py:79-86, GEMM first (the 1x1 Conv2d :79), then the einsum :86 on the accumulator tile in registers. */
 int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);

@@ -863,6 +863,9 @@ extern "C" int istgcn_gcn_fwd_rc(const void* x, const float* A, const void* Wq, 
                                  void* y, double* stats, int stats_rep, int NM, int Tin, int Tout, int Tlog, int V,
                                  int Cin, int Cout, int K, int in_t_stride, int out_t_stride, int dtype, int grid_cap,
                                  void* stream);
+extern "C" int istgcn_gcn_fwd_rc_f32(const void* x, const float* A, const void* Wq, const float* bterm, void* y, double* stats,
+                                     int stats_rep, int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
+                                     int in_t_stride, int out_t_stride, int grid_cap, void* stream);
 static bool gcn_use_rc() {
   const char* e = getenv("ISTGCN_GCN_RC");        // read per call: tools/gcn_exp.py A/B-times the two kernels in one process
   return !e || atoi(e) != 0;
@@ -886,9 +889,12 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   if (NM == 0 || Tlog == 0) return ISTGCN_OK;
   if (gcn_use_rc() && V <= 32 && !(stats && addend) && istgcn_gcn_rc_layout(Cin, Cout, K, dtype)) {
     const long long off = istgcn_gcn_rc_offset(Cin, Cout, K, dtype);
-    if (off >= 0)
+    if (off >= 0 && dtype != 0)
       return istgcn_gcn_fwd_rc(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 2, bterm, addend, y, stats, stats_rep, NM, Tin,
                                Tout, Tlog, V, Cin, Cout, K, in_t_stride, out_t_stride, dtype, grid_cap, stream);
+    if (off >= 0 && dtype == 0 && !addend)
+      return istgcn_gcn_fwd_rc_f32(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 4, bterm, y, stats, stats_rep, NM, Tin, Tout,
+                                   Tlog, V, Cin, Cout, K, in_t_stride, out_t_stride, grid_cap, stream);
   }
   if (gcn_use_v1(dtype))
     return istgcn_gcn_fwd_v1(x, A, Wp, bterm, addend, y, stats, stats_rep, status, NM, Tin, Tout, Tlog, V, Cin, Cout, K, in_t_stride,

@@ -353,6 +353,8 @@ int rc_fwd_T(const RcFwdParams& P, int Cin, int K, int grid_cap, hipStream_t str
 // Does the packed graph-conv weight buffer of (Cin, Cout, K, dtype) carry the register-chained layout behind the
 // round-2 one?  (istgcn.h)
 extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype) {
+  if (dtype == 0)      // float32 (gcn_rc_f32.hip): 64-channel chunks, all K partitions' tiles in registers
+    return (Cin == 64 || Cin == 128 || Cin == 256) && Cout >= 64 && Cout % 64 == 0 && K >= 1 && K <= 3;
   if (dtype != 1 && dtype != 2) return 0;
   if (Cin != 3 && Cin != 64 && Cin != 128 && Cin != 256) return 0;
   if (Cout < 64 || Cout % 64 != 0 || K < 1 || K > 4) return 0;

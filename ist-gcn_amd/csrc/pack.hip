@@ -40,6 +40,23 @@ __device__ static inline void pack_gcn_body(const PackGcn& P, int idx) {
     // register-chained section [jt][k][s][lane][8]: lane (c = lane & 31, h = lane >> 5) of fragment (jt, k, s) holds
     // Wr[32 jt + c][k][16 s + 8 h + e] -- the B operand of H_k = x W_k^T with the channels in natural k order
     if (!P.rc) return;
+    if constexpr (sizeof(T) == 4) {
+      // float32 section (gcn_rc_f32.hip) [jt][k][q][s4][lane][4]: lane (c, h) of vector (jt, k, q, s4) holds
+      // Wr[32 jt + c][k][64 q + 32 h + 4 s4 + e]
+      const int r = idx - total, NQ = P.Cin / 64;
+      if (r >= P.K * (P.Cout / 32) * NQ * 8 * 64) return;
+      const int lane = r & 63;
+      int f = r >> 6;
+      const int s4 = f & 7; f >>= 3;
+      const int q = f % NQ; f /= NQ;
+      const int k = f % P.K; const int jt = f / P.K;
+      const int o = 32 * jt + (lane & 31), i0 = 64 * q + 32 * (lane >> 5) + 4 * s4;
+      typename Elem<T>::frag v;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = Elem<T>::from_f(P.src[o * P.s_o + k * P.s_k + (i0 + e) * P.s_i]);
+      *reinterpret_cast<typename Elem<T>::frag*>(reinterpret_cast<T*>(P.dst) + (size_t)idx * EPL) = v;
+      return;
+    }
     const int r = idx - total, S = (P.Cin + 15) / 16;       // (the 3-channel first layer: one zero-padded k-step)
     if (r >= P.K * (P.Cout / 32) * S * 64) return;
     const int lane = r & 63;
@@ -189,7 +206,7 @@ extern "C" int istgcn_pack_job_gcn(void* rec, const float* src, long long s_o, l
   const int rc = istgcn_gcn_rc_layout(Cin, Cout, K, dtype);
   J.u.g = PackGcn{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot, rc};
   *reinterpret_cast<PackJob*>(rec) = J;
-  return ceil_div(nch * mttot * J.u.g.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / 8 : 0), 256);
+  return ceil_div(nch * mttot * J.u.g.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / epl : 0), 256);
 }
 
 extern "C" int istgcn_pack_job_tconv(void* rec, const float* src, long long s_t, long long s_o, long long s_i, const int* tap_sel,
@@ -255,7 +272,7 @@ extern "C" int istgcn_pack_gcn(const float* src, long long s_o, long long s_k, l
   if (int rc = istgcn_gcn_geometry(Cin, Cout, K, dtype, &cce, &nch, &kkp, &mttot, &epl)) return rc;
   const int rc = istgcn_gcn_rc_layout(Cin, Cout, K, dtype);
   PackGcn P{src, dst, s_o, s_k, s_i, Cin, Cout, K, cce, nch, kkp / (2 * epl), mttot, rc};
-  const int total = nch * mttot * P.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / 8 : 0);
+  const int total = nch * mttot * P.NKG * 2 * 32 + (rc ? K * Cout * round_up(Cin, 16) / epl : 0);
   if (dtype == 0) ISTGCN_LAUNCH(pack_gcn_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else if (dtype == 2) ISTGCN_LAUNCH(pack_gcn_kernel<_Float16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);
   else ISTGCN_LAUNCH(pack_gcn_kernel<__bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, P);

@@ -120,9 +120,13 @@ def pack_gcn_weight_ref(wr, dtype):
     out = w.to(dtype).contiguous()
     if _lib.load().istgcn_gcn_rc_layout(cin, cout, K, _DT[dtype]):
         out = out.reshape(-1)
-        # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][8] = Wr[32 jt + c][k][16 s + 8 h + e]
-        cpad = (cin + 15) // 16 * 16                       # (the 3-channel first layer: one zero-padded k-step)
-        q = F.pad(wr, (0, cpad - cin)).reshape(cout // 32, 32, K, cpad // 16, 2, 8).permute(0, 2, 3, 4, 1, 5)
+        if dtype == torch.float32:
+            # float32 section (csrc/gcn_rc_f32.hip): [jt][k][q][s4][h][c][4] = Wr[32 jt + c][k][64 q + 32 h + 4 s4 + e]
+            q = wr.reshape(cout // 32, 32, K, cin // 64, 2, 8, 4).permute(0, 2, 3, 5, 4, 1, 6)
+        else:
+            # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][8] = Wr[32 jt + c][k][16 s + 8 h + e]
+            cpad = (cin + 15) // 16 * 16                   # (the 3-channel first layer: one zero-padded k-step)
+            q = F.pad(wr, (0, cpad - cin)).reshape(cout // 32, 32, K, cpad // 16, 2, 8).permute(0, 2, 3, 4, 1, 5)
         out = torch.cat([out, q.to(dtype).contiguous().reshape(-1)])
     return out
 

@@ -319,3 +319,29 @@ def test_first_layer_adjacency_gradient_without_dx(ops, dt):
     dx2, _ = ops.gcn_bwd_data(to_ntvc(dy).to(d), A.detach().to(d), W.view(K, cout, cin).to(d), x=to_ntvc(x).to(d),
                               nnz_cap=cap, want_dx=False)
     assert dx2 is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 64, 64, 23, 25, 3), (2, 64, 128, 11, 25, 3), (2, 128, 256, 9, 25, 3), (2, 256, 256, 7, 18, 3),
+                                   (2, 128, 128, 12, 25, 2), (40, 64, 64, 38, 25, 3)])
+def test_gcn_fwd_float32_matrix_core_path_vs_oracle(ops, shape):
+    """float32 storage on the register-chained kernel (csrc/gcn_rc_f32.hip: contraction AND aggregation on
+    v_mfma_f32_32x32x2_f32, exact fp32 products): y and the BatchNorm partial sums against the oracle (net/utils/tgcn.py:79-86)."""
+    NM, cin, cout, T, V, K = shape
+    g = torch.Generator().manual_seed(hash(shape) & 0xFFFF)
+    x = torch.randn(NM, cin, T, V, generator=g)
+    W = torch.randn(K * cout, cin, 1, 1, generator=g) * cin ** -0.5
+    bias = torch.randn(K * cout, generator=g) * 0.1
+    A = torch.rand(K, V, V, generator=g) * (torch.rand(K, V, V, generator=g) < 0.15)
+    ref = R.graph_einsum(torch.nn.functional.conv2d(x, W, bias), A)
+    d = dev()
+    wr = W.view(K, cout, cin).permute(1, 0, 2).contiguous().to(d)
+    bterm = torch.einsum('kc,kw->wc', bias.view(K, cout), A.sum(1)).contiguous().to(d)
+    stats = torch.zeros(ops.STATS_REP, 2, cout, dtype=torch.float64, device=d)
+    y = ops.gcn_forward(to_ntvc(x).to(d), A.to(d), ops.pack_gcn_weight(wr, torch.float32), cout, bterm=bterm, stats=stats,
+                        nnz_cap=int((A != 0).sum()))
+    torch.cuda.synchronize()
+    assert diag('gcnf32_%s' % 'x'.join(map(str, shape)), to_nctv(y), ref, 2e-5) < 2e-5
+    yf, s = y.double().cpu(), stats.sum(0).cpu()
+    assert rel_err(s[0], yf.sum((0, 1, 2))) < 1e-5
+    assert rel_err(s[1], (yf * yf).sum((0, 1, 2))) < 1e-5

@@ -51,7 +51,12 @@ def test_geometry_and_packing_agree(lib):
             rc = lib.istgcn_gcn_rc_layout(cin, cout, K, ops._DT[dt])
             assert wp.numel() == n_old + (K * cout * ((cin + 15) // 16 * 16) if rc else 0)
             assert lib.istgcn_gcn_rc_offset(cin, cout, K, ops._DT[dt]) == (n_old if rc else -1)
-            if rc:
+            if rc and dt == torch.float32:
+                # float32 section (csrc/gcn_rc_f32.hip): [jt][k][q][s4][h][c][e] = Wr[32 jt + c][k][64 q + 32 h + 4 s4 + e]
+                q = wp.reshape(-1)[n_old:].view(cout // 32, K, cin // 64, 8, 2, 32, 4)
+                for (c, k, i) in ((0, 0, 0), (cout - 1, K - 1, cin - 1), (cout // 2, K // 2, cin // 3)):
+                    assert float(q[c // 32, k, i // 64, (i % 32) // 4, (i % 64) // 32, c % 32, i % 4]) == float(wr[c, k, i])
+            elif rc:
                 # register-chained section (csrc/gcn_rc.hip): [jt][k][s][h][c][e] = Wr[32 jt + c][k][16 s + 8 h + e]
                 q = wp.reshape(-1)[n_old:].view(cout // 32, K, (cin + 15) // 16, 2, 32, 8)
                 for (c, k, i) in ((0, 0, 0), (cout - 1, K - 1, cin - 1), (cout // 2, K // 2, cin // 3)):

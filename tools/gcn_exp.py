@@ -15,7 +15,7 @@ g = Graph('ntu-rgb+d', 'spatial_3')
 A = torch.tensor(g.A + g.A2 + g.A3, dtype=torch.float32, device=d)
 cap = int((A != 0).sum())
 NM, V, K = 128, 25, 3
-for cin, cout, T in ((3, 64, 300), (64, 64, 300), (64, 128, 300), (128, 128, 150), (128, 256, 150), (256, 256, 75)):
+for cin, cout, T in ((3, 64, 300) if dt != torch.float32 else (64, 64, 300), (64, 64, 300), (64, 128, 300), (128, 128, 150), (128, 256, 150), (256, 256, 75)):
     P = NM * T * V
     x = torch.randn(NM, T, V, cin, device=d).to(dt)
     dy = torch.randn(NM, T, V, cout, device=d).to(dt)
