@@ -19,6 +19,7 @@
 #include "gcn_rc.hpp"
 
 extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1, void* stream);
 
 namespace {
 
@@ -276,6 +277,273 @@ extern "C" int istgcn_gcn_fwd_rc_f32(const void* x, const float* A, const void* 
     case 1: return rc_f32_k<1>(P, grid_cap, (hipStream_t)stream);
     case 2: return rc_f32_k<2>(P, grid_cap, (hipStream_t)stream);
     case 3: return rc_f32_k<3>(P, grid_cap, (hipStream_t)stream);
+  }
+  return ISTGCN_EINVAL;
+}
+
+// =====================================================================================================================
+// Weight gradient, float32 (autograd of net/utils/tgcn.py:79-86):
+//   dW[k][c][i] += sum_{n,t,w} dy[t,w,c] * xa_k[t,w,i],  xa_k[w][i] = sum_v A_k[v][w] x[v][i];   S[w][c] += sum dy[t,w,c]
+// A wave owns one 32-input-channel tile of the workgroup's (64 output, 64 input) channel block for BOTH output tiles and
+// all K partitions (the aggregated tile is computed once per frame and partition) and walks every fourth frame of a batch:
+//   XA_k = A_k^T . x_frame      16 steps of v_mfma_f32_32x32x2_f32; per-lane operands are single floats, so the frame
+//                               images in LDS are read row-wise (ds_read_b32, conflict-free) -- no transposed reads in fp32
+//   dW_k[ct] += dy_frame^T . XA_k   the accumulator tile XA_k is the B operand as it stands (gcn_rc_f32 forward, step 2)
+//   S accumulates the dy values the lanes already hold (VALU).
+// Round 2's fp32 path (tconv_wgrad_kernel<..AGG..>) aggregates on the VALU into LDS images first.
+// =====================================================================================================================
+namespace {
+
+struct RcF32WgParams {
+  const float* dy; const float* x; const float* A; float* dW; float* S; float* ws;
+  long long ws_slice;
+  int NM, T, V, Cin, Cout, K;
+  int G, gy, nib;
+};
+
+constexpr int F32_RS = 64;                  // floats per image row
+constexpr int F32_IMG = 32 * F32_RS;        // floats per frame image (32 rows; rows >= V are zeros)
+
+template <int K>
+__global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_f32_wgrad_kernel(const RcF32WgParams P) {
+  constexpr int FB = 4;                                       // frames per batch = frame groups
+  constexpr int BUF = FB * 2 * F32_IMG;                       // floats per buffer: [frame][x | dy]
+  constexpr int NIT = FB * 2 * 32 * 16 / RC_NTH;              // staging slots per thread (16-byte vectors)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* lds = reinterpret_cast<float*>(smem);
+  f32x4* atl = reinterpret_cast<f32x4*>(lds + 2 * BUF);       // [K][4][64] A_k^T constants: lane (w, h), step s: A_k[16h + s][w]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int it = wave8 & 1, fg = wave8 >> 1;
+  const int b = blockIdx.x;
+  const int blk = (b >> 3) % P.gy;
+  const int grp = (b / (8 * P.gy)) * 8 + (b & 7);
+  const int ib = blk % P.nib, cb = blk / P.nib;
+  const int V = P.V, Cin = P.Cin, Cout = P.Cout;
+  const int c = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < 2 * BUF / 4; i += RC_NTH) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int idx = tid; idx < K * 4 * 64; idx += RC_NTH) {
+    const int ln = idx & 63, g4 = (idx >> 6) & 3, k = idx >> 8;
+    const int w = ln & 31, hh = ln >> 5;
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int v = 16 * hh + 4 * g4 + e;                     // step s = 4 g4 + e contracts joints s and 16 + s
+      a[e] = (w < V && v < V) ? P.A[(k * V + min(v, V - 1)) * V + min(w, V - 1)] : 0.f;
+    }
+    atl[idx] = a;
+  }
+
+  // staging slots: item = (frame of the batch, tensor, row, 16-byte vector of the 64-channel slice)
+  unsigned goff[NIT];
+  int loff[NIT], gsel[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int idx = tid + j * RC_NTH;
+    const int q = idx & 15, v = (idx >> 4) & 31, ten = (idx >> 9) & 1, f = idx >> 10;
+    const int C = ten ? Cout : Cin, c0 = ten ? cb * 64 : ib * 64;
+    goff[j] = v < V ? (unsigned)(((f * V + v) * C + c0 + 4 * q) * 4) : 0x7ffffff0u;
+    loff[j] = (f * 2 + ten) * F32_IMG + v * F32_RS + 4 * q;
+    gsel[j] = ten;
+  }
+  const long long F = (long long)P.NM * P.T;
+  const long long NB = (F + FB - 1) / FB;
+  f32x4 rg[NIT];
+  auto issue = [&](long long bt) __attribute__((always_inline)) {
+    const long long g0 = bt * FB;
+    const int nfr = (int)min((long long)FB, F - g0);
+    const rsrc_t r0 = make_rsrc(P.x + g0 * V * Cin, (unsigned)(nfr * V * Cin) * 4u);
+    const rsrc_t r1 = make_rsrc(P.dy + g0 * V * Cout, (unsigned)(nfr * V * Cout) * 4u);
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      // (the tensor of a slot is a per-thread constant: idx bit 9 -- 512 threads -> it alternates with j)
+      const u32x4 v = (j & 1) ? __builtin_amdgcn_raw_buffer_load_b128(r1, goff[j], 0, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(r0, goff[j], 0, 0);
+      rg[j] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto commit = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) *reinterpret_cast<f32x4*>(lds + half * BUF + loff[j]) = rg[j];
+  };
+
+  f32x16 acc[K][2];
+  float Sacc[2][16];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[k][ct][i] = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Sacc[ct][i] = 0.f;
+
+  auto frame = [&](const float* buf) __attribute__((always_inline)) {
+    const float* xi = buf + fg * 2 * F32_IMG;                 // this group's frame: x image, then dy image
+    const float* di = xi + F32_IMG;
+    float xv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xv[s] = xi[(16 * h + s) * F32_RS + 32 * it + c];              // B operand of XA: x[16h + s][i]
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      f32x16 XA;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) XA[i] = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 av = atl[(k * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) XA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xv[4 * g4 + e], XA, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        // A operand: dy[row of XA register i][c] -- re-read per partition (one ds_read_b32 per 64-cycle MFMA; holding both
+        // tiles' 32 values across the K partitions spilled)
+        float dv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dv[i] = di[((i & 3) + 8 * (i >> 2) + 4 * h) * F32_RS + 32 * ct + c];
+        if (k == 0 && it == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Sacc[ct][i] += dv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float xa = XA[i];
+          acc[k][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[i], xa, acc[k][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  long long bt = grp;
+  __syncthreads();
+  if (bt < NB) {
+    issue(bt);
+    commit(0);
+  }
+  __syncthreads();
+  int half = 0;
+  for (; bt < NB; bt += P.G) {
+    const long long nxt = bt + P.G;
+    issue(nxt < NB ? nxt : bt);
+    __builtin_amdgcn_sched_barrier(0);
+    frame(lds + half * BUF);
+    commit(half ^ 1);
+    half ^= 1;
+    __syncthreads();
+  }
+
+  // ---- flush: the four frame groups' sums are combined through LDS in two rounds, group 0 writes ----
+  float* red = lds;                                           // [2 waves][K*2*16 + 32][64]
+  constexpr int NR = K * 2 * 16 + 32;
+  auto put = [&](int slot) __attribute__((always_inline)) {
+    float* r = red + (size_t)slot * NR * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[((k * 2 + ct) * 16 + i) * 64] = acc[k][ct][i];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r[(K * 32 + ct * 16 + i) * 64] = Sacc[ct][i];
+  };
+  auto get = [&](int slot) __attribute__((always_inline)) {
+    const float* r = red + (size_t)slot * NR * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][ct][i] += r[((k * 2 + ct) * 16 + i) * 64];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Sacc[ct][i] += r[(K * 32 + ct * 16 + i) * 64];
+  };
+  if (fg >= 2) put((fg - 2) * 2 + it);
+  __syncthreads();
+  if (fg < 2) get(fg * 2 + it);
+  __syncthreads();
+  if (fg == 1) put(it);
+  __syncthreads();
+  if (fg == 0) {
+    get(it);
+    const int n0 = K * Cout * Cin;
+    const int icol = ib * 64 + 32 * it + c;
+    float* dW = P.ws ? P.ws + (size_t)grp * P.ws_slice : P.dW;
+    float* S = P.ws ? P.ws + (size_t)grp * P.ws_slice + n0 : P.S;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = cb * 64 + 32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h;
+          float* p = dW + ((size_t)k * Cout + r) * Cin + icol;
+          if (P.ws) *p = acc[k][ct][i]; else atomicAdd(p, acc[k][ct][i]);
+        }
+    if (it == 0 && ib == 0 && P.S) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int w = (i & 3) + 8 * (i >> 2) + 4 * h;
+          if (w < V) {
+            float* p = S + w * Cout + cb * 64 + 32 * ct + c;
+            if (P.ws) *p = Sacc[ct][i]; else atomicAdd(p, Sacc[ct][i]);
+          }
+        }
+    }
+  }
+}
+
+template <int K>
+int rc_f32_wg_launch(RcF32WgParams P, int grid_cap, hipStream_t stream) {
+  auto kfn = gcn_rc_f32_wgrad_kernel<K>;
+  size_t lds = (size_t)2 * 4 * 2 * F32_IMG * 4 + (size_t)K * 4 * 64 * 16;
+  const size_t redb = (size_t)4 * (K * 32 + 32) * 64 * 4;
+  if (redb > lds) lds = redb;
+  if (lds > 160 * 1024) return ISTGCN_EINVAL;
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
+  int res = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, RC_NTH, lds);
+  P.nib = P.Cin / 64;
+  P.gy = P.nib * (P.Cout / 64);
+  int G = res / P.gy / 8 * 8;
+  if (G < 8) G = 8;
+  const long long NB = ((long long)P.NM * P.T + 3) / 4;
+  while (G > 8 && G - 8 >= NB) G -= 8;
+  P.G = G;
+  const long long n0 = (long long)K * P.Cout * P.Cin, n1 = P.S ? (long long)P.V * P.Cout : 0;
+  const bool use_ws = P.ws && (long long)G * (n0 + n1) <= P.ws_slice && G >= 32;
+  if (use_ws) P.ws_slice = n0 + n1; else P.ws = nullptr;
+  ISTGCN_LAUNCH(kfn, dim3(G * P.gy), dim3(RC_NTH), lds, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  if (use_ws) return istgcn_wgrad_reduce(P.ws, n0 + n1, G, P.dW, (int)n0, P.S, (int)n1, stream);
+  return ISTGCN_OK;
+}
+
+}  // namespace
+
+extern "C" int istgcn_gcn_wgrad_rc_f32(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T,
+                                       int V, int Cin, int Cout, int K, int grid_cap, float* ws, long long ws_floats,
+                                       void* stream) {
+  if (V > 32 || Cin < 64 || Cin % 64 || Cout < 64 || Cout % 64 || K < 1 || K > 3) return ISTGCN_EINVAL;
+  RcF32WgParams P{};
+  P.dy = reinterpret_cast<const float*>(dy); P.x = reinterpret_cast<const float*>(x); P.A = A; P.dW = dW; P.S = S;
+  P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;
+  P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K;
+  switch (K) {
+    case 1: return rc_f32_wg_launch<1>(P, grid_cap, (hipStream_t)stream);
+    case 2: return rc_f32_wg_launch<2>(P, grid_cap, (hipStream_t)stream);
+    case 3: return rc_f32_wg_launch<3>(P, grid_cap, (hipStream_t)stream);
   }
   return ISTGCN_EINVAL;
 }

@@ -1780,6 +1780,9 @@ extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, fl
 }
 
 extern "C" int istgcn_gcn_wgrad_rc_ok(int V, int Cin, int Cout, int K, int dtype);
+extern "C" int istgcn_gcn_wgrad_rc_f32(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T,
+                                       int V, int Cin, int Cout, int K, int grid_cap, float* ws, long long ws_floats,
+                                       void* stream);
 extern "C" int istgcn_gcn_wgrad_rc(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V,
                                    int Cin, int Cout, int K, int dtype, int grid_cap, float* ws, long long ws_floats,
                                    void* stream);
@@ -1796,6 +1799,8 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
     const char* e = getenv("ISTGCN_GCN_RC");        // 0: the round-2 kernels (A/B timing, tools/gcn_exp.py)
     if ((!e || atoi(e) != 0) && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
       return istgcn_gcn_wgrad_rc(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, dtype, grid_cap, ws, ws_floats, stream);
+    if ((!e || atoi(e) != 0) && dtype == 0 && V <= 32 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
+      return istgcn_gcn_wgrad_rc_f32(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, grid_cap, ws, ws_floats, stream);
   }
   TwgParams P{};
   P.dz = dy; P.g = x; P.dW = dW; P.A = A; P.S = S; P.nnz_cap = nnz_cap;
