@@ -892,7 +892,9 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
     if (off >= 0 && dtype != 0)
       return istgcn_gcn_fwd_rc(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 2, bterm, addend, y, stats, stats_rep, NM, Tin,
                                Tout, Tlog, V, Cin, Cout, K, in_t_stride, out_t_stride, dtype, grid_cap, stream);
-    if (off >= 0 && dtype == 0 && !addend)
+    // (float32 is bound by the matrix instruction: the 32-row frame tile costs 32 / V of the round-1 kernel's row work.
+    //  Measured on config 3, V = 18: slower than round 1 -- 23.4 vs 19.8 ms per step; V = 25: 1.5-1.7x faster.)
+    if (off >= 0 && dtype == 0 && !addend && V >= 20)
       return istgcn_gcn_fwd_rc_f32(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 4, bterm, y, stats, stats_rep, NM, Tin, Tout,
                                    Tlog, V, Cin, Cout, K, in_t_stride, out_t_stride, grid_cap, stream);
   }

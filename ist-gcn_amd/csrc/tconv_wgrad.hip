@@ -1799,7 +1799,7 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
     const char* e = getenv("ISTGCN_GCN_RC");        // 0: the round-2 kernels (A/B timing, tools/gcn_exp.py)
     if ((!e || atoi(e) != 0) && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
       return istgcn_gcn_wgrad_rc(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, dtype, grid_cap, ws, ws_floats, stream);
-    if ((!e || atoi(e) != 0) && dtype == 0 && V <= 32 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
+    if ((!e || atoi(e) != 0) && dtype == 0 && V <= 32 && V >= 20 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
       return istgcn_gcn_wgrad_rc_f32(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, grid_cap, ws, ws_floats, stream);
   }
   TwgParams P{};
