@@ -140,6 +140,22 @@ def fold_tcn_taps_any(w1, w2, w3, b1, b2, b3, mst, scale=1.0):
     return fold_tcn_taps(w1, w2, w3, b1, b2, b3, mst, scale)
 
 
+def _pad_width(w, dt):
+    """bottleneck width rounded up to whole 16-byte channel vectors of the storage type"""
+    epl = 4 if dt == torch.float32 else 8
+    return (w + epl - 1) // epl * epl
+
+
+def _pad_bneck(Ws, bs, Wt, bt, We, w, wp):
+    """zero-padded views of the bottleneck's weights for a width of wp >= w channels: Ws [w][C] -> [wp][C], bs [w] -> [wp],
+    Wt [k][w][w] -> [k][wp][wp], bt likewise, We [C][w] -> [C][wp] (biases may be None)"""
+    if wp == w:
+        return Ws, bs, Wt, bt, We
+    p = wp - w
+    return (F.pad(Ws, (0, 0, 0, p)), None if bs is None else F.pad(bs, (0, p)), F.pad(Wt, (0, p, 0, p)),
+            None if bt is None else F.pad(bt, (0, p)), F.pad(We, (0, p)))
+
+
 _EYE = {}
 
 
@@ -272,12 +288,17 @@ class STGCNBlockFn(torch.autograd.Function):
             z = ops.tconv(g, wt, cout, taps, bias=bt, pre=coef1[:2].contiguous(), pre_relu=True, stats=st2,
                           Tout=Tz, Mlog=Tz, in_mul=in_mul)
         else:
-            w = cfg.width
-            ws = ops.pack_tconv_weight(Ws.view(1, w, cout), V, [0], 1, dt)
-            q = ops.tconv(g, ws, w, [0], bias=bs, pre=coef1[:2].contiguous(), pre_relu=True, Tout=T, Mlog=T)
-            wt = ops.pack_tconv_weight(Wt, V, taps, in_mul, dt)
-            yb = ops.tconv(q, wt, w, taps, bias=bt, Tout=Tz, Mlog=Tz, in_mul=in_mul)
-            we = ops.pack_tconv_weight(We.view(1, cout, w), V, [0], 1, dt)
+            # the bottleneck width int(sqrt(C)) (st_gcn_mstcn_1x1.py:190-224) is 11 at 128 channels: 22-byte rows that no
+            # 16-byte vector path can touch (measured, config 5: 4.3 ms per 128-channel block against 1.8 / 1.2 ms for the
+            # 8- and 16-wide ones).  The narrow tensors are therefore stored with the width padded to whole vectors; the
+            # padding channels carry zero weights and biases, so they ARE zeros and change nothing downstream.
+            w, wp = cfg.width, _pad_width(cfg.width, dt)
+            Ws_, bs_, Wt_, bt_, We_ = _pad_bneck(Ws, bs, Wt, bt, We, w, wp)
+            ws = ops.pack_tconv_weight(Ws_.view(1, wp, cout), V, [0], 1, dt)
+            q = ops.tconv(g, ws, wp, [0], bias=bs_, pre=coef1[:2].contiguous(), pre_relu=True, Tout=T, Mlog=T)
+            wt = ops.pack_tconv_weight(Wt_, V, taps, in_mul, dt)
+            yb = ops.tconv(q, wt, wp, taps, bias=bt_, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+            we = ops.pack_tconv_weight(We_.view(1, cout, wp), V, [0], 1, dt)
             z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
         coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
                                 clear=True)
@@ -346,15 +367,18 @@ class STGCNBlockFn(torch.autograd.Function):
             dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True, out=buf_t)
             d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b, packed=pk.get('wt_bwd'))
         else:
-            w = cfg.width
+            w, wp = cfg.width, _pad_width(cfg.width, dt)
+            Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
             dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
-            dWe = dWe3.view(cout, w)
-            dyb = _conv_bwd_data(dz, We.view(1, cout, w), 1, 1, Tz, w, V)
-            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t)
-            dq = _conv_bwd_data(dyb, Wt, k, s, T, w, V)
+            dWe = dWe3.view(cout, wp)[:, :w]
+            dyb = _conv_bwd_data(dz, We_.view(1, cout, wp), 1, 1, Tz, wp, V)
+            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t if wp == w else None)
+            dq = _conv_bwd_data(dyb, Wt_, k, s, T, wp, V)
             dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
-            dWs = dWs3.view(w, cout)
-            d1 = _conv_bwd_data(dq, Ws.view(1, w, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
+            dWs = dWs3.view(wp, cout)[:w]
+            d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
+            if wp != w:
+                dWt, dbt, dbs = dWt[:, :w, :w], dbt[:w], dbs[:w]
         abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True)
         dg = ops.affine2(d1, g, abc1)
         # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in
@@ -466,12 +490,14 @@ def build_infer_plan(cfg, dt, A_eff, bterm, Wg3, bn1, Wt, bt, bn2, Wr, br, bnr, 
             plan['wt'] = ops.pack_tconv_weight((Wt * s2.view(1, -1, 1)).contiguous(), V, taps, in_mul, dt)
             plan['bt'] = ((bt if bt is not None else zero) * s2 + h2).contiguous()
         else:
-            w = cfg.width
-            plan['ws'] = ops.pack_tconv_weight(Ws.view(1, w, cout), V, [0], 1, dt)
-            plan['bs'] = bs
-            plan['wt'] = ops.pack_tconv_weight(Wt.contiguous(), V, taps, in_mul, dt)
-            plan['bt'] = bt
-            plan['we'] = ops.pack_tconv_weight((We * s2.view(-1, 1)).contiguous().view(1, cout, w), V, [0], 1, dt)
+            w, wp = cfg.width, _pad_width(cfg.width, dt)          # width padded to whole channel vectors, as in training
+            Ws_, bs_, Wt_, bt_, We_ = _pad_bneck(Ws, bs, Wt, bt, (We * s2.view(-1, 1)), w, wp)
+            plan['wp'] = wp
+            plan['ws'] = ops.pack_tconv_weight(Ws_.contiguous().view(1, wp, cout), V, [0], 1, dt)
+            plan['bs'] = bs_
+            plan['wt'] = ops.pack_tconv_weight(Wt_.contiguous(), V, taps, in_mul, dt)
+            plan['bt'] = bt_
+            plan['we'] = ops.pack_tconv_weight(We_.contiguous().view(1, cout, wp), V, [0], 1, dt)
             plan['be'] = ((be if be is not None else zero) * s2 + h2).contiguous()
         if cfg.residual == 'conv':
             sr, hr = _bn_affine(bnr)
@@ -496,7 +522,7 @@ def run_infer_plan(cfg, plan, x):
         if cfg.tcn == 'conv':
             return ops.tconv(g, plan['wt'], cout, taps, bias=plan['bt'], pre=plan['pre1'], pre_relu=True, aux=res,
                              mode=2, Tout=Tz, Mlog=Tz, in_mul=in_mul)
-        w = cfg.width
+        w = plan['wp']
         q = ops.tconv(g, plan['ws'], w, [0], bias=plan['bs'], pre=plan['pre1'], pre_relu=True, Tout=T, Mlog=T)
         yb = ops.tconv(q, plan['wt'], w, taps, bias=plan['bt'], Tout=Tz, Mlog=Tz, in_mul=in_mul)
         return ops.tconv(yb, plan['we'], cout, [0], bias=plan['be'], aux=res, mode=2, Tout=Tz, Mlog=Tz)
