@@ -98,14 +98,15 @@ def load():
     # is dlopen'ed so that both share ONE runtime (device context, streams, allocations); loaded the other way round
     # the system libamdhip64 would come in as a second, device-less runtime (hipErrorNoDevice at the first launch).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('ISTGCN_LIB_PATH') or LIB_PATH      # experiment builds (tools/build_variant.sh); default: the in-tree library
+    if not os.path.exists(path):
         _err = ('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
-                'There is no CPU fallback for the IST-GCN hot path.' % LIB_PATH)
+                'There is no CPU fallback for the IST-GCN hot path.' % path)
         raise RuntimeError(_err)
     try:
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(path)
     except OSError as e:
-        raise RuntimeError('cannot load %s: %s' % (LIB_PATH, e))
+        raise RuntimeError('cannot load %s: %s' % (path, e))
     for name in ('istgcn_pack_gcn_elems', 'istgcn_pack_tconv_elems', 'istgcn_pack_gcn_bwd_elems', 'istgcn_gcn_rc_offset', 'istgcn_gcn_bwd_rc_offset'):
         getattr(_lib, name).restype = ctypes.c_longlong          # element counts; every other entry returns int
     return _lib

@@ -79,6 +79,11 @@ __device__ static inline void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifdef ISTGCN_TCONV_X_NOMFMA   /* experiment build: the compute waves issue everything but the MFMAs */
+constexpr bool TCONV_X_NOMFMA = true;
+#else
+constexpr bool TCONV_X_NOMFMA = false;
+#endif
 constexpr int UL = 8;     // 16-byte vectors of a staged chunk per memory-wave thread (rows x vectors <= UL * 256, checked on the host)
 
 template <typename T, int MT, int NT, bool VEC, int MODE, int WM>
@@ -162,6 +167,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
   };
   lds_barrier();
 
+#ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
+  if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
+#endif
   if (is_compute) {
     // =========================================== compute waves ===========================================
     // One wave per SIMD issues all the MFMAs, so nothing may stall it: the weight fragments come from L2 (500-900 cycles)
@@ -201,7 +209,11 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     auto load_a = [&](u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
       // branch-free: a ghost step (padding of an item to a multiple of DA steps) reads fragment 0 and does not advance
       const bool real = ppos < nit;
+#ifdef ISTGCN_TCONV_X_WL1      /* experiment build: every weight fragment is fragment 0 (L1 hits) */
+      const size_t off = 0;
+#else
       const size_t off = real ? aoff : 0;
+#endif
 #pragma unroll
       for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + off + (size_t)m * 64 * EPL);
       const size_t an = aoff + (real ? astride : 0);
@@ -214,8 +226,10 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     const int tapstep = rstep * P.us_stride - (P.NKG - 1) * KGS;
     int sb = 0, kgb = 0, soffb = 0;                         // step, its k-group, its element offset in the tile
     auto load_b = [&](u32x4 (&dst)[NTW]) __attribute__((always_inline)) {
+#ifndef ISTGCN_TCONV_X_NOB     /* experiment build: no activation fragment reads */
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt) dst[tt] = *reinterpret_cast<const u32x4*>(us + brow[tt] + soffb);
+#endif
       const bool adv = sb + 1 < nit;
       const bool wrap = kgb + 1 == P.NKG;
       soffb += adv ? (wrap ? tapstep : KGS) : 0;
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         const int st_ = s0 + (D);                                                                        \
         load_a(a[((D) + DA - 1) % DA]);                                                                  \
         load_b(b[((D) + PD) % DB]);                                                                      \
-        if (!(PRED) || st_ < nit) {                                                                      \
+        if (!TCONV_X_NOMFMA && (!(PRED) || st_ < nit)) {                                                 \
           _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                \
             _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) mma_kgroup(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); \
         }                                                                                                \

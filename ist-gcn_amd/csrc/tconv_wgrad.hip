@@ -771,6 +771,9 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
   f32x16 acc[JT];
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
 #define WSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
+  if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
+#endif
   if (is_compute) {
     // =========================================== compute waves ===========================================
     const int ot = wave8 & 1, it = wave8 >> 1;
@@ -1417,6 +1420,9 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
   f32x16 acc[OTW][KT];
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
 #define GSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
+  if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
+#endif
   if (is_compute) {
     // =========================================== compute waves ===========================================
     const int ot = wave8 & 1, it = wave8 >> 1;

@@ -63,12 +63,27 @@ class FlatGradSync:
         self._flat.div_(self.world)
         torch._foreach_copy_([g for g, _, _ in views], [self._flat[o:o + n].view_as(g) for g, o, n in views])
 
-    def all_reduce_flat_(self, flat):
-        """SUM-all-reduce a caller-owned flat gradient buffer in place (harness.FlatSGD's `G`): the whole exchange step
-        of the data-parallel path, no packing.  The caller folds 1/world into its update."""
+    def all_reduce_flat_(self, flat, async_op=False):
+        """SUM-all-reduce a caller-owned flat gradient buffer (a contiguous slice of harness.FlatSGD's `G`) in place: the
+        whole exchange step of the data-parallel path, no packing.  The caller folds 1/world into its update.
+        async_op=True returns the collective's Work handle (FlatSGD launches the early bucket from the backward pass and
+        waits for it in step(): with RCCL the collective runs on its own stream next to the rest of the backward kernels)."""
         if self.world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        return flat
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                return work
+        return None if async_op else flat
+
+    def agree_on(self, ints, device):
+        """rank 0's list of ints on every rank (FlatSGD's layout order: all ranks must cut the flat buffer identically)"""
+        if self.world <= 1:
+            return list(ints)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        n = torch.tensor([len(ints)], dtype=torch.int64, device=device)
+        dist.broadcast(n, src, group=self.group)
+        t = torch.tensor(list(ints) if int(n) == len(ints) else [0] * int(n), dtype=torch.int64, device=device)
+        dist.broadcast(t, src, group=self.group)
+        return [int(v) for v in t.cpu()]
 
     @property
     def bucket_bytes(self):

@@ -23,9 +23,19 @@ class FlatSGD:
       the engine wrote straight into their `G` view cost nothing.
     * interface used by the reference's processor: `param_groups[i]['lr']`, `zero_grad()`, `step()`.
     `update_fn(P, G, M, lr, momentum, weight_decay, nesterov, grad_scale)` defaults to the HIP kernel (GPU tensors only);
-    the CPU gloo test of the bucket logic passes a torch restatement."""
+    the CPU gloo test of the bucket logic passes a torch restatement.
 
-    def __init__(self, params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, loss_scale=1.0, update_fn=None):
+    Overlapped exchange (`overlap=True`, data parallel only).  The flat buffers are laid out in the order in which the
+    gradients became FINAL in the first backward pass (recorded by post-accumulate hooks; rank 0's order is adopted by
+    every rank), so "the gradients that are ready early" are one contiguous prefix of `G`.  From the second step on the
+    hook of the last parameter of that prefix (`early_fraction` of the bytes: the deep, wide blocks, which backward
+    reaches first) launches its all-reduce asynchronously while the rest of the backward pass is still running;
+    `step()` reduces the remaining suffix, waits for the early one and updates.  Two collectives instead of one, the
+    first of them hidden behind ~2/3 of the backward pass.  One backward per step is assumed (a second backward
+    before `step()` raises); under hipGraph capture the early launch is skipped and `step()` reduces everything."""
+
+    def __init__(self, params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, loss_scale=1.0, update_fn=None,
+                 overlap=True, early_fraction=0.75):
         self.params = [p for p in params if p.requires_grad]
         self.param_groups = [dict(params=self.params, lr=lr, momentum=momentum, nesterov=nesterov,
                                   weight_decay=weight_decay)]
@@ -35,11 +45,69 @@ class FlatSGD:
         self.P = self.G = self.M = None
         self.found_inf = None              # int32[1] on the device: raised by a non-finite gradient (see check_overflow)
         self._pending_M = None             # momentum loaded before the layout existed (load_state_dict on a fresh optimizer)
+        self._pending_order = None         # ... and the layout order it was saved in
         self._live, self._gviews, self._late = [], [], {}
+        self.overlap, self.early_fraction = bool(overlap), float(early_fraction)
+        self._arrival, self._seen = [], set()      # first backward: indices into self.params in the order the gradients became final
+        self._order = None                 # layout order (indices into self.params) of the live parameters
+        self._pos = {}                     # index into self.params -> position in the layout
+        self._early_n = self._early_end = 0    # live parameters / flat elements of the early bucket (0: one bucket)
+        self._arrived, self._work = 0, None
+        self.early_launches = 0            # diagnostics: early all-reduces launched so far
+        self._hooks = []
+        if hasattr(torch.Tensor, 'register_post_accumulate_grad_hook'):
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(param):
+            self._on_grad(i)
+        return hook
+
+    def _on_grad(self, i):
+        if self.P is None:                 # before the layout exists: record the order of the first backward
+            if i not in self._seen:
+                self._seen.add(i)
+                self._arrival.append(i)
+            return
+        if not self._early_n or self.sync is None or self.sync.world <= 1:
+            return
+        pos = self._pos.get(i)
+        if pos is None or pos >= self._early_n:
+            return
+        if self._work is not None:
+            raise RuntimeError('FlatSGD(overlap=True): a gradient of the early bucket arrived after its all-reduce was '
+                               'launched (second backward before step()?); use overlap=False for gradient accumulation')
+        self._arrived += 1
+        if self._arrived == self._early_n:
+            if self.P.is_cuda and torch.cuda.is_current_stream_capturing():
+                return                     # hipGraph capture: no collective inside the graph, step() reduces everything
+            self._gather(0, self._early_n)
+            self._work = self.sync.all_reduce_flat_(self.G[:self._early_end], async_op=True)
+            self.early_launches += 1
+
+    def _gather(self, lo, hi):
+        """gradients of the live parameters [lo, hi) that autograd delivered as tensors of their own -> their `G` views"""
+        src, dst = [], []
+        for p, gv in zip(self._live[lo:hi], self._gviews[lo:hi]):
+            g = p.grad
+            if g is None:
+                raise RuntimeError('FlatSGD: a parameter had a gradient on the first step and has none now')
+            if g.data_ptr() != gv.data_ptr():
+                src.append(g if g.dtype == torch.float32 else g.float())
+                dst.append(gv)
+                p.grad = gv
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def attach_sync(self, sync):
-        """dp.FlatGradSync: all-reduce `G` in place inside step()."""
+        """dp.FlatGradSync: all-reduce `G` in place inside step() (and, with overlap, its early prefix from the backward pass)."""
         self.sync = sync
+        if self.P is not None and sync is not None and sync.world > 1:
+            mine = list(self._order)
+            if sync.agree_on(mine, self.P.device) != mine:
+                raise RuntimeError('FlatSGD.attach_sync: the flat layout was fixed before the ranks could agree on it; '
+                                   'attach the sync before the first step')
         return self
 
     def zero_grad(self, set_to_none=True):
@@ -52,12 +120,24 @@ class FlatSGD:
             return
         for p in self.params:
             p.grad = None
+        self._arrived = 0
 
     def _build(self):
-        live = [p for p in self.params if p.grad is not None]
-        if not live:
+        live_idx = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not live_idx:
             raise RuntimeError('FlatSGD.step(): no parameter has a gradient')
-        dev = live[0].device
+        # layout order = the order in which the gradients became final (what the hooks saw), then whatever they missed
+        lset = set(live_idx)
+        order = [i for i in self._arrival if i in lset]
+        order += [i for i in live_idx if i not in set(order)]
+        dev = self.params[order[0]].device
+        if self.sync is not None and self.sync.world > 1:
+            order = self.sync.agree_on(order, dev)            # rank 0's order: one layout on every rank
+            if set(order) != lset:
+                raise RuntimeError('FlatSGD: the ranks disagree on which parameters have gradients')
+        self._order = order
+        self._pos = {i: n for n, i in enumerate(order)}
+        live = [self.params[i] for i in order]
         offs, total = [], 0
         for p in live:
             if p.dtype != torch.float32 or p.device != dev:
@@ -84,6 +164,14 @@ class FlatSGD:
         self._live = live
         self._pptrs = [p.data_ptr() for p in live]
         self._live_ids = {id(p) for p in live}
+        # early bucket: the shortest prefix of the arrival order that holds `early_fraction` of the elements -- only when the
+        # hooks really saw every live parameter arrive (otherwise the prefix is not known to be final early: one bucket)
+        self._early_n = self._early_end = 0
+        if self.overlap and self._hooks and lset <= self._seen and len(live) > 1 and 0.0 < self.early_fraction < 1.0:
+            for n, o in enumerate(offs[1:], 1):
+                if o >= self.early_fraction * total:
+                    self._early_n, self._early_end = n, o
+                    break
 
     @property
     def bucket_bytes(self):
@@ -94,30 +182,26 @@ class FlatSGD:
         if self.P is None:
             self._build()
             if self._pending_M is not None:        # exact resume: the momentum goes in BEFORE the first update
-                if self._pending_M.numel() != self.M.numel():
-                    raise RuntimeError('FlatSGD.load_state_dict: the saved momentum does not match this model\'s live parameters')
-                self.M.copy_(self._pending_M)
-                self._pending_M = None
-        src, dst = [], []
+                self._install_momentum(self._pending_M, self._pending_order)
+                self._pending_M = self._pending_order = None
         for p, pp in zip(self._live, self._pptrs):
             if p.data_ptr() != pp:
                 # .half()/.float()/.to(device)/`p.data = ...` after the layout was fixed: the update would go to an orphaned
                 # flat buffer and the model would silently stop learning
                 raise RuntimeError('FlatSGD: a parameter no longer aliases the flat buffer (was the model moved or cast '
                                    'after the first step?); create a new optimizer')
-        for p, gv in zip(self._live, self._gviews):
-            g = p.grad
-            if g is None:
-                raise RuntimeError('FlatSGD: a parameter had a gradient on the first step and has none now')
-            if g.data_ptr() != gv.data_ptr():
-                src.append(g if g.dtype == torch.float32 else g.float())
-                dst.append(gv)
-                p.grad = gv
-        if src:
-            torch._foreach_copy_(dst, src)
+        early, self._work = self._work, None
+        self._arrived = 0
+        self._gather(self._early_n if early is not None else 0, len(self._live))
         scale = 1.0 / self.loss_scale
         if self.sync is not None and self.sync.world > 1:
-            self.sync.all_reduce_flat_(self.G)                      # SUM, in place; the mean's 1/world goes into the update
+            # SUM, in place; the mean's 1/world goes into the update.  With the early prefix already on its way only the
+            # suffix is left (every rank launched the early one: the layout and the hook count are the same everywhere)
+            if early is not None:
+                self.sync.all_reduce_flat_(self.G[self._early_end:])
+                early.wait()
+            else:
+                self.sync.all_reduce_flat_(self.G)
             scale /= self.sync.world
         grp = self.param_groups[0]
         upd = self._update
@@ -154,7 +238,8 @@ class FlatSGD:
 
     def state_dict(self):
         return {'momentum': None if self.M is None else self.M.clone(), 'param_groups': [
-            {k: v for k, v in g.items() if k != 'params'} for g in self.param_groups], 'loss_scale': self.loss_scale}
+            {k: v for k, v in g.items() if k != 'params'} for g in self.param_groups], 'loss_scale': self.loss_scale,
+            'order': None if self._order is None else list(self._order)}     # layout of `momentum` (indices into the parameter list)
 
     def load_state_dict(self, sd):
         for g, s in zip(self.param_groups, sd['param_groups']):
@@ -165,8 +250,30 @@ class FlatSGD:
                 # the flat layout is fixed by the first step's gradients: keep the momentum and put it in place right after
                 # the layout is built, before that step's update (no throw-away step, the resume is exact)
                 self._pending_M = sd['momentum'].detach().clone()
+                self._pending_order = sd.get('order')
             else:
-                self.M.copy_(sd['momentum'])
+                self._install_momentum(sd['momentum'], sd.get('order'))
+
+    def _install_momentum(self, saved, order):
+        """saved flat momentum (laid out in `order`: indices into the parameter list; None = this optimizer's order) -> M"""
+        if order is None or list(order) == list(self._order):
+            if saved.numel() != self.M.numel():
+                raise RuntimeError('FlatSGD.load_state_dict: the saved momentum does not match this model\'s live parameters')
+            self.M.copy_(saved)
+            return
+        if sorted(order) != sorted(self._order):
+            raise RuntimeError('FlatSGD.load_state_dict: the saved momentum covers other parameters than this model\'s live ones')
+        offs, o = {}, 0
+        for i in order:                                  # offsets in the SAVED layout (same 4-element alignment rule)
+            offs[i] = o
+            o += (self.params[i].numel() + 3) // 4 * 4
+        if o != saved.numel():
+            raise RuntimeError('FlatSGD.load_state_dict: the saved momentum does not match this model\'s live parameters')
+        o = 0
+        for i in self._order:
+            n = (self.params[i].numel() + 3) // 4 * 4
+            self.M[o:o + n].copy_(saved[offs[i]:offs[i] + n])
+            o += n
 
 
 def make_optimizer(model, optimizer='SGD', base_lr=0.1, nesterov=True, weight_decay=1e-4, loss_scale=1.0):
