@@ -279,6 +279,31 @@ int istgcn_input_bwd(const float* raw, const int* shift, const double* move, con
 int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
                     float weight_decay, int nesterov, float grad_scale, int* found_inf, void* stream);
 
+/* Bottleneck temporal unit of the "1x1" models (16-bit storage; csrc/bneck_rc.hip), replacing the reference's
+ *   tcn_start -> conv_1x1_start -> tcn_1/2/3 (x mstcn_importance, summed) -> conv_1x1_end -> tcn_end sums
+ *   (net/st_gcn_mstcn_1x1.py:174-213, 258-265; net/st_gcn_mstcn_1x1_deep.py likewise) and its autograd:
+ * istgcn_bneck_in:   y[p][n] = sum_c W(n,c) * pre(x[p][c]) + bias[n]   for n < Wn, zeros for Wn <= n < Wp
+ *                    x: [rows][C], y: [rows][Wp]; W(n,c) = W[n*w_rs + c*w_cs] fp32 (any strides: the transposed use needs
+ *                    no copy); pre = optional [2][C] affine (+ ReLU): the BatchNorm2d + ReLU in front (tcn_start).
+ *                    forward q = Ws u + bs;  backward dyb = We^T dz.
+ * istgcn_bneck_out:  yb[n, out_mul*m + out_off, v, :] = sum_j Wt(j,:,:) q[n, in_mul*m + off0 + j, v, :] + bt    (narrow, saved)
+ *                    z [n, out_mul*m + out_off, v, o] = epi( sum_n' We(o,n') yb[...][n'] + be[o] )
+ *                    for m in [0, Mlog); frames outside [0, Tin) are zeros (the Conv2d padding).  Taps are consecutive
+ *                    input frames: tap j of the launch is weight slice tap_sel[j], Wt(j,r,c) = Wt[tap_sel[j]*wt_ts + r*wt_rs
+ *                    + c*wt_cs]; We(o,n') = We[o*we_rs + n'*we_cs].  ntaps <= 15.  in_mul = 2 only with mode 0.
+ *                    mode 0: epi = identity, stats += sum(z), sum(z^2)            (forward: yb, z and tcn_end's batch sums)
+ *                    mode 1: epi = * [aux*maux[0]+maux[1] > 0], stats += sum(z), sum(z * (aux - maux[2]) * maux[3])
+ *                            (backward through tcn_start: q := dyb, yb := dq, z := d1, aux = the graph conv's output)
+ * Shapes: istgcn_bneck_ok -- V <= 32, C in {64, 128, 256}, 1 <= Wn <= Wp, Wp in {8, 16}, dtype 1 or 2. */
+int istgcn_bneck_ok(int V, int C, int Wn, int Wp, int dtype);
+int istgcn_bneck_in(const void* x, const float* W, long long w_rs, long long w_cs, const float* bias, const float* pre,
+                    int pre_relu, void* y, long long rows, int C, int Wn, int Wp, int dtype, int grid_cap, void* stream);
+int istgcn_bneck_out(const void* q, const float* Wt, long long wt_ts, long long wt_rs, long long wt_cs, const int* tap_sel,
+                     int ntaps, int off0, const float* bt, void* yb, const float* We, long long we_rs, long long we_cs,
+                     const float* be, void* z, const void* aux, const float* maux, double* stats, int stats_rep, int mode,
+                     int NM, int Tin, int Tout, int Mlog, int V, int C, int Wn, int Wp, int in_mul, int out_mul, int out_off,
+                     int dtype, int grid_cap, void* stream);
+
 /* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);
 int istgcn_probe_tr16(const void* src, int nelem, const int* lane_byte_off, void* out, void* stream);

@@ -156,6 +156,13 @@ def _pad_bneck(Ws, bs, Wt, bt, We, w, wp):
             None if bt is None else F.pad(bt, (0, p)), F.pad(We, (0, p)))
 
 
+def _bneck_rc(cfg, V, dt):
+    """Do the register-chained bottleneck kernels (csrc/bneck_rc.hip) serve this block?  16-bit storage, <= 15 taps, stride
+    1 or 2, V <= 32, 64 / 128 / 256 wide; `ops.BNECK_RC = False` (ISTGCN_BNECK_RC=0) keeps the generic temporal-conv kernels."""
+    return (ops.BNECK_RC and cfg.ksize <= 15 and cfg.stride in (1, 2) and
+            ops.bneck_ok(V, cfg.cout, cfg.width, _pad_width(cfg.width, dt), dt))
+
+
 _EYE = {}
 
 
@@ -293,13 +300,20 @@ class STGCNBlockFn(torch.autograd.Function):
             # 8- and 16-wide ones).  The narrow tensors are therefore stored with the width padded to whole vectors; the
             # padding channels carry zero weights and biases, so they ARE zeros and change nothing downstream.
             w, wp = cfg.width, _pad_width(cfg.width, dt)
-            Ws_, bs_, Wt_, bt_, We_ = _pad_bneck(Ws, bs, Wt, bt, We, w, wp)
-            ws = ops.pack_tconv_weight(Ws_.view(1, wp, cout), V, [0], 1, dt)
-            q = ops.tconv(g, ws, wp, [0], bias=bs_, pre=coef1[:2].contiguous(), pre_relu=True, Tout=T, Mlog=T)
-            wt = ops.pack_tconv_weight(Wt_, V, taps, in_mul, dt)
-            yb = ops.tconv(q, wt, wp, taps, bias=bt_, Tout=Tz, Mlog=Tz, in_mul=in_mul)
-            we = ops.pack_tconv_weight(We_.view(1, cout, wp), V, [0], 1, dt)
-            z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
+            if _bneck_rc(cfg, V, dt):
+                # 16-bit storage: two register-chained stream kernels (csrc/bneck_rc.hip) -- wide -> narrow, then
+                # narrow -> 15 taps -> narrow (saved) -> wide with the BatchNorm sums; weights read in place, no packs
+                q = ops.bneck_in(g, Ws, wp, bias=bs, pre=coef1[:2].contiguous(), pre_relu=True)
+                yb, z = ops.bneck_out(q, Wt, list(range(len(taps))), taps[0], We, cout, bt=bt, be=be, stats=st2, mode=0,
+                                      Tout=Tz, Mlog=Tz, in_mul=in_mul)
+            else:
+                Ws_, bs_, Wt_, bt_, We_ = _pad_bneck(Ws, bs, Wt, bt, We, w, wp)
+                ws = ops.pack_tconv_weight(Ws_.view(1, wp, cout), V, [0], 1, dt)
+                q = ops.tconv(g, ws, wp, [0], bias=bs_, pre=coef1[:2].contiguous(), pre_relu=True, Tout=T, Mlog=T)
+                wt = ops.pack_tconv_weight(Wt_, V, taps, in_mul, dt)
+                yb = ops.tconv(q, wt, wp, taps, bias=bt_, Tout=Tz, Mlog=Tz, in_mul=in_mul)
+                we = ops.pack_tconv_weight(We_.view(1, cout, wp), V, [0], 1, dt)
+                z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
         coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
                                 clear=True)
         # 3. residual branch
@@ -368,15 +382,32 @@ class STGCNBlockFn(torch.autograd.Function):
             d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b, packed=pk.get('wt_bwd'))
         else:
             w, wp = cfg.width, _pad_width(cfg.width, dt)
-            Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
+            rc = _bneck_rc(cfg, V, dt)
+            if not rc:
+                Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
             dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
             dWe = dWe3.view(cout, wp)[:, :w]
-            dyb = _conv_bwd_data(dz, We_.view(1, cout, wp), 1, 1, Tz, wp, V)
+            if rc:
+                dyb = ops.bneck_in(dz, We.t(), wp)                       # dyb = We^T dz (the transposed view is read in place)
+            else:
+                dyb = _conv_bwd_data(dz, We_.view(1, cout, wp), 1, 1, Tz, wp, V)
             dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t if wp == w else None)
-            dq = _conv_bwd_data(dyb, Wt_, k, s, T, wp, V)
+            if rc:
+                # dq = sum_j Wt_j^T dyb and d1 = [relu mask] Ws^T dq with the BatchNorm-backward sums: one launch per stride
+                # phase, the taps of a phase in ascending order of the dyb frame they read
+                dq = torch.empty((NM, T, V, wp), dtype=dt, device=dz.device)
+                d1 = torch.empty((NM, T, V, cout), dtype=dt, device=dz.device)
+                for phase in range(s):
+                    tl = sorted(ops.conv_taps_bwd(k, s, phase), key=lambda jd: jd[1])
+                    ops.bneck_out(dyb, Wt.transpose(1, 2), [j for j, _ in tl], tl[0][1], Ws.t(), cout, aux=g, maux=coef1,
+                                  stats=st1b, mode=1, Tout=T, Mlog=(T - phase + s - 1) // s, in_mul=1, out_mul=s,
+                                  out_off=phase, yb=dq, z=d1)
+            else:
+                dq = _conv_bwd_data(dyb, Wt_, k, s, T, wp, V)
             dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
             dWs = dWs3.view(wp, cout)[:w]
-            d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
+            if not rc:
+                d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
             if wp != w:
                 dWt, dbt, dbs = dWt[:, :w, :w], dbt[:w], dbs[:w]
         abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True)

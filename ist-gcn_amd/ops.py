@@ -4,6 +4,7 @@ pointers and the current HIP stream of the tensor's device to `libistgcn_hip.so`
 RuntimeError on a non-zero return.  Nothing here computes on the CPU; there is no fallback.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -55,20 +56,20 @@ PROFILE = None
 PROFILE_ONLY = None     # if set: only launches of this entry point are timed (keeps the event overhead off the others)
 
 
-def _call(fn_name, *args, work=None, dev=None):
+def _call(fn_name, *args, work=None, dev=None, family=None):
     """dev: device of the tensors (from _check_dev).  The library launches on the CURRENT HIP device, so when the
     tensors live elsewhere (a model moved with .to('cuda:1') while cuda:0 is current) the call runs under a device
     guard; in the common case (same device) this costs one integer comparison."""
     lib = _lib.load()
     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
-            return _call(fn_name, *args, work=work)
+            return _call(fn_name, *args, work=work, family=family)
     if PROFILE is not None and work is not None and (PROFILE_ONLY is None or PROFILE_ONLY == fn_name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, fn_name)(*args)
         e1.record()
-        PROFILE.append((fn_name, work[0], work[1], e0, e1))
+        PROFILE.append((family or fn_name, work[0], work[1], e0, e1))      # (family: the breakdown row of bench.py)
     else:
         rc = getattr(lib, fn_name)(*args)
     if rc != 0:
@@ -259,6 +260,73 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
           work=(2.0 * NM * Mlog * V * cout * Cin * len(tap_off),
                 float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if (mode == 1 or aux is not None) else 1)) * _esz(x)), dev=dv)
     return out
+
+
+BNECK_RC = os.environ.get('ISTGCN_BNECK_RC', '1') != '0'     # A/B switch: False = the generic temporal-conv kernels
+
+
+def bneck_ok(V, C, Wn, Wp, dtype):
+    """Do the register-chained bottleneck kernels serve this shape (istgcn_bneck_ok)?"""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(_lib.load().istgcn_bneck_ok(int(V), int(C), int(Wn), int(Wp), 1 if dtype == torch.bfloat16 else 2))
+
+
+def bneck_in(x, W, Wp, bias=None, pre=None, pre_relu=False, grid_cap=0):
+    """istgcn_bneck_in: x [..., C] -> [..., Wp] with y[..., n] = sum_c W[n, c] pre(x[..., c]) + bias[n] (n < W.shape[0], zeros
+    above).  W: fp32 [Wn, C], ANY strides (a transposed view is read in place)."""
+    C = x.shape[-1]
+    Wn = W.shape[0]
+    assert x.is_contiguous() and W.shape == (Wn, C) and W.dtype == torch.float32
+    if bias is not None:
+        assert bias.shape == (Wn,) and bias.dtype == torch.float32 and bias.is_contiguous()
+    if pre is not None:
+        assert pre.shape == (2, C) and pre.dtype == torch.float32 and pre.is_contiguous()
+    rows = x.numel() // C
+    y = torch.empty(x.shape[:-1] + (Wp,), dtype=x.dtype, device=x.device)
+    dv = _check_dev(x, bias, pre, y)
+    assert W.device == x.device                              # (strided view: not for _check_dev's contiguity test)
+    _call('istgcn_bneck_in', _ptr(x), _ptr(W), ctypes.c_longlong(W.stride(0)), ctypes.c_longlong(W.stride(1)), _ptr(bias),
+          _ptr(pre), int(bool(pre_relu)), _ptr(y), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(x), grid_cap, _stream(x),
+          work=(2.0 * rows * C * Wn, float(rows) * (C + Wp) * _esz(x)), dev=dv, family='istgcn_tconv')
+    return y
+
+
+def bneck_out(q, Wt, tap_sel, off0, We, C, bt=None, be=None, aux=None, maux=None, stats=None, mode=0, Tout=None, Mlog=None,
+              in_mul=1, out_mul=1, out_off=0, Wn=None, yb=None, z=None, grid_cap=0):
+    """istgcn_bneck_out: q [NM,Tin,V,Wp] -> (yb [NM,Tout,V,Wp], z [NM,Tout,V,C]); include/istgcn.h has the index algebra.
+    Wt: fp32 [k, r, c] weight slices (any strides; tap j of the launch = slice tap_sel[j], its input frame in_mul*m + off0 + j),
+    We: fp32 [C, Wn] (any strides)."""
+    NM, Tin, V, Wp = q.shape
+    assert q.is_contiguous() and Wt.dim() == 3 and Wt.dtype == torch.float32 and We.dtype == torch.float32
+    Wn = We.shape[1] if Wn is None else Wn
+    assert We.shape == (C, Wn) and Wt.shape[1] == Wn and Wt.shape[2] == Wn
+    assert Mlog is not None and Tout is not None
+    if yb is None:
+        yb = torch.empty((NM, Tout, V, Wp), dtype=q.dtype, device=q.device)
+    if z is None:
+        z = torch.empty((NM, Tout, V, C), dtype=q.dtype, device=q.device)
+    assert yb.shape == (NM, Tout, V, Wp) and z.shape == (NM, Tout, V, C) and yb.is_contiguous() and z.is_contiguous()
+    if bt is not None:
+        assert bt.shape == (Wn,) and bt.dtype == torch.float32 and bt.is_contiguous()
+    if be is not None:
+        assert be.shape == (C,) and be.dtype == torch.float32 and be.is_contiguous()
+    if mode == 1:
+        assert aux is not None and aux.shape == z.shape and aux.dtype == q.dtype and aux.is_contiguous()
+        assert maux is not None and maux.shape == (4, C) and maux.dtype == torch.float32 and maux.is_contiguous()
+    if stats is not None:
+        assert stats.dtype == torch.float64 and stats.shape[-2:] == (2, C)
+    dv = _check_dev(q, bt, be, aux, maux, stats, yb, z)
+    assert Wt.device == q.device and We.device == q.device   # (strided views: not for _check_dev's contiguity test)
+    _call('istgcn_bneck_out', _ptr(q), _ptr(Wt), ctypes.c_longlong(Wt.stride(0)), ctypes.c_longlong(Wt.stride(1)),
+          ctypes.c_longlong(Wt.stride(2)), _int_array(tap_sel), len(tap_sel), int(off0), _ptr(bt), _ptr(yb), _ptr(We),
+          ctypes.c_longlong(We.stride(0)), ctypes.c_longlong(We.stride(1)), _ptr(be), _ptr(z), _ptr(aux), _ptr(maux),
+          _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, C, Wn, Wp, in_mul, out_mul,
+          out_off, dtype_code(q), grid_cap, _stream(q),
+          work=(2.0 * NM * Mlog * V * Wn * (Wn * len(tap_sel) + C),
+                float(NM * V) * (min(Tin, Mlog * in_mul) * Wp + Mlog * (Wp + C * (2 if mode == 1 else 1))) * _esz(q)),
+          dev=dv, family='istgcn_tconv')
+    return yb, z
 
 
 def conv_taps_fwd(k, stride):
