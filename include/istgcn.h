@@ -296,6 +296,14 @@ int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long
  *                            (backward through tcn_start: q := dyb, yb := dq, z := d1, aux = the graph conv's output)
  * Shapes: istgcn_bneck_ok -- V <= 32, C in {64, 128, 256}, 1 <= Wn <= Wp, Wp in {8, 16}, dtype 1 or 2. */
 int istgcn_bneck_ok(int V, int C, int Wn, int Wp, int dtype);
+/* istgcn_bneck_wgrad: weight gradients of the two 1x1 convolutions of the chain, accumulated (+=) into fp32 buffers:
+ *   dW(n, c) += sum_p nrw[p][n] * pre(wide[p][c]),  stored [C][Wp] (wide_is_out = 1: conv_1x1_end, wide = dz, nrw = yb)
+ *   or [Wp][C] (wide_is_out = 0: conv_1x1_start, wide = the graph conv's output behind `pre`, nrw = dq);
+ *   db += sum_p wide[p][:] ([C], db_wide = 1) or sum_p nrw[p][:] ([Wp], db_wide = 0); db may be NULL.
+ *   ws: partial-sum workspace of ws_floats floats (one slice per workgroup + the reduce kernel of the other wgrad kernels). */
+int istgcn_bneck_wgrad(const void* wide, const void* nrw, const float* pre, int pre_relu, float* dW, float* db,
+                       int wide_is_out, int db_wide, long long rows, int C, int Wp, int dtype, int grid_cap, float* ws,
+                       long long ws_floats, void* stream);
 int istgcn_bneck_in(const void* x, const float* W, long long w_rs, long long w_cs, const float* bias, const float* pre,
                     int pre_relu, void* y, long long rows, int C, int Wn, int Wp, int dtype, int grid_cap, void* stream);
 int istgcn_bneck_out(const void* q, const float* Wt, long long wt_ts, long long wt_rs, long long wt_cs, const int* tap_sel,

@@ -28,6 +28,7 @@
 // Frames / positions outside a sequence are outside a buffer descriptor: loads return zeros (= the Conv2d zero padding),
 // stores are dropped; no predicated memory operation anywhere (gcn_rc.hpp).
 #include "gcn_rc.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -496,6 +497,227 @@ int bout_T(const BoutParams& P, int in_mul, int mode, int grid_cap, hipStream_t 
   return ISTGCN_EINVAL;
 }
 
+// ======================================================================================================================
+// bneck_wgrad: weight gradients of the two 1x1 convolutions (wide x narrow), a FLAT stream over positions
+//   dW(n, c) = sum_p nrw[p][n] * pre(wide[p][c]),   db = sum_p wide[p][:]  or  sum_p nrw[p][:]
+// Both operands of a contraction over POSITIONS must carry positions on the k axis, but memory has them row-major
+// (channels contiguous).  A row vector is, however, the A operand of a product over channels: one MFMA against an identity
+// fragment delivers the 32-row tile TRANSPOSED in the accumulator layout (channel on the lane, rows in the registers;
+// exact: x * 1.0 in fp32), and that tile converted pairwise is an operand with k = rows -- for BOTH sides, so the
+// contraction chains from two accumulator tiles without a single LDS access or transposed load:
+//   Tn[p][n] = nrw_tile . I          (1 MFMA)      -> A operand (lane = n)
+//   Tw[p][c] = wide_tile . I_s       (2 per tile)  -> B operand (lane = c);  column sums of Tw / Tn = the bias gradients
+//   dW^T... D[n][c] += Tn^T . Tw     (2 k-steps per 32-channel tile)
+// ======================================================================================================================
+struct BwgParams {
+  const void* wide; const void* nrw; const float* pre; float* dW; float* db; float* ws;
+  long long ws_slice, rows;
+  int C, Wp, pre_relu, wide_is_out, db_wide, ntiles;
+};
+
+template <typename T, int S>
+__global__ __launch_bounds__(256, 2) void bneck_wgrad_kernel(const BwgParams P) {
+  using E = Elem<T>;
+  typedef typename E::frag frag_t;
+  constexpr int C = 16 * S, NT = C / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* idl = reinterpret_cast<u32x4*>(smem);                          // [2][64] identity fragments
+  float* pre_l = reinterpret_cast<float*>(smem + 2 * 64 * 16);          // [2][C]
+  float* red = pre_l + 2 * C;                                           // [NT][16][32] dW partial sums, then [C] + [16] bias sums
+  float* redb = red + NT * 16 * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  if (wave < 2) {
+    frag_t f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = E::from_f(16 * wave + 8 * h + e == c ? 1.f : 0.f);
+    idl[wave * 64 + lane] = __builtin_bit_cast(u32x4, f);
+  }
+  for (int i = tid; i < 2 * C; i += 256) pre_l[i] = P.pre ? P.pre[i] : (i < C ? 1.f : 0.f);
+  for (int i = tid; i < NT * 16 * 32 + C + 16; i += 256) red[i] = 0.f;
+  __syncthreads();
+
+  const rsrc_t rw = make_rsrc(P.wide, (unsigned)(P.rows * C * 2));
+  const rsrc_t rn = make_rsrc(P.nrw, (unsigned)(P.rows * P.Wp * 2));
+  const unsigned wl_ = (unsigned)(c * C + 8 * h) * 2u;
+  const unsigned nl_ = 8 * h < P.Wp ? (unsigned)(c * P.Wp + 8 * h) * 2u : OOB;
+  const bool pre = P.pre != nullptr, relu = P.pre_relu != 0;
+  const int nw = gridDim.x * 4;
+
+  f32x16 acc[NT];
+  float dbw[NT], dbn = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    dbw[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  }
+
+  // 256 channels: 128 accumulator registers leave no room for two whole-row register sets -- the row is taken in four
+  // quarters of four k-steps (register sets A / B alternate over the quarters; the narrow tile is loaded with each)
+  constexpr int SH = S > 8 ? 4 : S, NH = S / SH;
+  auto loadt = [&](int tile, int half, u32x4 (&xf)[SH], u32x4& nf) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)tile * (unsigned)(32 * C * 2) + wl_ + (unsigned)(half * SH * 32);
+#pragma unroll
+    for (int s = 0; s < SH; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, base + 32u * s, 0, 0);
+    nf = __builtin_amdgcn_raw_buffer_load_b128(rn, nl_ == OOB ? OOB : (unsigned)tile * (unsigned)(32 * P.Wp * 2) + nl_, 0, 0);
+  };
+  auto work = [&](auto half_c, u32x4 (&xf)[SH], const u32x4& nf) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(half_c)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                             // (keeps the identity-fragment reads inside the loop)
+    f32x16 Tn;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tn[i] = 0.f;
+    mma_kgroup(Tn, __builtin_bit_cast(frag_t, nf), __builtin_bit_cast(frag_t, idl[ln]));
+    u32x4 an[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) an[s2][d] = pack2<T>(Tn[8 * s2 + 2 * d], Tn[8 * s2 + 2 * d + 1]);
+    if constexpr (HALF == 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += Tn[i];
+      dbn += a;
+    }
+#pragma unroll
+    for (int tl = 0; tl < SH / 2; ++tl) {
+      constexpr int T0 = HALF * (SH / 2);
+      __builtin_amdgcn_sched_barrier(0);                     // one channel tile at a time (overlapped tiles spill)
+      f32x16 Tw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tw[i] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int sl = 2 * tl + s2, s = HALF * SH + sl;
+        u32x4 v = xf[sl];
+        if (pre) {
+          const f32x4 sc0 = *reinterpret_cast<const f32x4*>(pre_l + 16 * s + 8 * h), sc1 = *reinterpret_cast<const f32x4*>(pre_l + 16 * s + 8 * h + 4);
+          const f32x4 sh0 = *reinterpret_cast<const f32x4*>(pre_l + C + 16 * s + 8 * h), sh1 = *reinterpret_cast<const f32x4*>(pre_l + C + 16 * s + 8 * h + 4);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            float lo, hi;
+            unpack2<T>(v[d], lo, hi);
+            const float s0 = d < 2 ? sc0[2 * d] : sc1[2 * d - 4], s1 = d < 2 ? sc0[2 * d + 1] : sc1[2 * d - 3];
+            const float t0 = d < 2 ? sh0[2 * d] : sh1[2 * d - 4], t1 = d < 2 ? sh0[2 * d + 1] : sh1[2 * d - 3];
+            lo = fmaf(lo, s0, t0);
+            hi = fmaf(hi, s1, t1);
+            if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            v[d] = pack2<T>(lo, hi);
+          }
+        }
+        mma_kgroup(Tw, __builtin_bit_cast(frag_t, v), __builtin_bit_cast(frag_t, idl[s2 * 64 + ln]));
+      }
+      u32x4 bw[2];
+      float a = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bw[s2][d] = pack2<T>(Tw[8 * s2 + 2 * d], Tw[8 * s2 + 2 * d + 1]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += Tw[i];
+      dbw[T0 + tl] += a;
+      asm volatile("" : "+v"(dbw[T0 + tl]));                 // (the sum is needed at the end only: pinned here, else Tw lives on)
+      mma_kgroup(acc[T0 + tl], __builtin_bit_cast(frag_t, an[0]), __builtin_bit_cast(frag_t, bw[0]));
+      mma_kgroup(acc[T0 + tl], __builtin_bit_cast(frag_t, an[1]), __builtin_bit_cast(frag_t, bw[1]));
+    }
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < P.ntiles) {
+    u32x4 xa[SH], xb[SH], na, nb;
+    loadt(tile, 0, xa, na);
+    if constexpr (NH == 1) {
+      using H0 = std::integral_constant<int, 0>;
+      for (;;) {
+        const int t2 = tile + nw;
+        const bool more = t2 < P.ntiles;
+        loadt(more ? t2 : tile, 0, xb, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        work(H0{}, xa, na);
+        if (!more) break;
+        const int t3 = t2 + nw;
+        const bool more2 = t3 < P.ntiles;
+        loadt(more2 ? t3 : t2, 0, xa, na);
+        __builtin_amdgcn_sched_barrier(0);
+        work(H0{}, xb, nb);
+        if (!more2) break;
+        tile = t3;
+      }
+    } else {
+      static_assert(NH == 1 || NH == 4, "quarters");
+      for (;;) {
+        const int t2 = tile + nw;
+        const bool more = t2 < P.ntiles;
+        loadt(tile, 1, xb, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, 0>{}, xa, na);
+        loadt(tile, NH > 2 ? 2 : 0, xa, na);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, (NH > 1 ? 1 : 0)>{}, xb, nb);
+        loadt(tile, NH > 3 ? 3 : 0, xb, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, (NH > 2 ? 2 : 0)>{}, xa, na);
+        loadt(more ? t2 : tile, 0, xa, na);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, (NH > 3 ? 3 : 0)>{}, xb, nb);
+        if (!more) break;
+        tile = t2;
+      }
+    }
+  }
+
+  // ---- the four waves' sums -> LDS (one wave at a time: each lane owns its slots) -> this workgroup's slice ----
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                         // registers 0..7: narrow channels (i & 3) + 8 (i >> 2) + 4 h < 16
+          const int n = (i & 3) + 8 * (i >> 2) + 4 * h;
+          red[(t * 16 + n) * 32 + c] += acc[t][i];
+        }
+        const float a = dbw[t] + __shfl_xor(dbw[t], 32);
+        if (h == 0) redb[32 * t + c] += a;
+      }
+      const float a = dbn + __shfl_xor(dbn, 32);
+      if (h == 0 && c < 16) redb[C + c] += a;
+    }
+    __syncthreads();
+  }
+  const int n0 = C * P.Wp, n1 = P.db_wide ? C : P.Wp;
+  float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
+  for (int i = tid; i < n0; i += 256) {
+    int n, o;
+    if (P.wide_is_out) { o = i / P.Wp; n = i - o * P.Wp; } else { n = i / C; o = i - n * C; }
+    sl[i] = red[((o >> 5) * 16 + n) * 32 + (o & 31)];
+  }
+  for (int i = tid; i < n1; i += 256) sl[n0 + i] = P.db_wide ? redb[i] : redb[C + i];
+}
+
+extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1, void* stream);
+
+template <typename T, int S>
+int bwg_launch(BwgParams P, int grid_cap, long long ws_floats, hipStream_t stream) {
+  auto kfn = bneck_wgrad_kernel<T, S>;
+  constexpr int C = 16 * S;
+  const size_t lds = (size_t)2 * 64 * 16 + (size_t)2 * C * 4 + (size_t)((C / 32) * 16 * 32 + C + 16) * 4;
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
+  int g = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, 256, lds);
+  if (g > (P.ntiles + 3) / 4) g = (P.ntiles + 3) / 4;
+  if (g < 1) g = 1;
+  const int n0 = C * P.Wp, n1 = P.db_wide ? C : P.Wp;
+  P.ws_slice = n0 + n1;
+  while (g > 1 && (long long)g * P.ws_slice > ws_floats) g >>= 1;
+  if ((long long)g * P.ws_slice > ws_floats) return ISTGCN_EINVAL;
+  ISTGCN_LAUNCH(kfn, dim3(g), dim3(256), lds, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return istgcn_wgrad_reduce(P.ws, P.ws_slice, g, P.dW, n0, P.db, P.db ? n1 : 0, stream);
+}
+
 }  // namespace
 
 // Shapes the two kernels serve (istgcn.h): 16-bit storage, V <= 32, wide side 64 / 128 / 256 channels, narrow side
@@ -550,4 +772,27 @@ extern "C" int istgcn_bneck_out(const void* q, const float* Wt, long long wt_ts,
   for (int j = 0; j < NTAP; ++j) P.tap_sel[j] = j < ntaps ? tap_sel[j] : 0;
   if (dtype == 1) return bout_T<__bf16>(P, in_mul, mode, grid_cap, (hipStream_t)stream);
   return bout_T<_Float16>(P, in_mul, mode, grid_cap, (hipStream_t)stream);
+}
+
+extern "C" int istgcn_bneck_wgrad(const void* wide, const void* nrw, const float* pre, int pre_relu, float* dW, float* db,
+                                  int wide_is_out, int db_wide, long long rows, int C, int Wp, int dtype, int grid_cap,
+                                  float* ws, long long ws_floats, void* stream) {
+  if (!wide || !nrw || !dW || !ws || rows < 0) return ISTGCN_EINVAL;
+  if (!istgcn_bneck_ok(1, C, Wp, Wp, dtype)) return ISTGCN_EINVAL;
+  if (rows * C * 2 >= (1ll << 32) - (1 << 20)) return ISTGCN_EINVAL;
+  if (rows == 0) return ISTGCN_OK;
+  BwgParams P{};
+  P.wide = wide; P.nrw = nrw; P.pre = pre; P.dW = dW; P.db = db; P.ws = ws; P.rows = rows; P.C = C; P.Wp = Wp;
+  P.pre_relu = pre_relu; P.wide_is_out = wide_is_out; P.db_wide = db_wide;
+  P.ntiles = (int)((rows + 31) / 32);
+  hipStream_t st = (hipStream_t)stream;
+#define GO(TT)                                                          \
+  switch (C) {                                                          \
+    case 64: return bwg_launch<TT, 4>(P, grid_cap, ws_floats, st);      \
+    case 128: return bwg_launch<TT, 8>(P, grid_cap, ws_floats, st);     \
+    case 256: return bwg_launch<TT, 16>(P, grid_cap, ws_floats, st);    \
+  }
+  if (dtype == 1) { GO(__bf16) } else { GO(_Float16) }
+#undef GO
+  return ISTGCN_EINVAL;
 }

@@ -385,7 +385,10 @@ class STGCNBlockFn(torch.autograd.Function):
             rc = _bneck_rc(cfg, V, dt)
             if not rc:
                 Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
-            dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
+            if rc:
+                dWe3, dbe = ops.bneck_wgrad(dz, yb, True)              # [cout][wp], [cout]
+            else:
+                dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
             dWe = dWe3.view(cout, wp)[:, :w]
             if rc:
                 dyb = ops.bneck_in(dz, We.t(), wp)                       # dyb = We^T dz (the transposed view is read in place)
@@ -404,7 +407,10 @@ class STGCNBlockFn(torch.autograd.Function):
                                   out_off=phase, yb=dq, z=d1)
             else:
                 dq = _conv_bwd_data(dyb, Wt_, k, s, T, wp, V)
-            dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
+            if rc:
+                dWs3, dbs = ops.bneck_wgrad(g, dq, False, pre=pre1, pre_relu=True)   # [wp][cout], [wp]
+            else:
+                dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
             dWs = dWs3.view(wp, cout)[:w]
             if not rc:
                 d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)

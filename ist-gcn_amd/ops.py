@@ -329,6 +329,26 @@ def bneck_out(q, Wt, tap_sel, off0, We, C, bt=None, be=None, aux=None, maux=None
     return yb, z
 
 
+def bneck_wgrad(wide, nrw, wide_is_out, pre=None, pre_relu=False, want_bias=True, grid_cap=0):
+    """istgcn_bneck_wgrad -> (dW fp32 [C][Wp] (wide_is_out) or [Wp][C], db fp32 [C] (wide_is_out) or [Wp], or None):
+    dW(n, c) = sum_p nrw[p][n] pre(wide[p][c]); the bias gradient is the column sum of the conv's OUTPUT gradient, i.e. of
+    `wide` when the wide tensor is the output side (conv_1x1_end) and of `nrw` otherwise (conv_1x1_start)."""
+    C, Wp = wide.shape[-1], nrw.shape[-1]
+    assert wide.is_contiguous() and nrw.is_contiguous() and wide.dtype == nrw.dtype
+    rows = wide.numel() // C
+    assert nrw.numel() // Wp == rows
+    if pre is not None:
+        assert pre.shape == (2, C) and pre.dtype == torch.float32 and pre.is_contiguous()
+    dW = torch.zeros((C, Wp) if wide_is_out else (Wp, C), dtype=torch.float32, device=wide.device)
+    db = torch.zeros((C if wide_is_out else Wp,), dtype=torch.float32, device=wide.device) if want_bias else None
+    dv = _check_dev(wide, nrw, pre, dW, db)
+    _call('istgcn_bneck_wgrad', _ptr(wide), _ptr(nrw), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db),
+          int(bool(wide_is_out)), int(bool(wide_is_out)), ctypes.c_longlong(rows), C, Wp, dtype_code(wide), grid_cap,
+          _ptr(_wgrad_ws(wide.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(wide),
+          work=(2.0 * rows * C * Wp, float(rows) * (C + Wp) * _esz(wide)), dev=dv, family='istgcn_tconv_wgrad')
+    return dW, db
+
+
 def conv_taps_fwd(k, stride):
     """(tap offsets, in_mul) of a (k,1) Conv2d with padding (k-1)//2: in frame = stride*m + j - pad."""
     pad = (k - 1) // 2

@@ -147,6 +147,35 @@ def test_bneck_out_backward_mode_vs_torch(ops, dt, C, Wn, Wp, stride):
 
 
 @pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
+@pytest.mark.parametrize('C,Wn,Wp', [(64, 8, 8), (128, 11, 16), (256, 16, 16)])
+def test_bneck_wgrad_vs_torch(ops, dt, C, Wn, Wp):
+    """Both weight gradients of the 1x1 convolutions (contraction over positions through two identity-MFMA transposes):
+    dWe[o][n] = sum_p dz[p][o] yb[p][n], dbe = sum_p dz;  dWs[n][c] = sum_p dq[p][n] relu(bn1(g))[p][c], dbs = sum_p dq."""
+    rows = 2 * 37 * 25 + 7
+    wide = _randn(rows, C, seed=1, dt=dt)
+    nrw = _randn(rows, Wp, seed=2, dt=dt)
+    nrw[:, Wn:] = 0
+    coef = torch.stack([_randn(C, seed=4).abs() + 0.5, _randn(C, seed=5)]).contiguous()
+    dW, db = ops.bneck_wgrad(wide, nrw, True)
+    ref = wide.double().t() @ nrw.double()
+    assert dW.shape == (C, Wp) and db.shape == (C,)
+    tol = 2e-5 * rows ** 0.5 * float(ref.abs().max() / rows ** 0.5 + 1.0)
+    assert float((dW.double() - ref).abs().max()) <= tol, float((dW.double() - ref).abs().max())
+    assert float((db.double() - wide.double().sum(0)).abs().max()) <= tol
+    dW2, db2 = ops.bneck_wgrad(wide, nrw, False, pre=coef, pre_relu=True)
+    u = torch.relu(wide.double() * coef[0].double() + coef[1].double()).to(dt).double()      # rounded like the forward operand
+    ref2 = nrw.double().t() @ u
+    assert dW2.shape == (Wp, C) and db2.shape == (Wp,)
+    assert float((dW2.double() - ref2).abs().max()) <= tol, float((dW2.double() - ref2).abs().max())
+    assert float((db2.double() - nrw.double().sum(0)).abs().max()) <= tol
+    # additivity over row shards (every workgroup's slice and the reduce kernel)
+    h = (rows // 2) // 32 * 32 + 5
+    a, _ = ops.bneck_wgrad(wide[:h].contiguous(), nrw[:h].contiguous(), True)
+    b, _ = ops.bneck_wgrad(wide[h:].contiguous(), nrw[h:].contiguous(), True)
+    assert float((a + b - dW).abs().max()) <= tol
+
+
+@pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
 @pytest.mark.parametrize('tag,layout', [('st_gcn_mstcn_1x1', 'openpose'), ('st_gcn_mstcn_1x1_deep', 'ntu-rgb+d')])
 def test_model_new_kernels_vs_generic_kernels(ops, dt, tag, layout):
     """Whole bottleneck models (all widths 8 / 11 -> 16 / 16, both stride-2 blocks), one training step with the
