@@ -301,6 +301,12 @@ int istgcn_bneck_ok(int V, int C, int Wn, int Wp, int dtype);
  *   or [Wp][C] (wide_is_out = 0: conv_1x1_start, wide = the graph conv's output behind `pre`, nrw = dq);
  *   db += sum_p wide[p][:] ([C], db_wide = 1) or sum_p nrw[p][:] ([Wp], db_wide = 0); db may be NULL.
  *   ws: partial-sum workspace of ws_floats floats (one slice per workgroup + the reduce kernel of the other wgrad kernels). */
+/* istgcn_bneck_wgrad_taps: weight gradient of the narrow temporal conv (tcn_1/2/3 pre-summed):
+ *   dW[j][n'][n] += sum_{seq, m, v} dy[seq, m, v, n'] * q[seq, in_mul*m + off0 + j, v, n]   (frames outside [0, Tin): zeros)
+ *   db[n'] += sum dy;  dy: [NM][Tz][V][Wp], q: [NM][Tin][V][Wp], dW: fp32 [ntaps][Wp][Wp], db: fp32 [Wp] or NULL. */
+int istgcn_bneck_wgrad_taps(const void* dy, const void* q, float* dW, float* db, int NM, int Tin, int Tz, int V, int Wp,
+                            int ntaps, int off0, int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats,
+                            void* stream);
 int istgcn_bneck_wgrad(const void* wide, const void* nrw, const float* pre, int pre_relu, float* dW, float* db,
                        int wide_is_out, int db_wide, long long rows, int C, int Wp, int dtype, int grid_cap, float* ws,
                        long long ws_floats, void* stream);

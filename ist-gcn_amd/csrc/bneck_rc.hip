@@ -718,6 +718,165 @@ int bwg_launch(BwgParams P, int grid_cap, long long ws_floats, hipStream_t strea
   return istgcn_wgrad_reduce(P.ws, P.ws_slice, g, P.dW, n0, P.db, P.db ? n1 : 0, stream);
 }
 
+// ======================================================================================================================
+// bneck_wgrad_taps: weight gradient of the narrow temporal conv,  dWt[j][n'][n] += sum_{seq, m, v} dy[m][v][n'] q[IM m + off0 + j][v][n]
+// (+ its bias gradient sum dy).  The frame walk of bneck_out with the ring holding TRANSPOSED frames: a narrow frame
+// (<= 32 rows x <= 16 channels) through two 16x16x32 MFMAs against an identity fragment comes out with the channel on
+// the lane and its 32 positions in eight registers -- converted pairwise, one operand register quad with k = positions,
+// the same size as the raw row vector.  Each new q frame is transposed ONCE when it enters the ring; an output frame then
+// costs one MFMA per tap (K = 32 = the whole frame) into a 4-register accumulator tile per tap.
+// ======================================================================================================================
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ static inline f32x4v mma16(const bf16x8& a, const bf16x8& b, const f32x4v& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ static inline f32x4v mma16(const f16x8& a, const f16x8& b, const f32x4v& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+struct BwtParams {
+  const void* dy; const void* q; float* dW; float* db; float* ws;
+  long long ws_slice;
+  int NM, Tin, Tz, V, Wp, ntaps, off0;
+  int seg, nseg_seq, nseg;
+};
+
+template <typename T, int IM>
+__global__ __launch_bounds__(RC_NTH, 2) void bneck_wgrad_taps_kernel(const BwtParams P) {
+  using E = Elem<T>;
+  typedef typename E::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);               // [NTAP][16][16] + [16]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int V = P.V, Wp = P.Wp;
+  for (int i = tid; i < NTAP * 256 + 16; i += RC_NTH) red[i] = 0.f;
+  // identity fragment (B operand of the transposing product): column n = l16, k = 8 g + e
+  u32x4 idf;
+  {
+    frag_t f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = E::from_f(8 * g + e == l16 ? 1.f : 0.f);
+    idf = __builtin_bit_cast(u32x4, f);
+  }
+  __syncthreads();
+
+  const T* dyg = reinterpret_cast<const T*>(P.dy);
+  const T* qg = reinterpret_cast<const T*>(P.q);
+  const unsigned frm_b = (unsigned)(V * Wp) * 2u;
+  // raw row vectors of a frame: rows l16 (lo) and 16 + l16 (hi), channels 8 g .. 8 g + 7
+  const unsigned lo_off = (l16 < V && 8 * g < Wp) ? (unsigned)(l16 * Wp + 8 * g) * 2u : OOB;
+  const unsigned hi_off = (16 + l16 < V && 8 * g < Wp) ? (unsigned)((16 + l16) * Wp + 8 * g) * 2u : OOB;
+
+  // frame (two raw vectors) -> transposed operand: k slot e of lane group g = position 4 g + (e & 3) + 16 (e >> 2)
+  auto transpose = [&](const u32x4& lo, const u32x4& hi, float& colsum) __attribute__((always_inline)) {
+    f32x4v z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v dl = mma16(__builtin_bit_cast(frag_t, lo), __builtin_bit_cast(frag_t, idf), z);
+    const f32x4v dh = mma16(__builtin_bit_cast(frag_t, hi), __builtin_bit_cast(frag_t, idf), z);
+    colsum += (dl[0] + dl[1]) + (dl[2] + dl[3]) + (dh[0] + dh[1]) + (dh[2] + dh[3]);
+    return u32x4{pack2<T>(dl[0], dl[1]), pack2<T>(dl[2], dl[3]), pack2<T>(dh[0], dh[1]), pack2<T>(dh[2], dh[3])};
+  };
+
+  f32x4v acc[NTAP];
+#pragma unroll
+  for (int j = 0; j < NTAP; ++j) acc[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  float dbs = 0.f, dummy = 0.f;
+
+  const int nwv = gridDim.x * 8;
+  for (int sg = blockIdx.x * 8 + wave8; sg < P.nseg; sg += nwv) {
+    const int n = sg / P.nseg_seq;
+    const int m_lo = (sg - n * P.nseg_seq) * P.seg, m_hi = min(P.Tz, m_lo + P.seg);
+    const rsrc_t rq = make_rsrc(qg + (size_t)n * P.Tin * V * Wp, (unsigned)(P.Tin * V * Wp) * 2u);
+    const T* dyn = dyg + (size_t)n * P.Tz * V * Wp;
+    auto loadq = [&](int f, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+      dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rq, lo_off == OOB ? OOB : (unsigned)f * frm_b + lo_off, 0, 0);
+      dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rq, hi_off == OOB ? OOB : (unsigned)f * frm_b + hi_off, 0, 0);
+    };
+    auto loady = [&](int m, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+      // (frames m >= m_hi: ghost steps -- an empty descriptor, zeros)
+      const rsrc_t ry = make_rsrc(dyn + (size_t)(m < m_hi ? m : 0) * V * Wp, m < m_hi ? frm_b : 0u);
+      dst[0] = __builtin_amdgcn_raw_buffer_load_b128(ry, lo_off, 0, 0);
+      dst[1] = __builtin_amdgcn_raw_buffer_load_b128(ry, hi_off, 0, 0);
+    };
+    u32x4 R[NTAP];
+    u32x4 L0[IM][2], L1[IM][2], L2[IM][2], Y0[2], Y1[2], Y2[2];
+    const int f0 = IM * m_lo + P.off0;
+    {
+      u32x4 tmp[2];
+#pragma unroll
+      for (int e = 0; e < NTAP; ++e) { loadq(f0 + e, tmp); R[e] = transpose(tmp[0], tmp[1], dummy); }
+    }
+#pragma unroll
+    for (int i = 0; i < IM; ++i) { loadq(f0 + IM + NTAP - IM + i, L0[i]); loadq(f0 + 2 * IM + NTAP - IM + i, L1[i]); }
+    loady(m_lo, Y0);
+    loady(m_lo + 1, Y1);
+    auto step = [&](int m, u32x4 (&Lnew)[IM][2], const u32x4 (&Lold)[IM][2], u32x4 (&Ynew)[2], const u32x4 (&Ycur)[2]) __attribute__((always_inline)) {
+      const int fm = IM * m + P.off0;
+#pragma unroll
+      for (int i = 0; i < IM; ++i) loadq(fm + 3 * IM + NTAP - IM + i, Lnew[i]);
+      loady(m + 2, Ynew);
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 ad = transpose(Ycur[0], Ycur[1], dbs);
+#pragma unroll
+      for (int j = 0; j < NTAP; ++j) acc[j] = mma16(__builtin_bit_cast(frag_t, ad), __builtin_bit_cast(frag_t, R[j]), acc[j]);
+#pragma unroll
+      for (int e = 0; e < NTAP - IM; ++e) R[e] = R[e + IM];
+#pragma unroll
+      for (int i = 0; i < IM; ++i) R[NTAP - IM + i] = transpose(Lold[i][0], Lold[i][1], dummy);
+    };
+    for (int m = m_lo; m < m_hi; m += 3) {
+      step(m, L2, L0, Y2, Y0);
+      step(m + 1, L0, L1, Y0, Y1);
+      step(m + 2, L1, L2, Y1, Y2);
+    }
+  }
+
+  // ---- the eight waves' sums -> LDS (one wave at a time) -> this workgroup's slice ----
+  {
+    // column sums of the transposed dy tiles: lane (n' = l16, g) summed its rows; the four lane groups together = all rows
+    dbs += __shfl_xor(dbs, 16);
+    dbs += __shfl_xor(dbs, 32);
+  }
+  for (int w = 0; w < 8; ++w) {
+    if (wave8 == w) {
+#pragma unroll
+      for (int j = 0; j < NTAP; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(j * 16 + 4 * g + i) * 16 + l16] += acc[j][i];     // D: column n = l16, row n' = 4 g + i
+      if (g == 0) red[NTAP * 256 + l16] += dbs;
+    }
+    __syncthreads();
+  }
+  const int n0 = P.ntaps * Wp * Wp;
+  float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
+  for (int i = tid; i < n0; i += RC_NTH) {
+    const int j = i / (Wp * Wp), r = (i / Wp) % Wp, cc = i % Wp;
+    sl[i] = red[(j * 16 + r) * 16 + cc];
+  }
+  for (int i = tid; i < Wp; i += RC_NTH) sl[n0 + i] = red[NTAP * 256 + i];
+}
+
+template <typename T, int IM>
+int bwt_launch(BwtParams P, int grid_cap, long long ws_floats, hipStream_t stream) {
+  auto kfn = bneck_wgrad_taps_kernel<T, IM>;
+  const size_t lds = (size_t)(NTAP * 256 + 16) * 4;
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
+  int g = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, RC_NTH, lds);
+  const long long frames = (long long)P.NM * P.Tz;
+  long long seg = (frames + (long long)g * 8 - 1) / ((long long)g * 8);
+  if (seg < 12) seg = 12;
+  if (seg > P.Tz) seg = P.Tz;
+  P.nseg_seq = (int)((P.Tz + seg - 1) / seg);
+  P.seg = (int)((P.Tz + P.nseg_seq - 1) / P.nseg_seq);
+  P.nseg = P.nseg_seq * P.NM;
+  if (g > (P.nseg + 7) / 8) g = (P.nseg + 7) / 8;
+  if (g < 1) g = 1;
+  const int n0 = P.ntaps * P.Wp * P.Wp, n1 = P.Wp;
+  P.ws_slice = n0 + n1;
+  if ((long long)g * P.ws_slice > ws_floats) return ISTGCN_EINVAL;
+  ISTGCN_LAUNCH(kfn, dim3(g), dim3(RC_NTH), lds, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return istgcn_wgrad_reduce(P.ws, P.ws_slice, g, P.dW, n0, P.db, P.db ? n1 : 0, stream);
+}
+
 }  // namespace
 
 // Shapes the two kernels serve (istgcn.h): 16-bit storage, V <= 32, wide side 64 / 128 / 256 channels, narrow side
@@ -795,4 +954,20 @@ extern "C" int istgcn_bneck_wgrad(const void* wide, const void* nrw, const float
   if (dtype == 1) { GO(__bf16) } else { GO(_Float16) }
 #undef GO
   return ISTGCN_EINVAL;
+}
+
+extern "C" int istgcn_bneck_wgrad_taps(const void* dy, const void* q, float* dW, float* db, int NM, int Tin, int Tz, int V,
+                                       int Wp, int ntaps, int off0, int in_mul, int dtype, int grid_cap, float* ws,
+                                       long long ws_floats, void* stream) {
+  if (!dy || !q || !dW || !ws) return ISTGCN_EINVAL;
+  if (!istgcn_bneck_ok(V, 64, Wp, Wp, dtype)) return ISTGCN_EINVAL;
+  if (ntaps < 1 || ntaps > NTAP || NM < 0 || Tin < 1 || Tz < 0 || (in_mul != 1 && in_mul != 2)) return ISTGCN_EINVAL;
+  if ((long long)Tin * V * Wp * 2 >= (1ll << 30) || (long long)Tz * V * Wp * 2 >= (1ll << 30)) return ISTGCN_EINVAL;
+  if (NM == 0 || Tz == 0) return ISTGCN_OK;
+  BwtParams P{};
+  P.dy = dy; P.q = q; P.dW = dW; P.db = db; P.ws = ws; P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Wp = Wp;
+  P.ntaps = ntaps; P.off0 = off0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) return in_mul == 1 ? bwt_launch<__bf16, 1>(P, grid_cap, ws_floats, st) : bwt_launch<__bf16, 2>(P, grid_cap, ws_floats, st);
+  return in_mul == 1 ? bwt_launch<_Float16, 1>(P, grid_cap, ws_floats, st) : bwt_launch<_Float16, 2>(P, grid_cap, ws_floats, st);
 }

@@ -394,7 +394,10 @@ class STGCNBlockFn(torch.autograd.Function):
                 dyb = ops.bneck_in(dz, We.t(), wp)                       # dyb = We^T dz (the transposed view is read in place)
             else:
                 dyb = _conv_bwd_data(dz, We_.view(1, cout, wp), 1, 1, Tz, wp, V)
-            dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t if wp == w else None)
+            if rc:
+                dWt, dbt = ops.bneck_wgrad_taps(dyb, q, len(taps), taps[0], in_mul=in_mul)    # [k][wp][wp], [wp]
+            else:
+                dWt, dbt = ops.tconv_wgrad(dyb, q, taps, in_mul=in_mul, out=buf_t if wp == w else None)
             if rc:
                 # dq = sum_j Wt_j^T dyb and d1 = [relu mask] Ws^T dq with the BatchNorm-backward sums: one launch per stride
                 # phase, the taps of a phase in ascending order of the dyb frame they read
@@ -416,6 +419,7 @@ class STGCNBlockFn(torch.autograd.Function):
                 d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
             if wp != w:
                 dWt, dbt, dbs = dWt[:, :w, :w], dbt[:w], dbs[:w]
+            # (the register-chained kernels write their own zero-filled gradient buffers; the arena slots stay unused)
         abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True)
         dg = ops.affine2(d1, g, abc1)
         # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in

@@ -349,6 +349,21 @@ def bneck_wgrad(wide, nrw, wide_is_out, pre=None, pre_relu=False, want_bias=True
     return dW, db
 
 
+def bneck_wgrad_taps(dy, q, ntaps, off0, in_mul=1, want_bias=True, grid_cap=0):
+    """istgcn_bneck_wgrad_taps -> (dW fp32 [ntaps][Wp][Wp], db fp32 [Wp] or None): dW[j][n'][n] = sum dy[m][v][n'] q[in_mul m + off0 + j][v][n]."""
+    NM, Tz, V, Wp = dy.shape
+    NM2, Tin, V2, Wp2 = q.shape
+    assert (NM, V, Wp) == (NM2, V2, Wp2) and dy.dtype == q.dtype and dy.is_contiguous() and q.is_contiguous()
+    dW = torch.zeros((ntaps, Wp, Wp), dtype=torch.float32, device=dy.device)
+    db = torch.zeros((Wp,), dtype=torch.float32, device=dy.device) if want_bias else None
+    dv = _check_dev(dy, q, dW, db)
+    _call('istgcn_bneck_wgrad_taps', _ptr(dy), _ptr(q), _ptr(dW), _ptr(db), NM, Tin, Tz, V, Wp, ntaps, int(off0), in_mul,
+          dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dy.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
+          work=(2.0 * NM * Tz * V * Wp * Wp * ntaps, float(NM * V) * (Tz + Tin) * Wp * _esz(dy)), dev=dv,
+          family='istgcn_tconv_wgrad')
+    return dW, db
+
+
 def conv_taps_fwd(k, stride):
     """(tap offsets, in_mul) of a (k,1) Conv2d with padding (k-1)//2: in frame = stride*m + j - pad."""
     pad = (k - 1) // 2

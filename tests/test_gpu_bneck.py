@@ -176,6 +176,32 @@ def test_bneck_wgrad_vs_torch(ops, dt, C, Wn, Wp):
 
 
 @pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
+@pytest.mark.parametrize('Wn,Wp,V,stride', [(8, 8, 25, 1), (11, 16, 25, 2), (16, 16, 18, 1), (8, 8, 18, 2)])
+def test_bneck_wgrad_taps_vs_torch(ops, dt, Wn, Wp, V, stride):
+    """Weight + bias gradient of the narrow 15-tap conv (frames transposed by 16x16x32 identity MFMAs as they enter the
+    register ring) against autograd of F.conv2d in float64 on the same 16-bit tensors."""
+    NM, T, k = 3, 43, 15
+    Tz = (T - 1) // stride + 1
+    q = _randn(NM, T, V, Wp, seed=1, dt=dt)
+    dy = _randn(NM, Tz, V, Wp, seed=2, dt=dt)
+    q[..., Wn:] = 0
+    dy[..., Wn:] = 0
+    taps, in_mul = ops.conv_taps_fwd(k, stride)
+    dW, db = ops.bneck_wgrad_taps(dy, q, k, taps[0], in_mul=in_mul)
+    w4 = torch.zeros(Wp, Wp, k, 1, dtype=torch.float64, device=dev(), requires_grad=True)
+    out = F.conv2d(q.double().permute(0, 3, 1, 2), w4, None, (stride, 1), ((k - 1) // 2, 0))
+    out.backward(dy.double().permute(0, 3, 1, 2))
+    ref = w4.grad[..., 0].permute(2, 0, 1)                       # [k][n'][n]
+    n = NM * Tz * V
+    tol = 3e-5 * n ** 0.5 * (float(ref.abs().max()) / n ** 0.5 + 1.0)
+    assert dW.shape == (k, Wp, Wp) and db.shape == (Wp,)
+    assert float((dW.double() - ref).abs().max()) <= tol, float((dW.double() - ref).abs().max())
+    assert float((db.double() - dy.double().sum((0, 1, 2))).abs().max()) <= tol
+    if Wp > Wn:
+        assert float(dW[:, Wn:].abs().max()) == 0.0 and float(dW[:, :, Wn:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
 @pytest.mark.parametrize('tag,layout', [('st_gcn_mstcn_1x1', 'openpose'), ('st_gcn_mstcn_1x1_deep', 'ntu-rgb+d')])
 def test_model_new_kernels_vs_generic_kernels(ops, dt, tag, layout):
     """Whole bottleneck models (all widths 8 / 11 -> 16 / 16, both stride-2 blocks), one training step with the
