@@ -18,6 +18,7 @@
 // The K accumulator tiles live in registers for the whole walk; flush = per-workgroup partial sums to the workspace +
 // the reduce kernel of tconv_wgrad.hip (or atomics without a workspace).
 #include "gcn_rc.hpp"
+#include <cstdlib>
 
 extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1, void* stream);
 
@@ -33,14 +34,18 @@ struct RcWgParams {
 constexpr int WG_FBT = 4;                 // frames per batch (all frame groups together)
 
 // CT = 32-channel tiles of dy per workgroup block (2 or 4); the block's input side is always 64 channels (two tiles).
-// Waves: (ct, input tile) pairs x FG frame groups, FG = 8 / (2 CT).
+// OT = output tiles a wave owns next to ONE input tile (1 or 2): the aggregated tile XA_k is computed once per wave and
+// frame, so with OT = 2 a frame costs 2K + 2 * 2K + 2 MFMAs for two (output, input) pairs instead of 2 * (4K + 1) -- a
+// quarter of the matrix work of this MFMA-issue-bound kernel -- at 2 * (K + 1) accumulator tiles per wave.
+// Waves: (ct group, input tile) x FG frame groups, FG = 8 / (2 CT / OT).
 // CN != 0: the models' 3-channel first layer -- x rows are 2*CN bytes, read with 16-bit loads into channel vector 0 of
 // the (otherwise zero) 64-channel image.
-template <typename T, int K, int CT, int CN>
+template <typename T, int K, int CT, int CN, int OT>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParams P) {
   using E = Elem<T>;
   typedef typename E::frag frag_t;
-  constexpr int FG = 8 / (2 * CT);
+  constexpr int CTG = CT / OT;                              // wave groups along the output tiles
+  constexpr int FG = 8 / (2 * CTG);
   constexpr int XROW = 64, DROW = 32 * CT;                  // elements per image row
   constexpr int XFRM = 32 * XROW, DFRM = 32 * DROW;         // elements per frame image (32 rows)
   constexpr int BUF = WG_FBT * (XFRM + DFRM);               // elements per buffer
@@ -51,7 +56,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int itl = wave8 & 1, ct = (wave8 >> 1) % CT, fg = (wave8 >> 1) / CT;
+  const int itl = wave8 & 1, ctg = (wave8 >> 1) % CTG, fg = (wave8 >> 1) / CTG;
+  const int ct = ctg * OT;                                  // first output tile of this wave
   const int b = blockIdx.x;
   const int blk = (b >> 3) % P.gy;                          // channel block of this workgroup
   const int grp = (b / (8 * P.gy)) * 8 + (b & 7);
@@ -152,27 +158,37 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
   // x^T (B operand, natural k order): block rows 16s + 8h (+4), columns 32 itl + 16 g1 + 4 (lane&3)
   const int xq = 4 * itl + 2 * g1 + ((lane & 3) >> 1);
   const int xlane = (8 * h + qq) * XROW + ((xq ^ (4 * ((qq >> 1) & 1))) * 8) + 4 * (lane & 1);
-  // dy^T (A operand, chained k order): block rows 16s + 4h (+8), columns 32 ct + 16 g1 + 4 (lane&3)
-  const int dq = 4 * ct + 2 * g1 + ((lane & 3) >> 1);
+  // dy^T (A operand, chained k order): block rows 16s + 4h (+8), columns 32 (ct + o) + 16 g1 + 4 (lane&3)
   const int dsw = CT == 2 ? 4 * ((qq >> 1) & 1) : 4 * qq;
-  const int dlane = WG_FBT * XFRM + (4 * h + qq) * DROW + ((dq ^ dsw) * 8) + 4 * (lane & 1);
+  int dlane[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    const int dq = 4 * (ct + o) + 2 * g1 + ((lane & 3) >> 1);
+    dlane[o] = WG_FBT * XFRM + (4 * h + qq) * DROW + ((dq ^ dsw) * 8) + 4 * (lane & 1);
+  }
 
-  f32x16 acc[K], accS;
+  f32x16 acc[OT][K], accS[OT];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
+  for (int o = 0; o < OT; ++o) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    for (int k = 0; k < K; ++k)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) accS[i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[o][k][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accS[o][i] = 0.f;
+  }
 
   auto frame = [&](const T* bufp, int f) __attribute__((always_inline)) {
     const T* xb = bufp + f * XFRM + xlane;
-    const T* db = bufp + f * DFRM + dlane;
-    frag_t xT[2], dT[2];
+    frag_t xT[2], dT[OT][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       xT[s] = tr_pair<T>(xb + 16 * s * XROW, xb + (16 * s + 4) * XROW);
-      dT[s] = tr_pair<T>(db + 16 * s * DROW, db + (16 * s + 8) * DROW);
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const T* db = bufp + f * DFRM + dlane[o];
+        dT[o][s] = tr_pair<T>(db + 16 * s * DROW, db + (16 * s + 8) * DROW);
+      }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -186,12 +202,18 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int q = 0; q < 4; ++q) xab[s][q] = pack2<T>(XA[8 * s + 2 * q], XA[8 * s + 2 * q + 1]);
-      mma_kgroup(acc[k], dT[0], __builtin_bit_cast(frag_t, xab[0]));
-      mma_kgroup(acc[k], dT[1], __builtin_bit_cast(frag_t, xab[1]));
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        mma_kgroup(acc[o][k], dT[o][0], __builtin_bit_cast(frag_t, xab[0]));
+        mma_kgroup(acc[o][k], dT[o][1], __builtin_bit_cast(frag_t, xab[1]));
+      }
     }
     if (itl == 0) {
-      mma_kgroup(accS, dT[0], __builtin_bit_cast(frag_t, Ip[0]));
-      mma_kgroup(accS, dT[1], __builtin_bit_cast(frag_t, Ip[1]));
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        mma_kgroup(accS[o], dT[o][0], __builtin_bit_cast(frag_t, Ip[0]));
+        mma_kgroup(accS[o], dT[o][1], __builtin_bit_cast(frag_t, Ip[1]));
+      }
     }
   };
 
@@ -217,76 +239,89 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
   }
 
   // ---- flush ----
-  float* red = reinterpret_cast<float*>(smem);               // FG == 2: group 1 hands its sums to group 0 through LDS
-  if constexpr (FG == 2) {
-    const int pw = (wave8 >> 1) % CT * 2 + itl;              // pair index within a frame group
-    if (fg == 1) {
+  float* red = reinterpret_cast<float*>(smem);               // frame groups 1.. hand their sums to group 0 through LDS, one at a time
+  const int pw = ctg * 2 + itl;                              // this wave's slot within a frame group
+  constexpr int SLOT = OT * (K + 1) * 16 * 64;               // floats per slot
+#pragma unroll 1
+  for (int gsrc = 1; gsrc < FG; ++gsrc) {
+    __syncthreads();
+    if (fg == gsrc) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+      for (int o = 0; o < OT; ++o) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[((pw * (K + 1) + k) * 16 + i) * 64 + lane] = acc[k][i];
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) red[((pw * (K + 1) + K) * 16 + i) * 64 + lane] = accS[i];
+          for (int i = 0; i < 16; ++i) red[pw * SLOT + ((o * (K + 1) + k) * 16 + i) * 64 + lane] = acc[o][k][i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[pw * SLOT + ((o * (K + 1) + K) * 16 + i) * 64 + lane] = accS[o][i];
+      }
     }
     __syncthreads();
     if (fg == 0) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+      for (int o = 0; o < OT; ++o) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[k][i] += red[((pw * (K + 1) + k) * 16 + i) * 64 + lane];
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) accS[i] += red[((pw * (K + 1) + K) * 16 + i) * 64 + lane];
+          for (int i = 0; i < 16; ++i) acc[o][k][i] += red[pw * SLOT + ((o * (K + 1) + k) * 16 + i) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accS[o][i] += red[pw * SLOT + ((o * (K + 1) + K) * 16 + i) * 64 + lane];
+      }
     }
   }
   if (fg == 0) {
     const int n0 = K * Cout * Cin;
-    const int crow = cb * 32 * CT + 32 * ct, icol = ib * 64 + 32 * itl + c;
+    const int icol = ib * 64 + 32 * itl + c;
     const bool col_ok = icol < Cin;                           // (the 3-channel first layer: 3 of the 64 columns exist)
-    if (P.ws) {
-      float* sl = P.ws + (size_t)grp * P.ws_slice;
-      if (col_ok) {
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+    for (int o = 0; o < OT; ++o) {
+      const int crow = cb * 32 * CT + 32 * (ct + o);
+      if (P.ws) {
+        float* sl = P.ws + (size_t)grp * P.ws_slice;
+        if (col_ok) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-            sl[((size_t)k * Cout + crow + r) * Cin + icol] = acc[k][i];
-          }
-      }
-      if (itl == 0 && ib == 0 && P.S && c < V) {
+          for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-          sl[n0 + c * Cout + crow + r] = accS[i];
+            for (int i = 0; i < 16; ++i) {
+              const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+              sl[((size_t)k * Cout + crow + r) * Cin + icol] = acc[o][k][i];
+            }
         }
-      }
-    } else {
-      if (col_ok) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
+        if (itl == 0 && ib == 0 && P.S && c < V) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-            atomicAdd(P.dW + ((size_t)k * Cout + crow + r) * Cin + icol, acc[k][i]);
+            sl[n0 + c * Cout + crow + r] = accS[o][i];
           }
-      }
-      if (itl == 0 && ib == 0 && P.S && c < V) {
+        }
+      } else {
+        if (col_ok) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-          atomicAdd(P.S + c * Cout + crow + r, accS[i]);
+          for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+              atomicAdd(P.dW + ((size_t)k * Cout + crow + r) * Cin + icol, acc[o][k][i]);
+            }
+        }
+        if (itl == 0 && ib == 0 && P.S && c < V) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(P.S + c * Cout + crow + r, accS[o][i]);
+          }
         }
       }
     }
   }
 }
 
-template <typename T, int K, int CT, int CN = 0>
+template <typename T, int K, int CT, int CN = 0, int OT = 1>
 int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
-  auto kfn = gcn_rc_wgrad_kernel<T, K, CT, CN>;
-  constexpr int FG = 8 / (2 * CT);
+  auto kfn = gcn_rc_wgrad_kernel<T, K, CT, CN, OT>;
+  constexpr int FG = 8 / (2 * (CT / OT));
   size_t lds = (size_t)2 * WG_FBT * (32 * 64 + 32 * 32 * CT) * 2 + (size_t)K * 32 * 32 * 4;
-  const size_t redb = FG == 2 ? (size_t)2 * CT * (K + 1) * 16 * 64 * 4 : 0;
+  const size_t redb = FG >= 2 ? (size_t)2 * (CT / OT) * OT * (K + 1) * 16 * 64 * 4 : 0;
   if (redb > lds) lds = redb;
   if (lds > 160 * 1024) return ISTGCN_EINVAL;
   static std::atomic<unsigned long long> optin{0};
@@ -318,6 +353,15 @@ int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
 template <typename T, int K>
 int rc_wg_ct(const RcWgParams& P, int grid_cap, hipStream_t stream) {
   if (P.Cin == 3) return rc_wg_launch<T, K, 2, 3>(P, grid_cap, stream);
+  // two output tiles per wave where the flush image of a frame group fits LDS (K <= 3); ISTGCN_GWG_OT=1: one (A/B timing)
+  const char* e = getenv("ISTGCN_GWG_OT");
+  const bool ot2 = K <= 3 && !(e && atoi(e) == 1);
+  if constexpr (K <= 3) {
+    if (ot2) {
+      if (P.Cout % 128 == 0) return rc_wg_launch<T, K, 4, 0, 2>(P, grid_cap, stream);
+      return rc_wg_launch<T, K, 2, 0, 2>(P, grid_cap, stream);
+    }
+  }
   if (P.Cout % 128 == 0) return rc_wg_launch<T, K, 4>(P, grid_cap, stream);
   return rc_wg_launch<T, K, 2>(P, grid_cap, stream);
 }
