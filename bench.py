@@ -42,13 +42,15 @@ MODELS = {
 FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit GEMM)',
           'istgcn_tconv_wgrad': 'tconv_wgrad', 'istgcn_gcn_fwd': 'gcn_fwd (graph conv fwd + data-grad)',
           'istgcn_gcn_wgrad': 'gcn_wgrad', 'istgcn_gcn_bwd_data': 'gcn_bwd_data (graph conv data + adjacency gradient)', 'istgcn_block_out_fwd': 'block_out_fwd', 'istgcn_block_out_bwd': 'block_out_bwd',
-          'istgcn_affine2': 'bn_bwd_apply'}
+          'istgcn_affine2': 'bn_bwd_apply',
+          'istgcn_bneck': 'bneck_in + bneck_out (bottleneck chain fwd + data-grad, register-chained streams)',
+          'istgcn_bneck_wgrad': 'bneck_wgrad (+ taps: bottleneck weight gradients)'}
 
 
 PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
            'istgcn_gcn_bwd_data': 'gcn_rc_bwd_kernel', 'istgcn_gcn_wgrad': 'gcn_rc_wgrad_kernel',
            'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
-           'istgcn_affine2': 'affine2_kernel'}
+           'istgcn_affine2': 'affine2_kernel', 'istgcn_bneck': 'bneck_in/out kernels', 'istgcn_bneck_wgrad': 'bneck_wgrad kernels'}
 # BASELINE.json configs[i-1] -> (model, storage type, clips per GPU): the reference's own arithmetic per config (fp32 for
 # configs 1/3/4 -- SURVEY 8a; config 2 bf16, config 5 fp16); --dtype / --batch on the command line override.
 CONFIGS = {1: ('st_gcnold', 'f32', 2), 2: ('st_gcn_msgcn', 'bf16', 64), 3: ('st_gcn_mstcn_1x1', 'f32', 256),
@@ -313,6 +315,9 @@ def main():
                                    'dropout 0.5, random-init weights' % (args.model, T, V, B),
                        'launch': 'fwd+bwd replayed from one hipGraph; all-reduce + SGD eager' if use_graph else 'eager',
                        'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
+                       'exchange': None if world == 1 else {
+                           'bucket_bytes': opt.bucket_bytes, 'early_bucket_bytes': 4 * getattr(opt, '_early_end', 0),
+                           'early_all_reduces_launched_from_backward': getattr(opt, 'early_launches', 0)},
                        'storage': ('%s activations, fp32 accumulate/params, fp64 BN sums%s' % (
                            args.dtype, ', static loss scale %g' % loss_scale if loss_scale != 1.0 else '')) if half else 'fp32'},
             'roofline': roof, 'final_loss': round(loss_val, 4),

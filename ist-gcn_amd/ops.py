@@ -64,7 +64,7 @@ def _call(fn_name, *args, work=None, dev=None, family=None):
     if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             return _call(fn_name, *args, work=work, family=family)
-    if PROFILE is not None and work is not None and (PROFILE_ONLY is None or PROFILE_ONLY == fn_name):
+    if PROFILE is not None and work is not None and (PROFILE_ONLY is None or PROFILE_ONLY == (family or fn_name)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(lib, fn_name)(*args)
@@ -288,7 +288,7 @@ def bneck_in(x, W, Wp, bias=None, pre=None, pre_relu=False, grid_cap=0):
     assert W.device == x.device                              # (strided view: not for _check_dev's contiguity test)
     _call('istgcn_bneck_in', _ptr(x), _ptr(W), ctypes.c_longlong(W.stride(0)), ctypes.c_longlong(W.stride(1)), _ptr(bias),
           _ptr(pre), int(bool(pre_relu)), _ptr(y), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(x), grid_cap, _stream(x),
-          work=(2.0 * rows * C * Wn, float(rows) * (C + Wp) * _esz(x)), dev=dv, family='istgcn_tconv')
+          work=(2.0 * rows * C * Wn, float(rows) * (C + Wp) * _esz(x)), dev=dv, family='istgcn_bneck')
     return y
 
 
@@ -325,7 +325,7 @@ def bneck_out(q, Wt, tap_sel, off0, We, C, bt=None, be=None, aux=None, maux=None
           out_off, dtype_code(q), grid_cap, _stream(q),
           work=(2.0 * NM * Mlog * V * Wn * (Wn * len(tap_sel) + C),
                 float(NM * V) * (min(Tin, Mlog * in_mul) * Wp + Mlog * (Wp + C * (2 if mode == 1 else 1))) * _esz(q)),
-          dev=dv, family='istgcn_tconv')
+          dev=dv, family='istgcn_bneck')
     return yb, z
 
 
@@ -345,7 +345,7 @@ def bneck_wgrad(wide, nrw, wide_is_out, pre=None, pre_relu=False, want_bias=True
     _call('istgcn_bneck_wgrad', _ptr(wide), _ptr(nrw), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db),
           int(bool(wide_is_out)), int(bool(wide_is_out)), ctypes.c_longlong(rows), C, Wp, dtype_code(wide), grid_cap,
           _ptr(_wgrad_ws(wide.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(wide),
-          work=(2.0 * rows * C * Wp, float(rows) * (C + Wp) * _esz(wide)), dev=dv, family='istgcn_tconv_wgrad')
+          work=(2.0 * rows * C * Wp, float(rows) * (C + Wp) * _esz(wide)), dev=dv, family='istgcn_bneck_wgrad')
     return dW, db
 
 
@@ -360,7 +360,7 @@ def bneck_wgrad_taps(dy, q, ntaps, off0, in_mul=1, want_bias=True, grid_cap=0):
     _call('istgcn_bneck_wgrad_taps', _ptr(dy), _ptr(q), _ptr(dW), _ptr(db), NM, Tin, Tz, V, Wp, ntaps, int(off0), in_mul,
           dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dy.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
           work=(2.0 * NM * Tz * V * Wp * Wp * ntaps, float(NM * V) * (Tz + Tin) * Wp * _esz(dy)), dev=dv,
-          family='istgcn_tconv_wgrad')
+          family='istgcn_bneck_wgrad')
     return dW, db
 
 

@@ -13,6 +13,10 @@ OUT = os.path.join(ROOT, 'gpurun_out')
 
 def fam(name):
     n = name.replace('(anonymous namespace)::', '')
+    if 'bneck_wgrad' in n:
+        return 'bneck_wgrad kernels'
+    if 'bneck_in_kernel' in n or 'bneck_out_kernel' in n:
+        return 'bneck_in/out kernels'
     for key in ('gcn_rc_fwd_kernel', 'gcn_rc_bwd_kernel', 'gcn_rc_wgrad_kernel', 'twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
                 'block_out_bwd_kernel', 'affine2_kernel', 'bn_finalize_kernel', 'bn_bwd_coef_kernel', 'fold_fwd_kernel', 'fold_bwd_kernel',
                 'sgd_step_kernel', 'pool_fwd_kernel', 'pool_bwd_kernel', 'tcn_fold_fwd_kernel', 'tcn_fold_bwd_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
