@@ -301,6 +301,16 @@ int istgcn_bneck_ok(int V, int C, int Wn, int Wp, int dtype);
  *   or [Wp][C] (wide_is_out = 0: conv_1x1_start, wide = the graph conv's output behind `pre`, nrw = dq);
  *   db += sum_p wide[p][:] ([C], db_wide = 1) or sum_p nrw[p][:] ([Wp], db_wide = 0); db may be NULL.
  *   ws: partial-sum workspace of ws_floats floats (one slice per workgroup + the reduce kernel of the other wgrad kernels). */
+/* istgcn_bneck_bwd_in: the backward pass INTO the chain as ONE stream (C = 64 / 128: istgcn_bneck_bwd_in_ok) -- the
+ * elementwise half of tcn_end's BatchNorm backward, dz = abc[0][c]*dropmask*dres + abc[1][c]*z + abc[2][c] (what
+ * istgcn_affine2 writes as a tensor; same Philox stream: p_drop, seed, seed_epoch), formed in registers and rounded to the
+ * storage type, then dyb = W dz (W(n,c) = W[n*w_rs + c*w_cs]: pass We^T), dW [C][Wp] += dz^T yb, db [C] += sum dz.
+ * Replaces istgcn_affine2 + istgcn_bneck_in + istgcn_bneck_wgrad (5 passes over wide tensors) by 2. */
+int istgcn_bneck_bwd_in_ok(int C, int Wn, int Wp, int dtype);
+int istgcn_bneck_bwd_in(const void* dres, const void* z, const float* abc, float p_drop, unsigned long long seed,
+                        const unsigned long long* seed_epoch, const void* yb, const float* W, long long w_rs, long long w_cs,
+                        void* dyb, float* dW, float* db, long long rows, int C, int Wn, int Wp, int dtype, int grid_cap,
+                        float* ws, long long ws_floats, void* stream);
 /* istgcn_bneck_wgrad_taps: weight gradient of the narrow temporal conv (tcn_1/2/3 pre-summed):
  *   dW[j][n'][n] += sum_{seq, m, v} dy[seq, m, v, n'] * q[seq, in_mul*m + off0 + j, v, n]   (frames outside [0, Tin): zeros)
  *   db[n'] += sum dy;  dy: [NM][Tz][V][Wp], q: [NM][Tin][V][Wp], dW: fp32 [ntaps][Wp][Wp], db: fp32 [Wp] or NULL. */

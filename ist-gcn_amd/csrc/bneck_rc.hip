@@ -28,6 +28,7 @@
 // Frames / positions outside a sequence are outside a buffer descriptor: loads return zeros (= the Conv2d zero padding),
 // stores are dropped; no predicated memory operation anywhere (gcn_rc.hpp).
 #include "gcn_rc.hpp"
+#include "dropout.hpp"
 #include <type_traits>
 
 namespace {
@@ -877,6 +878,243 @@ int bwt_launch(BwtParams P, int grid_cap, long long ws_floats, hipStream_t strea
   return istgcn_wgrad_reduce(P.ws, P.ws_slice, g, P.dW, n0, P.db, P.db ? n1 : 0, stream);
 }
 
+// ======================================================================================================================
+// bneck_bwd_in: the backward pass INTO the chain in one stream (64 / 128 channels):
+//   dz  = a[c] * dropmask * dres + b[c] * z + c[c]      the elementwise half of tcn_end's BatchNorm backward (what
+//                                                       istgcn_affine2 would write as a tensor), formed in registers from
+//                                                       the two row vectors, rounded to the storage type like the tensor was
+//   dyb = We^T dz                                       (bneck_in's product: dz vectors as the B operand)
+//   dWe += dz^T yb,  dbe += sum dz                      (bneck_wgrad's products: dz vectors transposed by identity MFMAs)
+// Replaces affine2 (3 wide passes) + bneck_in (1) + bneck_wgrad (1) by 2 wide passes.  The dropout mask is regenerated
+// with the forward's Philox stream (dropout.hpp) per 8-channel vector.  Rows are taken in passes of four k-steps
+// (64 channels) with two register sets alternating; the narrow accumulator of dyb lives across the passes of a tile.
+// ======================================================================================================================
+struct BbiParams {
+  const void* dres; const void* z; const float* abc; const void* nrw; const float* W; void* dyb; float* dW; float* db; float* ws;
+  long long w_rs, w_cs, ws_slice, rows;
+  DropCfg D;
+  int C, Wn, Wp, ntiles;
+};
+
+template <typename T, int S>
+__global__ __launch_bounds__(256, 2) void bneck_bwd_in_kernel(const BbiParams P) {
+  using E = Elem<T>;
+  typedef typename E::frag frag_t;
+  constexpr int C = 16 * S, NT = C / 32, SH = 4, NH = S / SH;
+  static_assert(NH == 1 || NH == 2, "64 or 128 channels");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* idl = reinterpret_cast<u32x4*>(smem);                          // [2][64] identity fragments
+  u32x4* wl = idl + 2 * 64;                                             // [S][64] A fragments of W (dyb = W dz)
+  float* abc_l = reinterpret_cast<float*>(wl + S * 64);                 // [3][C]
+  float* red = abc_l + 3 * C;                                           // [NT][16][32] + [C] + [16]; setup: [16][C] copy of W
+  float* redb = red + NT * 16 * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  uint32_t dk0, dk1;
+  drop_key(P.D, dk0, dk1);
+  const bool drop_on = P.D.on != 0;
+  if (wave < 2) {
+    frag_t f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = E::from_f(16 * wave + 8 * h + e == c ? 1.f : 0.f);
+    idl[wave * 64 + lane] = __builtin_bit_cast(u32x4, f);
+  }
+  for (int i = tid; i < 3 * C; i += 256) abc_l[i] = P.abc[i];
+  for (int i = tid; i < 16 * C; i += 256) {
+    const int n = i / C, cc = i - n * C;
+    red[i] = n < P.Wn ? P.W[n * P.w_rs + cc * P.w_cs] : 0.f;
+  }
+  __syncthreads();
+  for (int s = wave; s < S; s += 4) {
+    frag_t f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = E::from_f(c < 16 ? red[c * C + 16 * s + 8 * h + j] : 0.f);
+    wl[s * 64 + lane] = __builtin_bit_cast(u32x4, f);
+  }
+  __syncthreads();
+  for (int i = tid; i < NT * 16 * 32 + C + 16; i += 256) red[i] = 0.f;
+  __syncthreads();
+
+  const rsrc_t rd = make_rsrc(P.dres, (unsigned)(P.rows * C * 2));
+  const rsrc_t rz = make_rsrc(P.z, (unsigned)(P.rows * C * 2));
+  const rsrc_t rn = make_rsrc(P.nrw, (unsigned)(P.rows * P.Wp * 2));
+  const rsrc_t ry = make_rsrc(P.dyb, (unsigned)(P.rows * P.Wp * 2));
+  const unsigned wl_ = (unsigned)(c * C + 8 * h) * 2u;
+  const unsigned nl_ = 8 * h < P.Wp ? (unsigned)(c * P.Wp + 8 * h) * 2u : OOB;
+  const unsigned yl = (unsigned)(c * P.Wp + 4 * h) * 2u;
+  const bool wide16 = P.Wp == 16;
+  const int nw = gridDim.x * 4;
+
+  f32x16 acc[NT], accy;
+  float dbw[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    dbw[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  }
+
+  auto loadt = [&](int tile, int q, u32x4 (&df)[SH], u32x4 (&zf)[SH], u32x4& nf) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)tile * (unsigned)(32 * C * 2) + wl_ + (unsigned)(q * SH * 32);
+#pragma unroll
+    for (int s = 0; s < SH; ++s) {
+      df[s] = __builtin_amdgcn_raw_buffer_load_b128(rd, base + 32u * s, 0, 0);
+      zf[s] = __builtin_amdgcn_raw_buffer_load_b128(rz, base + 32u * s, 0, 0);
+    }
+    nf = __builtin_amdgcn_raw_buffer_load_b128(rn, nl_ == OOB ? OOB : (unsigned)tile * (unsigned)(32 * P.Wp * 2) + nl_, 0, 0);
+  };
+  auto work = [&](auto q_c, int tile, u32x4 (&df)[SH], u32x4 (&zf)[SH], const u32x4& nf) __attribute__((always_inline)) {
+    constexpr int Q = decltype(q_c)::value;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const long long row = (long long)tile * 32 + c;
+    const bool rowok = row < P.rows;                          // (rows past the tensor: dz must be zero, not c[c])
+    f32x16 Tn;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tn[i] = 0.f;
+    mma_kgroup(Tn, __builtin_bit_cast(frag_t, nf), __builtin_bit_cast(frag_t, idl[ln]));
+    u32x4 an[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) an[s2][d] = pack2<T>(Tn[8 * s2 + 2 * d], Tn[8 * s2 + 2 * d + 1]);
+    if constexpr (Q == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accy[i] = 0.f;
+    }
+#pragma unroll
+    for (int tl = 0; tl < SH / 2; ++tl) {
+      constexpr int T0 = Q * (SH / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 Tw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Tw[i] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int sl = 2 * tl + s2, s = Q * SH + sl;
+        const int ch0 = 16 * s + 8 * h;
+        float m[8];
+        if (drop_on) drop_scales<8>(m, (size_t)(row * C + ch0), P.D.thr, P.D.inv_keep, dk0, dk1);
+        u32x4 v;
+#pragma unroll
+        for (int d4 = 0; d4 < 2; ++d4) {
+          const f32x4 ca = *reinterpret_cast<const f32x4*>(abc_l + ch0 + 4 * d4), cb = *reinterpret_cast<const f32x4*>(abc_l + C + ch0 + 4 * d4);
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(abc_l + 2 * C + ch0 + 4 * d4);
+#pragma unroll
+          for (int d2 = 0; d2 < 2; ++d2) {
+            const int d = 2 * d4 + d2;
+            float g0, g1, z0, z1;
+            unpack2<T>(df[sl][d], g0, g1);
+            unpack2<T>(zf[sl][d], z0, z1);
+            if (drop_on) { g0 *= m[2 * d]; g1 *= m[2 * d + 1]; }
+            // (the same operation order as affine2_kernel: (d * mask) * a, then + x * b + c)
+            float r0 = g0 * ca[2 * d2] + (z0 * cb[2 * d2] + cc[2 * d2]);
+            float r1 = g1 * ca[2 * d2 + 1] + (z1 * cb[2 * d2 + 1] + cc[2 * d2 + 1]);
+            v[d] = rowok ? pack2<T>(r0, r1) : 0u;
+          }
+        }
+        mma_kgroup(accy, __builtin_bit_cast(frag_t, wl[s * 64 + ln]), __builtin_bit_cast(frag_t, v));
+        mma_kgroup(Tw, __builtin_bit_cast(frag_t, v), __builtin_bit_cast(frag_t, idl[s2 * 64 + ln]));
+      }
+      u32x4 bw[2];
+      float a = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bw[s2][d] = pack2<T>(Tw[8 * s2 + 2 * d], Tw[8 * s2 + 2 * d + 1]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += Tw[i];
+      dbw[T0 + tl] += a;
+      asm volatile("" : "+v"(dbw[T0 + tl]));
+      mma_kgroup(acc[T0 + tl], __builtin_bit_cast(frag_t, an[0]), __builtin_bit_cast(frag_t, bw[0]));
+      mma_kgroup(acc[T0 + tl], __builtin_bit_cast(frag_t, an[1]), __builtin_bit_cast(frag_t, bw[1]));
+    }
+    if constexpr (Q == NH - 1) {
+      const unsigned yb = (unsigned)tile * (unsigned)(32 * P.Wp * 2) + yl;
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<T>(accy[0], accy[1]), pack2<T>(accy[2], accy[3])}, ry, yb, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2<T>(accy[4], accy[5]), pack2<T>(accy[6], accy[7])}, ry, wide16 ? yb + 16u : OOB, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < P.ntiles) {
+    u32x4 da[SH], za[SH], db_[SH], zb[SH], na, nb;
+    loadt(tile, 0, da, za, na);
+    for (;;) {
+      const int t2 = tile + nw;
+      const bool more = t2 < P.ntiles;
+      if constexpr (NH == 1) {
+        loadt(more ? t2 : tile, 0, db_, zb, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, 0>{}, tile, da, za, na);
+        if (!more) break;
+        const int t3 = t2 + nw;
+        const bool more2 = t3 < P.ntiles;
+        loadt(more2 ? t3 : t2, 0, da, za, na);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, 0>{}, t2, db_, zb, nb);
+        if (!more2) break;
+        tile = t3;
+      } else {
+        loadt(tile, 1, db_, zb, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, 0>{}, tile, da, za, na);
+        loadt(more ? t2 : tile, 0, da, za, na);
+        __builtin_amdgcn_sched_barrier(0);
+        work(std::integral_constant<int, NH - 1>{}, tile, db_, zb, nb);
+        if (!more) break;
+        tile = t2;
+      }
+    }
+  }
+
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int n = (i & 3) + 8 * (i >> 2) + 4 * h;
+          red[(t * 16 + n) * 32 + c] += acc[t][i];
+        }
+        const float a = dbw[t] + __shfl_xor(dbw[t], 32);
+        if (h == 0) redb[32 * t + c] += a;
+      }
+    }
+    __syncthreads();
+  }
+  const int n0 = C * P.Wp;
+  float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
+  for (int i = tid; i < n0; i += 256) {
+    const int o = i / P.Wp, n = i - o * P.Wp;
+    sl[i] = red[((o >> 5) * 16 + n) * 32 + (o & 31)];
+  }
+  for (int i = tid; i < C; i += 256) sl[n0 + i] = redb[i];
+}
+
+template <typename T, int S>
+int bbi_launch(BbiParams P, int grid_cap, long long ws_floats, hipStream_t stream) {
+  auto kfn = bneck_bwd_in_kernel<T, S>;
+  constexpr int C = 16 * S;
+  size_t red_b = (size_t)((C / 32) * 16 * 32 + C + 16) * 4;
+  if (red_b < (size_t)16 * C * 4) red_b = (size_t)16 * C * 4;
+  const size_t lds = (size_t)(2 + S) * 64 * 16 + (size_t)3 * C * 4 + red_b;
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
+  int g = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, 256, lds);
+  if (g > (P.ntiles + 3) / 4) g = (P.ntiles + 3) / 4;
+  if (g < 1) g = 1;
+  const int n0 = C * P.Wp, n1 = C;
+  P.ws_slice = n0 + n1;
+  while (g > 1 && (long long)g * P.ws_slice > ws_floats) g >>= 1;
+  if ((long long)g * P.ws_slice > ws_floats) return ISTGCN_EINVAL;
+  ISTGCN_LAUNCH(kfn, dim3(g), dim3(256), lds, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  return istgcn_wgrad_reduce(P.ws, P.ws_slice, g, P.dW, n0, P.db, P.db ? n1 : 0, stream);
+}
+
 }  // namespace
 
 // Shapes the two kernels serve (istgcn.h): 16-bit storage, V <= 32, wide side 64 / 128 / 256 channels, narrow side
@@ -970,4 +1208,25 @@ extern "C" int istgcn_bneck_wgrad_taps(const void* dy, const void* q, float* dW,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 1) return in_mul == 1 ? bwt_launch<__bf16, 1>(P, grid_cap, ws_floats, st) : bwt_launch<__bf16, 2>(P, grid_cap, ws_floats, st);
   return in_mul == 1 ? bwt_launch<_Float16, 1>(P, grid_cap, ws_floats, st) : bwt_launch<_Float16, 2>(P, grid_cap, ws_floats, st);
+}
+
+extern "C" int istgcn_bneck_bwd_in_ok(int C, int Wn, int Wp, int dtype) {
+  return istgcn_bneck_ok(1, C, Wn, Wp, dtype) && (C == 64 || C == 128);
+}
+
+extern "C" int istgcn_bneck_bwd_in(const void* dres, const void* z, const float* abc, float p_drop, unsigned long long seed,
+                                   const unsigned long long* seed_epoch, const void* yb, const float* W, long long w_rs,
+                                   long long w_cs, void* dyb, float* dW, float* db, long long rows, int C, int Wn, int Wp,
+                                   int dtype, int grid_cap, float* ws, long long ws_floats, void* stream) {
+  if (!dres || !z || !abc || !yb || !W || !dyb || !dW || !ws || rows < 0 || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
+  if (!istgcn_bneck_bwd_in_ok(C, Wn, Wp, dtype)) return ISTGCN_EINVAL;
+  if (rows * C * 2 >= (1ll << 32) - (1 << 20)) return ISTGCN_EINVAL;
+  if (rows == 0) return ISTGCN_OK;
+  BbiParams P{};
+  P.dres = dres; P.z = z; P.abc = abc; P.nrw = yb; P.W = W; P.w_rs = w_rs; P.w_cs = w_cs; P.dyb = dyb; P.dW = dW; P.db = db;
+  P.ws = ws; P.rows = rows; P.C = C; P.Wn = Wn; P.Wp = Wp; P.D = make_drop(p_drop, seed, seed_epoch);
+  P.ntiles = (int)((rows + 31) / 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) return C == 64 ? bbi_launch<__bf16, 4>(P, grid_cap, ws_floats, st) : bbi_launch<__bf16, 8>(P, grid_cap, ws_floats, st);
+  return C == 64 ? bbi_launch<_Float16, 4>(P, grid_cap, ws_floats, st) : bbi_launch<_Float16, 8>(P, grid_cap, ws_floats, st);
 }

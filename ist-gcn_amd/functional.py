@@ -355,7 +355,11 @@ class STGCNBlockFn(torch.autograd.Function):
         dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True, epoch=cfg.seed_epoch,
                                              relu_mask=rmask)
         abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
-        dz = ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
+        # (bottleneck blocks at 64 / 128 channels in 16-bit storage: dz is never written -- the stream kernel that consumes it
+        #  forms it in registers from dres and z, dropout mask included; ops.BNECK_FUSE_BN = False keeps the separate pass)
+        fuse_in = (cfg.tcn == 'bneck' and ops.BNECK_FUSE_BN and _bneck_rc(cfg, V, dt) and
+                   ops.bneck_bwd_in_ok(cout, cfg.width, _pad_width(cfg.width, dt), dt))
+        dz = None if fuse_in else ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
         taps, in_mul = ops.conv_taps_fwd(k, s)
         pre1 = coef1[:2].contiguous()
@@ -385,12 +389,16 @@ class STGCNBlockFn(torch.autograd.Function):
             rc = _bneck_rc(cfg, V, dt)
             if not rc:
                 Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
-            if rc:
+            if fuse_in:
+                dyb, dWe3, dbe = ops.bneck_bwd_in(dres, z, abc2, yb, We.t(), wp, p_drop=p, seed=seed, epoch=cfg.seed_epoch)
+            elif rc:
                 dWe3, dbe = ops.bneck_wgrad(dz, yb, True)              # [cout][wp], [cout]
             else:
                 dWe3, dbe = ops.tconv_wgrad(dz, yb, [0], in_mul=1)
             dWe = dWe3.view(cout, wp)[:, :w]
-            if rc:
+            if fuse_in:
+                pass
+            elif rc:
                 dyb = ops.bneck_in(dz, We.t(), wp)                       # dyb = We^T dz (the transposed view is read in place)
             else:
                 dyb = _conv_bwd_data(dz, We_.view(1, cout, wp), 1, 1, Tz, wp, V)
@@ -401,8 +409,8 @@ class STGCNBlockFn(torch.autograd.Function):
             if rc:
                 # dq = sum_j Wt_j^T dyb and d1 = [relu mask] Ws^T dq with the BatchNorm-backward sums: one launch per stride
                 # phase, the taps of a phase in ascending order of the dyb frame they read
-                dq = torch.empty((NM, T, V, wp), dtype=dt, device=dz.device)
-                d1 = torch.empty((NM, T, V, cout), dtype=dt, device=dz.device)
+                dq = torch.empty((NM, T, V, wp), dtype=dt, device=dyb.device)
+                d1 = torch.empty((NM, T, V, cout), dtype=dt, device=dyb.device)
                 for phase in range(s):
                     tl = sorted(ops.conv_taps_bwd(k, s, phase), key=lambda jd: jd[1])
                     ops.bneck_out(dyb, Wt.transpose(1, 2), [j for j, _ in tl], tl[0][1], Ws.t(), cout, aux=g, maux=coef1,

@@ -263,6 +263,7 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
 
 
 BNECK_RC = os.environ.get('ISTGCN_BNECK_RC', '1') != '0'     # A/B switch: False = the generic temporal-conv kernels
+BNECK_FUSE_BN = os.environ.get('ISTGCN_BNECK_FUSE_BN', '1') != '0'   # A/B switch: False = affine2 writes dz as a tensor
 
 
 def bneck_ok(V, C, Wn, Wp, dtype):
@@ -362,6 +363,34 @@ def bneck_wgrad_taps(dy, q, ntaps, off0, in_mul=1, want_bias=True, grid_cap=0):
           work=(2.0 * NM * Tz * V * Wp * Wp * ntaps, float(NM * V) * (Tz + Tin) * Wp * _esz(dy)), dev=dv,
           family='istgcn_bneck_wgrad')
     return dW, db
+
+
+def bneck_bwd_in_ok(C, Wn, Wp, dtype):
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(_lib.load().istgcn_bneck_bwd_in_ok(int(C), int(Wn), int(Wp), 1 if dtype == torch.bfloat16 else 2))
+
+
+def bneck_bwd_in(dres, z, abc, yb, W, Wp, p_drop=0.0, seed=0, epoch=None, grid_cap=0):
+    """istgcn_bneck_bwd_in -> (dyb [..., Wp], dW fp32 [C][Wp], db fp32 [C]): dz = abc[0]*dropmask*dres + abc[1]*z + abc[2] formed
+    in registers (never stored), dyb = W dz with W fp32 [Wn, C] (any strides: pass We.t()), dW = dz^T yb, db = sum dz."""
+    C = dres.shape[-1]
+    Wn = W.shape[0]
+    assert dres.is_contiguous() and z.is_contiguous() and yb.is_contiguous() and dres.shape == z.shape and dres.dtype == z.dtype == yb.dtype
+    assert abc.shape == (3, C) and abc.dtype == torch.float32 and abc.is_contiguous()
+    assert W.shape == (Wn, C) and W.dtype == torch.float32 and yb.shape == dres.shape[:-1] + (Wp,)
+    rows = dres.numel() // C
+    dyb = torch.empty(dres.shape[:-1] + (Wp,), dtype=dres.dtype, device=dres.device)
+    dW = torch.zeros((C, Wp), dtype=torch.float32, device=dres.device)
+    db = torch.zeros((C,), dtype=torch.float32, device=dres.device)
+    dv = _check_dev(dres, z, abc, yb, dyb, dW, db)
+    assert W.device == dres.device
+    _call('istgcn_bneck_bwd_in', _ptr(dres), _ptr(z), _ptr(abc), ctypes.c_float(p_drop), ctypes.c_ulonglong(seed),
+          _epoch_ptr(epoch, dres), _ptr(yb), _ptr(W), ctypes.c_longlong(W.stride(0)), ctypes.c_longlong(W.stride(1)),
+          _ptr(dyb), _ptr(dW), _ptr(db), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(dres), grid_cap,
+          _ptr(_wgrad_ws(dres.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dres),
+          work=(4.0 * rows * C * Wp + 4.0 * rows * C, float(rows) * (2 * C + 2 * Wp) * _esz(dres)), dev=dv, family='istgcn_bneck')
+    return dyb, dW, db
 
 
 def conv_taps_fwd(k, stride):

@@ -202,6 +202,33 @@ def test_bneck_wgrad_taps_vs_torch(ops, dt, Wn, Wp, V, stride):
 
 
 @pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
+@pytest.mark.parametrize('C,Wn,Wp', [(64, 8, 8), (128, 11, 16)])
+@pytest.mark.parametrize('p', [0.0, 0.5])
+def test_bneck_bwd_in_equals_affine2_then_in_then_wgrad(ops, dt, C, Wn, Wp, p):
+    """The fused backward input (BatchNorm-backward elementwise half + dropout mask formed in registers) against the three
+    launches it replaces, on the same inputs and the same Philox seed: dz is rounded to the storage type in both, so dyb
+    agrees to a rounding of the result and the weight / bias gradients to fp32 summation noise."""
+    rows = 2 * 29 * 25 + 9
+    dres = _randn(rows, C, seed=1, dt=dt)
+    z = _randn(rows, C, seed=2, dt=dt)
+    yb = _randn(rows, Wp, seed=3, dt=dt)
+    yb[:, Wn:] = 0
+    abc = torch.stack([_randn(C, seed=4).abs() + 0.3, _randn(C, seed=5) * 0.2, _randn(C, seed=6) * 0.05]).contiguous()
+    We = _randn(C, Wn, seed=7, scale=C ** -0.5)
+    seed = 1234567
+    dz = ops.affine2(dres, z, abc, p, seed)
+    dyb0 = ops.bneck_in(dz, We.t(), Wp)
+    dW0, db0 = ops.bneck_wgrad(dz, yb, True)
+    dyb1, dW1, db1 = ops.bneck_bwd_in(dres, z, abc, yb, We.t(), Wp, p_drop=p, seed=seed)
+    _close(dyb1, dyb0, dt, 'dyb', extra=1.0)
+    tol = 2e-5 * rows ** 0.5 * (float(dW0.abs().max()) / rows ** 0.5 + 1.0)
+    assert float((dW1 - dW0).abs().max()) <= tol and float((db1 - db0).abs().max()) <= tol
+    if p > 0:                                                  # the mask really is applied (and is the forward's)
+        dz_nodrop = ops.affine2(dres, z, abc, 0.0, seed)
+        assert float((dz.float() - dz_nodrop.float()).abs().max()) > 0.1
+
+
+@pytest.mark.parametrize('dt', DT, ids=lambda d: str(d)[6:])
 @pytest.mark.parametrize('tag,layout', [('st_gcn_mstcn_1x1', 'openpose'), ('st_gcn_mstcn_1x1_deep', 'ntu-rgb+d')])
 def test_model_new_kernels_vs_generic_kernels(ops, dt, tag, layout):
     """Whole bottleneck models (all widths 8 / 11 -> 16 / 16, both stride-2 blocks), one training step with the
