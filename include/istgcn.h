@@ -328,6 +328,20 @@ int istgcn_bneck_out(const void* q, const float* Wt, long long wt_ts, long long 
                      int NM, int Tin, int Tout, int Mlog, int V, int C, int Wn, int Wp, int in_mul, int out_mul, int out_off,
                      int dtype, int grid_cap, void* stream);
 
+/* "Last workgroup finalises" (csrc/bn_tail.hpp): the arithmetic of istgcn_bn_finalize / istgcn_bn_bwd_coef as the TAIL of
+ * the kernel that produces the batch sums.  istgcn_bn_tail_arm_* arms one tail for the calling host thread; the next launch
+ * (same thread) of istgcn_gcn_fwd (register-chained variant), istgcn_tconv (wave-specialised variant), istgcn_bneck_out or
+ * istgcn_block_out_bwd whose `stats` (stats2) pointer equals the armed one carries it: after its last workgroup's sums the
+ * outputs are written, the running statistics updated, `stats` zeroed again and the ticket reset.  istgcn_bn_tail_disarm
+ * returns 1 if the tail was NOT taken (a kernel variant without tails: launch the stand-alone entry point), else 0.
+ * ticket: zero-initialised device word, one per stats buffer. */
+int istgcn_bn_tail_arm_finalize(double* stats, int stats_rep, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* coef, int C,
+                                unsigned* ticket);
+int istgcn_bn_tail_arm_bwd(double* stats, int stats_rep, double count, const float* gamma, const float* coef, int training,
+                           float* abc, float* dgamma, float* dbeta, int C, unsigned* ticket);
+int istgcn_bn_tail_disarm(void);
+
 /* Test-only probes of the hardware conventions the kernels assume (MFMA lane maps, ds_read_b64_tr_b16). */
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);
 int istgcn_probe_tr16(const void* src, int nelem, const int* lane_byte_off, void* out, void* stream);

@@ -29,6 +29,7 @@
 // stores are dropped; no predicated memory operation anywhere (gcn_rc.hpp).
 #include "gcn_rc.hpp"
 #include "dropout.hpp"
+#include "bn_tail.hpp"
 #include <type_traits>
 
 namespace {
@@ -176,6 +177,7 @@ struct BoutParams {
   int NM, Tin, Tout, Mlog, V, C, Wn, Wp, ntaps, off0, out_mul, out_off;
   int tap_sel[NTAP];
   int seg, nseg_seq, nseg;       // logical frames per segment, segments per sequence, segments in total
+  BnTail tail;                   // "last workgroup finalises" the BatchNorm behind the sums (bn_tail.hpp), when armed
 };
 
 // NPAIR = C / 64, IM = frames the input advances per output frame (1, or 2: the stride-2 forward conv), MODE 0: BatchNorm
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void bneck_out_kernel(const BoutParams P
       atomic_add_f64(dst + C + i, (double)stat[C + i]);
     }
   }
+  bn_tail_run(P.tail, gridDim.x, reinterpret_cast<unsigned*>(smem));
 }
 
 template <typename T, int NPAIR, int IM, int MODE>
@@ -1167,6 +1170,7 @@ extern "C" int istgcn_bneck_out(const void* q, const float* Wt, long long wt_ts,
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Mlog = Mlog; P.V = V; P.C = C; P.Wn = Wn; P.Wp = Wp; P.ntaps = ntaps; P.off0 = off0;
   P.out_mul = out_mul; P.out_off = out_off;
   for (int j = 0; j < NTAP; ++j) P.tap_sel[j] = j < ntaps ? tap_sel[j] : 0;
+  if (stats) istgcn_bn_tail_take(stats, &P.tail);
   if (dtype == 1) return bout_T<__bf16>(P, in_mul, mode, grid_cap, (hipStream_t)stream);
   return bout_T<_Float16>(P, in_mul, mode, grid_cap, (hipStream_t)stream);
 }

@@ -22,6 +22,7 @@
 // next frame's operand registers while it computes, and never meets a barrier inside the loop.  The weights of the
 // workgroup's channel slice (<= 98 KB) are copied to LDS once.
 #include "gcn_rc.hpp"
+#include "bn_tail.hpp"
 
 extern "C" int istgcn_gcn_rc_layout(int Cin, int Cout, int K, int dtype);
 
@@ -33,6 +34,7 @@ struct RcFwdParams {
   int nfw;               // frame workers in the grid
   int step_n, step_t;    // nfw = step_n * Tlog + step_t: a worker's (sequence, frame) cursor advances without dividing
   int gy;                // output-channel slices: workgroups that share frames (placed on one XCD: they re-read x from its L2)
+  BnTail tail;           // "last workgroup finalises" the BatchNorm that follows (bn_tail.hpp), when the caller armed it
 };
 
 // S = Cin / 16 (k-steps of the channel contraction), NCP = 64-channel pairs per workgroup slice (waves of a workgroup:
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_fwd_kernel(const RcFwdParams
       atomic_add_f64(dst + P.Cout + i, (double)stat[64 * NCP + i]);
     }
   }
+  bn_tail_run(P.tail, gridDim.x, reinterpret_cast<unsigned*>(smem));
 }
 
 template <typename T, int S, int K, int NCP, bool PF2, bool ADD, int CN>
@@ -372,6 +375,7 @@ extern "C" int istgcn_gcn_fwd_rc(const void* x, const float* A, const void* Wq, 
   P.x = x; P.Wq = Wq; P.A = A; P.bterm = bterm; P.addend = addend; P.y = y; P.stats = stats;
   P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Tlog = Tlog; P.V = V; P.Cout = Cout;
   P.in_t_stride = in_t_stride; P.out_t_stride = out_t_stride; P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
+  if (stats) istgcn_bn_tail_take(stats, &P.tail);
   if (dtype == 1) return rc_fwd_T<__bf16>(P, Cin, K, grid_cap, (hipStream_t)stream);
   return rc_fwd_T<_Float16>(P, Cin, K, grid_cap, (hipStream_t)stream);
 }

@@ -9,6 +9,7 @@
 // the forward mask instead of storing it.
 #include "common.hpp"
 #include "dropout.hpp"
+#include "bn_tail.hpp"
 
 namespace {
 
@@ -53,35 +54,23 @@ __global__ void bn_finalize_kernel(double* stats, int rep, int clear, double cou
                                    float* coef, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float mean, rstd;
   if (training) {
     double s = 0, ss = 0;
     for (int r = 0; r < rep; ++r) {
       s += stats[(size_t)r * 2 * C + c]; ss += stats[(size_t)r * 2 * C + C + c];
       if (clear) { stats[(size_t)r * 2 * C + c] = 0.0; stats[(size_t)r * 2 * C + C + c] = 0.0; }   // ready for the next producer
     }
-    const double m = s / count;
-    double var = ss / count - m * m;
-    if (var < 0) var = 0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (rmean) {
-      const double unb = count > 1 ? var * count / (count - 1) : var;
-      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-    }
+    bn_finalize_channel(s, ss, count, gamma, beta, rmean, rvar, momentum, eps, coef, C, c);
   } else {
-    mean = rmean[c];
-    rstd = 1.f / sqrtf(rvar[c] + eps);
+    const float mean = rmean[c], rstd = 1.f / sqrtf(rvar[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    coef[c] = g * rstd;
+    coef[C + c] = b - mean * g * rstd;
+    coef[2 * C + c] = mean;
+    coef[3 * C + c] = rstd;
   }
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  coef[c] = g * rstd;
-  coef[C + c] = b - mean * g * rstd;
-  coef[2 * C + c] = mean;
-  coef[3 * C + c] = rstd;
 }
 
-// dx = a*d + b*x + c ; a = g*rstd, b = -g*rstd^2*m2, c = -g*rstd*m1 + g*rstd^2*m2*mean   (m1 = sum d / M, m2 = sum d*xhat / M)
 __global__ void bn_bwd_coef_kernel(double* stats, int rep, int clear, double count, const float* gamma,
                                    const float* coef, int training, float* abc, float* dgamma, float* dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -91,17 +80,7 @@ __global__ void bn_bwd_coef_kernel(double* stats, int rep, int clear, double cou
     s += stats[(size_t)r * 2 * C + c]; sx += stats[(size_t)r * 2 * C + C + c];
     if (clear) { stats[(size_t)r * 2 * C + c] = 0.0; stats[(size_t)r * 2 * C + C + c] = 0.0; }
   }
-  const float g = gamma ? gamma[c] : 1.f, mean = coef[2 * C + c], rstd = coef[3 * C + c];
-  if (dgamma) dgamma[c] = (float)sx;
-  if (dbeta) dbeta[c] = (float)s;
-  if (training) {
-    const double m1 = s / count, m2 = sx / count;
-    abc[c] = g * rstd;
-    abc[C + c] = (float)(-(double)g * rstd * rstd * m2);
-    abc[2 * C + c] = (float)(-(double)g * rstd * m1 + (double)g * rstd * rstd * m2 * mean);
-  } else {
-    abc[c] = g * rstd; abc[C + c] = 0.f; abc[2 * C + c] = 0.f;
-  }
+  bn_bwd_coef_channel(s, sx, count, gamma, coef, training, abc, dgamma, dbeta, C, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -164,7 +143,7 @@ template <typename T, int VW, bool HASR>
 __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const T* out, const unsigned char* rmask, const T* z,
                                                           const float* coef2, const T* r, const float* coefr, T* dres,
                                                           double* stats2, double* statsr, int rep, size_t rows, int C,
-                                                          DropCfg D) {
+                                                          DropCfg D, BnTail tail) {
   uint32_t dk0, dk1;
   drop_key(D, dk0, dk1);
   __shared__ float red[4][NT];
@@ -234,6 +213,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
     }
     __syncthreads();
   }
+  bn_tail_run(tail, gridDim.x, reinterpret_cast<unsigned*>(&red[0][0]));                              // tcn.3's backward coefficients, when the caller armed them
 }
 
 template <typename T, int VW>
@@ -350,6 +330,45 @@ template <typename T> static inline int pick_vw(int C, bool need_div) {
 
 }  // namespace
 
+// ---- armed BatchNorm tail of this host thread (bn_tail.hpp) ----
+static thread_local BnTail g_bn_tail{};
+
+extern "C" int istgcn_bn_tail_take(const double* stats, BnTail* out) {
+  if (g_bn_tail.kind == 0 || g_bn_tail.stats != stats) return 0;
+  *out = g_bn_tail;
+  g_bn_tail.kind = 0;
+  return 1;
+}
+
+extern "C" int istgcn_bn_tail_arm_finalize(double* stats, int stats_rep, double count, const float* gamma, const float* beta,
+                                           float* running_mean, float* running_var, float momentum, float eps, float* coef,
+                                           int C, unsigned* ticket) {
+  if (!stats || !coef || !ticket || stats_rep < 1 || C < 1 || count <= 0) return ISTGCN_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return ISTGCN_EINVAL;
+  BnTail t{};
+  t.kind = 1; t.rep = stats_rep; t.C = C; t.training = 1; t.stats = stats; t.ticket = ticket; t.count = count;
+  t.gamma = gamma; t.beta = beta; t.rmean = running_mean; t.rvar = running_var; t.momentum = momentum; t.eps = eps; t.out0 = coef;
+  g_bn_tail = t;
+  return ISTGCN_OK;
+}
+
+extern "C" int istgcn_bn_tail_arm_bwd(double* stats, int stats_rep, double count, const float* gamma, const float* coef,
+                                      int training, float* abc, float* dgamma, float* dbeta, int C, unsigned* ticket) {
+  if (!stats || !coef || !abc || !ticket || stats_rep < 1 || C < 1 || count <= 0) return ISTGCN_EINVAL;
+  BnTail t{};
+  t.kind = 2; t.rep = stats_rep; t.C = C; t.training = training; t.stats = stats; t.ticket = ticket; t.count = count;
+  t.gamma = gamma; t.coef_in = coef; t.out0 = abc; t.out1 = dgamma; t.out2 = dbeta;
+  g_bn_tail = t;
+  return ISTGCN_OK;
+}
+
+// 1 if a tail was still armed (no producer took it: the caller runs the stand-alone kernel), 0 otherwise
+extern "C" int istgcn_bn_tail_disarm() {
+  const int was = g_bn_tail.kind != 0;
+  g_bn_tail.kind = 0;
+  return was;
+}
+
 extern "C" int istgcn_bn_finalize(double* stats, int stats_rep, int clear, double count, const float* gamma,
                                   const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                   int training, float* coef, int C, void* stream) {
@@ -428,9 +447,11 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const uns
   const size_t gcap = r ? 1024 : 1536;
   if (g > gcap) g = gcap;
   const dim3 grid((int)g);
+  BnTail tail{};
+  istgcn_bn_tail_take(stats2, &tail);
 #define BOB_LAUNCH(VWv, HR)                                                                                              \
   ISTGCN_LAUNCH((block_out_bwd_kernel<ET, VWv, HR>), grid, dim3(NT), 0, (hipStream_t)stream, (const ET*)dout, (const ET*)out,  \
-                relu_mask, (const ET*)z, coef2, (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D)
+                relu_mask, (const ET*)z, coef2, (const ET*)r, coefr, (ET*)dres, stats2, statsr, stats_rep, (size_t)rows, C, D, tail)
   EW_CASES({
     if (vw == VWB) { if (r) BOB_LAUNCH(VWB, true); else BOB_LAUNCH(VWB, false); }
     else { if (r) BOB_LAUNCH(1, true); else BOB_LAUNCH(1, false); }

@@ -35,6 +35,7 @@
 // (round 1: two 4-wave workgroups per CU, each running stage -> barrier -> MFMA -> barrier -> epilogue in sequence) 40 %
 // of the time was un-overlapped staging and epilogue.
 #include "common.hpp"
+#include "bn_tail.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -65,6 +66,7 @@ struct TconvParams {
   int us_stride, out_stride, off_stat, off_u0, off_u1, off_o;
   int cin_pad;           // nch * CC: length of the LDS copies of the `pre` rows
   int abl;               // diagnostic ablation (ISTGCN_TCONV_ABL): 1 = no input loads, 2 = no MFMAs; results are then wrong
+  BnTail tail;           // "last workgroup finalises" the BatchNorm behind these sums (bn_tail.hpp), when the caller armed it
 };
 
 struct Tile {
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       }
     }
   }
+  bn_tail_run(P.tail, gridDim.x * gridDim.y, reinterpret_cast<unsigned*>(smem));
 }
 
 template <typename T, int MT, int NT, int WM>
@@ -773,6 +776,7 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
+  if (stats) istgcn_bn_tail_take(stats, &P.tail);
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);

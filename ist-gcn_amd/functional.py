@@ -184,11 +184,13 @@ def conv_bwd_phases(k, stride):
     return out
 
 
-def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None, packed=None):
+def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, stats=None, packed=None, before_last=None):
     """Data gradient of a (k,1)/stride conv with taps w_taps [k][Cout][Cin]: one tconv launch per output phase.
-    packed: {phase: fragment-packed transposed taps} from a PackPlan (else packed here, one launch per phase)."""
+    packed: {phase: fragment-packed transposed taps} from a PackPlan (else packed here, one launch per phase).
+    before_last: called right before the LAST launch that adds into `stats` (arms the BatchNorm tail, ops.bn_bwd_coef(defer=True))."""
     NM, Tz = dz.shape[0], dz.shape[1]
     out = torch.empty((NM, T_in, V, cin), dtype=dz.dtype, device=dz.device)
+    launching = [ph for ph in range(stride) if (T_in - ph + stride - 1) // stride > 0 and ops.conv_taps_bwd(k, stride, ph)]
     for phase in range(stride):
         tl = ops.conv_taps_bwd(k, stride, phase)
         Mlog = (T_in - phase + stride - 1) // stride
@@ -197,6 +199,8 @@ def _conv_bwd_data(dz, w_taps, k, stride, T_in, cin, V, aux=None, maux=None, sta
         if not tl:                       # no tap lands on this phase (k < stride): those frames get no gradient
             out[:, phase::stride].zero_()
             continue
+        if before_last is not None and phase == launching[-1]:
+            before_last()
         offs = [dj for _, dj in tl]
         # transposed taps [k][Cin][Cout] as a view; the packer gathers this phase's taps straight from the parameter
         wp = packed[phase] if packed is not None else \
@@ -283,11 +287,20 @@ class STGCNBlockFn(torch.autograd.Function):
         st1 = ops.stats_scratch(0, cout, dev) if training else None
         pk = cfg.packed or {}
         wp = pk['wg'] if 'wg' in pk else ops.pack_gcn_weight(Wg3.permute(1, 0, 2), dt)
-        g = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, stats=st1, nnz_cap=cfg.nnz_cap)
+        # (training: the BatchNorm arithmetic is armed as the tail of the kernel that produces the sums -- its last workgroup
+        #  finalises -- and bn_tail_flush() launches the stand-alone kernel only if that kernel's variant has no tail)
         coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training,
-                                clear=True)
+                                clear=True, defer=True) if training else None
+        g = ops.gcn_forward(x, A_eff, wp, cout, bterm=bterm, stats=st1, nnz_cap=cfg.nnz_cap)
+        if training:
+            ops.bn_tail_flush()
+        else:
+            coef1 = ops.bn_finalize(st1, NM * T * V, g1, b1, bufs['bn1'][0], bufs['bn1'][1], cfg.momentum, cfg.eps, training,
+                                    clear=True)
         # 2. temporal conv (BN1+ReLU fused into the staging; BN2 batch sums from the epilogue)
         st2 = ops.stats_scratch(1, cout, dev) if training else None
+        coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
+                                clear=True, defer=True) if training else None
         taps, in_mul = ops.conv_taps_fwd(cfg.ksize, s)
         q = yb = None
         if cfg.tcn == 'conv':
@@ -314,8 +327,11 @@ class STGCNBlockFn(torch.autograd.Function):
                 yb = ops.tconv(q, wt, wp, taps, bias=bt_, Tout=Tz, Mlog=Tz, in_mul=in_mul)
                 we = ops.pack_tconv_weight(We_.view(1, cout, wp), V, [0], 1, dt)
                 z = ops.tconv(yb, we, cout, [0], bias=be, stats=st2, Tout=Tz, Mlog=Tz)
-        coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
-                                clear=True)
+        if training:
+            ops.bn_tail_flush()
+        else:
+            coef2 = ops.bn_finalize(st2, NM * Tz * V, g2, b2, bufs['bn2'][0], bufs['bn2'][1], cfg.momentum, cfg.eps, training,
+                                    clear=True)
         # 3. residual branch
         r = coefr = None
         if cfg.residual == 'id':
@@ -352,9 +368,9 @@ class STGCNBlockFn(torch.autograd.Function):
             dout = dout.to(dt)
         pk = cfg.packed or {}
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
-        dres, st2b, strb = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True, epoch=cfg.seed_epoch,
-                                             relu_mask=rmask)
-        abc2, dg2, db2 = ops.bn_bwd_coef(st2b, NM * Tz * V, g2, coef2, training, clear=True)
+        dres, st2b, strb, (abc2, dg2, db2) = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True,
+                                                               epoch=cfg.seed_epoch, relu_mask=rmask,
+                                                               tail=(NM * Tz * V, g2, training))
         # (bottleneck blocks at 64 / 128 channels in 16-bit storage: dz is never written -- the stream kernel that consumes it
         #  forms it in registers from dres and z, dropout mask included; ops.BNECK_FUSE_BN = False keeps the separate pass)
         fuse_in = (cfg.tcn == 'bneck' and ops.BNECK_FUSE_BN and _bneck_rc(cfg, V, dt) and
@@ -364,6 +380,10 @@ class STGCNBlockFn(torch.autograd.Function):
         taps, in_mul = ops.conv_taps_fwd(k, s)
         pre1 = coef1[:2].contiguous()
         st1b = ops.stats_scratch(2, cout, x.device)
+        bwd1 = []                          # (abc1, dgamma1, dbeta1) of tcn.0's BatchNorm: armed as the tail of the last launch that adds into st1b
+
+        def arm1():
+            bwd1.append(ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True, defer=True))
         dWs = dbs = dWe = dbe = None
         need_A = ctx.needs_input_grad[5]
         K = A_eff.shape[0]
@@ -383,7 +403,8 @@ class STGCNBlockFn(torch.autograd.Function):
         buf_r = (arena.take(), arena.take()) if cfg.residual == 'conv' else None
         if cfg.tcn == 'conv':
             dWt, dbt = ops.tconv_wgrad(dz, g, taps, in_mul=in_mul, pre=pre1, pre_relu=True, out=buf_t)
-            d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b, packed=pk.get('wt_bwd'))
+            d1 = _conv_bwd_data(dz, Wt, k, s, T, cout, V, aux=g, maux=coef1, stats=st1b, packed=pk.get('wt_bwd'),
+                                before_last=arm1)
         else:
             w, wp = cfg.width, _pad_width(cfg.width, dt)
             rc = _bneck_rc(cfg, V, dt)
@@ -413,6 +434,8 @@ class STGCNBlockFn(torch.autograd.Function):
                 d1 = torch.empty((NM, T, V, cout), dtype=dt, device=dyb.device)
                 for phase in range(s):
                     tl = sorted(ops.conv_taps_bwd(k, s, phase), key=lambda jd: jd[1])
+                    if phase == s - 1:
+                        arm1()
                     ops.bneck_out(dyb, Wt.transpose(1, 2), [j for j, _ in tl], tl[0][1], Ws.t(), cout, aux=g, maux=coef1,
                                   stats=st1b, mode=1, Tout=T, Mlog=(T - phase + s - 1) // s, in_mul=1, out_mul=s,
                                   out_off=phase, yb=dq, z=d1)
@@ -424,11 +447,12 @@ class STGCNBlockFn(torch.autograd.Function):
                 dWs3, dbs = ops.tconv_wgrad(dq, g, [0], in_mul=1, pre=pre1, pre_relu=True)
             dWs = dWs3.view(wp, cout)[:w]
             if not rc:
-                d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b)
+                d1 = _conv_bwd_data(dq, Ws_.view(1, wp, cout), 1, 1, T, cout, V, aux=g, maux=coef1, stats=st1b, before_last=arm1)
             if wp != w:
                 dWt, dbt, dbs = dWt[:, :w, :w], dbt[:w], dbs[:w]
             # (the register-chained kernels write their own zero-filled gradient buffers; the arena slots stay unused)
-        abc1, dg1, db1 = ops.bn_bwd_coef(st1b, NM * T * V, g1, coef1, training, clear=True)
+        ops.bn_tail_flush()
+        abc1, dg1, db1 = bwd1[0]
         dg = ops.affine2(d1, g, abc1)
         # 1'. graph conv: parameter gradients, then the data gradient with the residual gradient folded in
         dWg, S = ops.gcn_wgrad(dg, x, A_eff, want_S=ctx.has_b, nnz_cap=cfg.nnz_cap, out=buf_g)

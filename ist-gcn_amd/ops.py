@@ -633,11 +633,47 @@ def _scratch_consumed(stats):
         ent[1] = False
 
 
-def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear=False):
-    """-> coef [4][C] fp32: scale, shift, mean, rstd.  Training also updates the running statistics in place."""
+# "Last workgroup finalises" tails (csrc/bn_tail.hpp) instead of the stand-alone bn_finalize / bn_bwd_coef launches: built,
+# tested (tests/test_gpu_block.py::test_bn_tails_equal_standalone_launches) and measured NEUTRAL (config 2: 14.49 vs 14.53
+# ms/step, config 1: 7.46 vs 7.33, config 5: 46.9 vs 47.0 -- the serial tail of the last workgroup costs what the 5 us launch
+# did), hence off by default; ISTGCN_BN_TAILS=1 turns them on.
+BN_TAILS = os.environ.get('ISTGCN_BN_TAILS', '0') == '1'
+_TAIL = threading.local()
+_TICKETS = {}                # stats data_ptr -> int32[1] ticket of the "last workgroup finalises" protocol (zero between launches)
+
+
+def _ticket(stats):
+    t = _TICKETS.get(stats.data_ptr())
+    if t is None or t.device != stats.device:
+        t = _TICKETS[stats.data_ptr()] = torch.zeros(1, dtype=torch.int32, device=stats.device)
+    return t
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear=False, defer=False):
+    """-> coef [4][C] fp32: scale, shift, mean, rstd.  Training also updates the running statistics in place.
+    defer=True (training, clear=True; call it BEFORE launching the kernel that adds into `stats`): the arithmetic is armed
+    as the tail of that kernel -- its last workgroup finalises (csrc/bn_tail.hpp) -- and `bn_tail_flush()` after the
+    producer's launch runs the stand-alone kernel instead if the producer's variant has no tail."""
     C = gamma.shape[0]
     coef = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
     dv = _check_dev(stats, gamma, beta, running_mean, running_var, coef)
+    args = (stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear, coef, dv)
+    if defer:
+        # (always computed AFTER the producer's launch: by its last workgroup when armed, by bn_tail_flush() otherwise)
+        _drop_stale_tail()
+        armed = BN_TAILS and training and clear and stats is not None
+        if armed:
+            _call('istgcn_bn_tail_arm_finalize', _ptr(stats), stats.shape[0], ctypes.c_double(float(count)), _ptr(gamma),
+                  _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps), _ptr(coef),
+                  C, _ptr(_ticket(stats)), dev=dv)
+        _TAIL.pending = ('fin', args, armed)
+        return coef
+    _bn_finalize_now(*args)
+    return coef
+
+
+def _bn_finalize_now(stats, count, gamma, beta, running_mean, running_var, momentum, eps, training, clear, coef, dv):
+    C = gamma.shape[0]
     _call('istgcn_bn_finalize', _ptr(stats), 0 if stats is None else stats.shape[0], int(bool(clear)),
           ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), ctypes.c_float(momentum),
@@ -646,22 +682,68 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
         _scratch_consumed(stats)
     if training:
         bump_weights_epoch()              # running_mean / running_var were written through raw pointers
-    return coef
 
 
-def bn_bwd_coef(stats, count, gamma, coef, training, clear=False):
-    """-> (abc [3][C], dgamma [C], dbeta [C]) from the two BatchNorm-backward sums."""
+def bn_bwd_coef(stats, count, gamma, coef, training, clear=False, defer=False):
+    """-> (abc [3][C], dgamma [C], dbeta [C]) from the two BatchNorm-backward sums.  defer: as in bn_finalize."""
     C = gamma.shape[0]
     abc = torch.empty((3, C), dtype=torch.float32, device=gamma.device)
     dg = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     db = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     dv = _check_dev(stats, gamma, coef, abc, dg, db)
+    args = (stats, count, gamma, coef, training, clear, abc, dg, db, dv)
+    if defer:
+        _drop_stale_tail()
+        armed = BN_TAILS and clear
+        if armed:
+            _call('istgcn_bn_tail_arm_bwd', _ptr(stats), stats.shape[0], ctypes.c_double(float(count)), _ptr(gamma), _ptr(coef),
+                  int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _ptr(_ticket(stats)), dev=dv)
+        _TAIL.pending = ('bwd', args, armed)
+        return abc, dg, db
+    _bn_bwd_coef_now(*args)
+    return abc, dg, db
+
+
+def _bn_bwd_coef_now(stats, count, gamma, coef, training, clear, abc, dg, db, dv):
+    C = gamma.shape[0]
     _call('istgcn_bn_bwd_coef', _ptr(stats), stats.shape[0], int(bool(clear)), ctypes.c_double(float(count)),
           _ptr(gamma), _ptr(coef),
           int(bool(training)), _ptr(abc), _ptr(dg), _ptr(db), C, _stream(gamma), dev=dv)
     if clear:
         _scratch_consumed(stats)
-    return abc, dg, db
+
+
+TAIL_STATS = {'taken': 0, 'standalone': 0}       # diagnostics: tails carried by a producer / run as their own launch
+
+
+def _drop_stale_tail():
+    # an exception between arming and flushing (the producer's launch raised) leaves a tail behind: forget it
+    if getattr(_TAIL, 'pending', None) is not None:
+        if _TAIL.pending[2]:
+            _lib.load().istgcn_bn_tail_disarm()
+        _TAIL.pending = None
+
+
+def bn_tail_flush():
+    """After the launch(es) of the producer of an armed tail: if no kernel took the tail (a variant without one), run the
+    stand-alone kernel now; either way the deferred outputs are valid (in stream order) afterwards."""
+    pend = getattr(_TAIL, 'pending', None)
+    if pend is None:
+        return
+    _TAIL.pending = None
+    kind, args, armed = pend
+    if not armed or _lib.load().istgcn_bn_tail_disarm():
+        TAIL_STATS['standalone'] += 1
+        (_bn_finalize_now if kind == 'fin' else _bn_bwd_coef_now)(*args)
+        return
+    TAIL_STATS['taken'] += 1
+    _scratch_consumed(args[0])                      # the tail zeroed the sums
+    if kind == 'fin':
+        bump_weights_epoch()
+
+
+def bn_tail_armed():
+    return getattr(_TAIL, 'pending', None) is not None
 
 
 def _rows(t):
@@ -700,9 +782,12 @@ def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0, epoch=None
     return (out, rmask) if want_mask else out
 
 
-def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None, relu_mask=None):
+def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None, relu_mask=None,
+                  tail=None):
     """-> (dres = dout*[out>0], stats2, statsr or None); scratch=True: the sums go to `stats_scratch` slots 0 / 1
-    (consume them with bn_bwd_coef(clear=True)).  relu_mask: the forward's byte mask; `out` is then not read."""
+    (consume them with bn_bwd_coef(clear=True)).  relu_mask: the forward's byte mask; `out` is then not read.
+    tail = (count, gamma, training): tcn.3's backward coefficients are computed by the kernel's last workgroup (or by the
+    stand-alone kernel right behind it) and returned as a fourth value (abc, dgamma, dbeta)."""
     C = z.shape[-1]
     dres = torch.empty_like(z)
     if scratch:
@@ -715,10 +800,16 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
     assert out is not None or relu_mask is not None
     dv = _check_dev(dout, out, relu_mask, z, coef2, r, coefr, dres, st2, str_)
     nt = (4 if r is not None else 3) + (1.0 / 16 if relu_mask is not None else 1)
+    res2 = None
+    if tail is not None:
+        res2 = bn_bwd_coef(st2, tail[0], tail[1], coef2, tail[2], clear=True, defer=True)
     _call('istgcn_block_out_bwd', _ptr(dout), _ptr(None if relu_mask is not None else out), _ptr(relu_mask), _ptr(z),
           _ptr(coef2), _ptr(r), _ptr(coefr), _ptr(dres), _ptr(st2), _ptr(str_), STATS_REP, ctypes.c_longlong(_rows(z)), C,
           ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, z), dtype_code(z), _stream(z),
           work=(6.0 * z.numel(), float(z.numel()) * nt * _esz(z)), dev=dv)
+    if tail is not None:
+        bn_tail_flush()
+        return dres, st2, str_, res2
     return dres, st2, str_
 
 

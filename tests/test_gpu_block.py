@@ -795,3 +795,59 @@ def test_flat_sgd_tap_major_layout_and_checkpoint_round_trip(tmp_path):
     fresh.w, fresh.b = torch.nn.Parameter(torch.zeros(16, 16, 9, 1)), torch.nn.Parameter(torch.zeros(16))
     harness.load_weights(fresh, path)
     assert torch.equal(fresh.w.detach(), wa.detach().cpu()) and torch.equal(fresh.b.detach(), ba.detach().cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,dt', [('st_gcn_msgcn', torch.bfloat16), ('st_gcnold', torch.float32), ('st_gcn_mstcn_1x1', torch.float16),
+                                    ('st_gcn_multi3_fix_3A_mstcn', torch.bfloat16)])
+def test_bn_tails_equal_standalone_launches(tag, dt):
+    """"Last workgroup finalises" (csrc/bn_tail.hpp): two training steps with the BatchNorm arithmetic carried as the tail of the
+    kernels that produce the batch sums against the same steps with the stand-alone bn_finalize / bn_bwd_coef launches
+    (ops.BN_TAILS = False): logits, running statistics and gradients agree to the noise of the fp64 atomics' summation
+    order; the tails really are taken where the kernel variants have them, and the sums / tickets are left zeroed (the
+    second step would otherwise double-count)."""
+    from istgcn_amd import harness, ops
+    gargs, nc = MODEL_CFG[tag]
+    Vj = 18 if gargs['layout'] == 'openpose' else 25
+    mod = importlib.import_module('istgcn_amd.net.' + tag)
+    res = {}
+    keep = ops.BN_TAILS
+    try:
+        for key, flag in (('tail', True), ('alone', False), ('alone2', False)):
+            ops.BN_TAILS = flag
+            ops.TAIL_STATS['taken'] = ops.TAIL_STATS['standalone'] = 0
+            torch.manual_seed(0)
+            m = mod.Model(3, nc, gargs, True, dropout=0, compute_dtype=dt)
+            m.apply(harness.weights_init)
+            m.to(dev()).train()
+            gen = torch.Generator().manual_seed(5)
+            x = torch.randn(4, 3, 48, Vj, 2, generator=gen).to(dev())
+            y = torch.randint(0, nc, (4,), generator=gen).to(dev())
+            ls = 1024.0 if dt == torch.float16 else 1.0
+            for _ in range(2):
+                m.zero_grad()
+                logits = m(x)
+                (F.cross_entropy(logits, y) * ls).backward()
+            rs = torch.cat([b.detach().double().flatten() for n_, b in m.named_buffers() if 'running' in n_]).cpu()
+            gr = torch.cat([(p.grad.double() / ls).flatten() for p in m.parameters() if p.grad is not None]).cpu()
+            res[key] = (logits.detach().double().cpu(), rs, gr, dict(ops.TAIL_STATS))
+    finally:
+        ops.BN_TAILS = keep
+    (l1, r1, g1, st1), (l0, r0, g0, st0), (l2, r2, g2, _) = res['tail'], res['alone'], res['alone2']
+    assert st0['taken'] == 0 and st1['taken'] > 0, (st0, st1)
+    if dt == torch.bfloat16:
+        assert st1['taken'] >= 2 * 30, st1                       # 16-bit trunk: every block's four BatchNorm sites
+    rel = lambda a, b: float((a - b).norm() / max(1e-30, float(b.norm())))
+    # the yardstick is the run-to-run difference of the stand-alone path itself (the order of the fp64 / fp32 atomics varies;
+    # a pre-activation within round-off of zero then takes the other ReLU branch, and in 16-bit storage a 1e-5 change of a
+    # BatchNorm coefficient re-draws the rounding of a fraction of the stored activations)
+    from gpu_util import OUT
+    import os
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'bn_tails_measured.txt'), 'a') as f:
+        f.write('%s %s: tails taken %d stand-alone %d | tail vs alone: running %.3g logits %.3g grads %.3g | alone vs alone: running %.3g '
+                'logits %.3g grads %.3g\n' % (tag, str(dt)[6:], st1['taken'], st1['standalone'], rel(r1, r0), rel(l1, l0), rel(g1, g0),
+                                              rel(r2, r0), rel(l2, l0), rel(g2, g0)))
+    assert rel(r1, r0) < 3 * rel(r2, r0) + 1e-5, (rel(r1, r0), rel(r2, r0))
+    assert rel(l1, l0) < 3 * rel(l2, l0) + (1e-5 if dt == torch.float32 else 5e-3), (rel(l1, l0), rel(l2, l0))
+    assert torch.isfinite(g1).all() and rel(g1, g0) < 3 * rel(g2, g0) + (1e-4 if dt == torch.float32 else 0.1), (rel(g1, g0), rel(g2, g0))
