@@ -644,7 +644,9 @@ int launch4(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
 // Tiling decision shared by the launcher and the geometry query (the host packs weights to match).
 struct TconvGeom { int CC, nch, NKG, MT, MTtot, gy, NT, F, Fin, min_off, lds, off_stat, off_u0, off_u1, off_o, us_stride, out_stride; };
 
-inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, TconvGeom* G) {
+// nt_max = 1: the short-tile variant (128 rows) for launches too small to give every CU a 256-row tile; the launcher takes
+// it only when the channel chunking -- which the packed weights depend on -- comes out the same as for nt_max = 2.
+inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, TconvGeom* G, int nt_max = 2) {
   const int epl = dtype == 0 ? 4 : 8, kgs = 2 * epl, esz = dtype == 0 ? 4 : 2;
   int mn = tap_off[0], mx = tap_off[0];
   for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
@@ -659,7 +661,7 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
   const int cc_max = dtype == 0 ? 16 : 32;
   const int budget = 160 * 1024;
   int best_nt = 0, best_cc = 0;
-  for (int nt = 2; nt >= 1 && !best_nt; --nt) {
+  for (int nt = nt_max; nt >= 1 && !best_nt; --nt) {
     const int F = nt * 128 / V;
     if (F < 1) continue;
     for (int cc = cc_max; cc >= kgs; cc >>= 1) {
@@ -776,6 +778,20 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
+  if (G.NT == 2) {
+    // small launches (config 1: 4 sequences): fewer 256-row tiles than half the CUs -> 128-row tiles, twice the workgroups
+    // each with half the serial work (the weight layout must not change: same chunk width, same channel tiling)
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const long tiles2 = (long)NM * ceil_div(Mlog, G.F) * G.gy;
+    if (2 * tiles2 <= cus) {
+      TconvGeom G1;
+      if (tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G1, 1) == ISTGCN_OK && G1.NT == 1 && G1.CC == G.CC &&
+          G1.nch == G.nch && G1.MT == G.MT && G1.MTtot == G.MTtot)
+        G = G1;
+    }
+  }
   if (stats) istgcn_bn_tail_take(stats, &P.tail);
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
