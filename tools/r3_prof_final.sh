@@ -1,5 +1,5 @@
-# final round-3 profiles: kernel trace + PMC passes per workload (tools/profile_bench.sh), then the plain bench lines
-for spec in "r03_st_gcn_mstcn_1x1_deep_f16_b128:--config 5" "r03_st_gcn_mstcn_1x1_bf16_b256:--config 3 --dtype bf16" "r03_st_gcn_multi3_fix_3A_mstcn_bf16_b64:--config 4 --dtype bf16"; do
+# final round-3 profiles: kernel trace + PMC passes per workload (tools/profile_bench.sh)
+for spec in "r03_st_gcn_msgcn_bf16_b64:--config 2" "r03_st_gcn_mstcn_1x1_deep_f16_b128:--config 5" "r03_st_gcn_mstcn_1x1_bf16_b256:--config 3 --dtype bf16" "r03_st_gcn_multi3_fix_3A_mstcn_bf16_b64:--config 4 --dtype bf16" "r03_st_gcn_mstcn_1x1_f32_b256:--config 3" "r03_st_gcn_multi3_fix_3A_mstcn_f32_b64:--config 4" "r03_st_gcnold_f32_b2:--config 1"; do
   tag=$(echo "$spec" | cut -d: -f1); args=$(echo "$spec" | cut -d: -f2)
   echo "=== $tag ($args)"
   bash tools/profile_bench.sh $tag $args > gpurun_out/${tag}_profile.log 2>&1 || { tail -20 gpurun_out/${tag}_profile.log; exit 1; }
