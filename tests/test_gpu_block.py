@@ -850,4 +850,6 @@ def test_bn_tails_equal_standalone_launches(tag, dt):
                                               rel(r2, r0), rel(l2, l0), rel(g2, g0)))
     assert rel(r1, r0) < 3 * rel(r2, r0) + 1e-5, (rel(r1, r0), rel(r2, r0))
     assert rel(l1, l0) < 3 * rel(l2, l0) + (1e-5 if dt == torch.float32 else 5e-3), (rel(l1, l0), rel(l2, l0))
-    assert torch.isfinite(g1).all() and rel(g1, g0) < 3 * rel(g2, g0) + (1e-4 if dt == torch.float32 else 0.1), (rel(g1, g0), rel(g2, g0))
+    # (float32: logits agree to 3e-7, but one ReLU mask flip at a pre-activation within round-off of zero moves the whole
+    #  gradient by 1e-3 .. 4e-3 -- discrete events, so two runs of the SAME path differ by 0.0006 .. 0.002 as well; cf. smoke())
+    assert torch.isfinite(g1).all() and rel(g1, g0) < 3 * rel(g2, g0) + (1e-2 if dt == torch.float32 else 0.1), (rel(g1, g0), rel(g2, g0))
