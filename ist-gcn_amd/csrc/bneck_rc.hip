@@ -35,6 +35,14 @@
 namespace {
 
 constexpr unsigned OOB = 0x7ffffff0u;
+// cache policy of the loads that read a WIDE tensor exactly once (raw buffer `aux` operand: 2 = nt, streaming): they do not
+// displace what the neighbouring kernels re-read -- measured WORSE here (config 5: 46.3 -> 49.1 ms/step, config 3 bf16 28.6 -> 29.9):
+// these tensors were written by the previous kernel and still sit in the Infinity Cache, which a streaming read forgoes.  Default
+// policy (0) therefore; ISTGCN_X_BNECK_LDAUX overrides (experiments).
+#ifndef ISTGCN_X_BNECK_LDAUX
+#define ISTGCN_X_BNECK_LDAUX 0
+#endif
+constexpr int LDW = ISTGCN_X_BNECK_LDAUX;
 
 // ======================================================================================================================
 // bneck_in
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256, S >= 16 ? 2 : 4) void bneck_in_kernel(const Bi
   auto loadx = [&](int tile, u32x4 (&xf)[S]) __attribute__((always_inline)) {
     const unsigned base = (unsigned)tile * (unsigned)(32 * C * 2) + xl;   // (beyond the last row: outside the descriptor)
 #pragma unroll
-    for (int s = 0; s < S; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rx, base + 32u * s, 0, 0);
+    for (int s = 0; s < S; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rx, base + 32u * s, 0, LDW);
   };
   auto work = [&](int tile, u32x4 (&xf)[S]) __attribute__((always_inline)) {
     f32x16 acc;
@@ -293,8 +301,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void bneck_out_kernel(const BoutParams P
     const rsrc_t ra = make_rsrc(MODE == 1 ? auxg + fo * V * C : zg + fo * V * C, nb_z);
     u32x4 ax[2], axn[2];                                     // aux row vectors of the current / next channel tile
     if constexpr (MODE == 1) {
-      ax[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, al, 0, 0);
-      ax[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + 32u, 0, 0);
+      ax[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, al, 0, LDW);
+      ax[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + 32u, 0, LDW);
     }
     f32x16 D2;
 #pragma unroll
@@ -337,8 +345,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void bneck_out_kernel(const BoutParams P
         __builtin_amdgcn_sched_barrier(0);                   // one tile at a time: overlapping tiles is what spills
         if constexpr (MODE == 1) {
           if (t + 1 < 2 * NPAIR) {
-            axn[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + (unsigned)(32 * (t + 1)) * 2u, 0, 0);
-            axn[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + (unsigned)(32 * (t + 1) + 16) * 2u, 0, 0);
+            axn[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + (unsigned)(32 * (t + 1)) * 2u, 0, LDW);
+            axn[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, al + (unsigned)(32 * (t + 1) + 16) * 2u, 0, LDW);
           }
 #pragma unroll
           for (int i = 0; i < 16; ++i) Xa[i] = 0.f;
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void bneck_wgrad_kernel(const BwgParams P) 
   auto loadt = [&](int tile, int half, u32x4 (&xf)[SH], u32x4& nf) __attribute__((always_inline)) {
     const unsigned base = (unsigned)tile * (unsigned)(32 * C * 2) + wl_ + (unsigned)(half * SH * 32);
 #pragma unroll
-    for (int s = 0; s < SH; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, base + 32u * s, 0, 0);
+    for (int s = 0; s < SH; ++s) xf[s] = __builtin_amdgcn_raw_buffer_load_b128(rw, base + 32u * s, 0, LDW);
     nf = __builtin_amdgcn_raw_buffer_load_b128(rn, nl_ == OOB ? OOB : (unsigned)tile * (unsigned)(32 * P.Wp * 2) + nl_, 0, 0);
   };
   auto work = [&](auto half_c, u32x4 (&xf)[SH], const u32x4& nf) __attribute__((always_inline)) {
@@ -963,8 +971,8 @@ __global__ __launch_bounds__(256, 2) void bneck_bwd_in_kernel(const BbiParams P)
     const unsigned base = (unsigned)tile * (unsigned)(32 * C * 2) + wl_ + (unsigned)(q * SH * 32);
 #pragma unroll
     for (int s = 0; s < SH; ++s) {
-      df[s] = __builtin_amdgcn_raw_buffer_load_b128(rd, base + 32u * s, 0, 0);
-      zf[s] = __builtin_amdgcn_raw_buffer_load_b128(rz, base + 32u * s, 0, 0);
+      df[s] = __builtin_amdgcn_raw_buffer_load_b128(rd, base + 32u * s, 0, LDW);
+      zf[s] = __builtin_amdgcn_raw_buffer_load_b128(rz, base + 32u * s, 0, LDW);
     }
     nf = __builtin_amdgcn_raw_buffer_load_b128(rn, nl_ == OOB ? OOB : (unsigned)tile * (unsigned)(32 * P.Wp * 2) + nl_, 0, 0);
   };

@@ -15,10 +15,23 @@ namespace {
 
 constexpr int NT = 256;
 
-template <typename T, int VW>
+// Streaming (non-temporal) loads: these passes read every vector exactly once; left to the default policy they push the
+// weights and halo rows of the MFMA kernels that run between them out of L2 / the Infinity Cache.  Measured over the whole
+// step (config 2, same box, ms/step): default policy 14.77, every operand streaming 14.41 (-2.4 %), only the operands that
+// come from far back (COLD: the forward's tensors in the backward pass, the block input in block_out_fwd) 14.52; config 5:
+// -0.4 %.  Streaming STORES on top measured worse (the next kernel reads the output), and so did streaming loads in the
+// bottleneck stream kernels (their inputs were just written and still sit in the Infinity Cache) and of tconv's staged
+// chunks (halo rows are re-read by the neighbouring tile).  -DISTGCN_X_NT=0 none, 1 (default) every operand, 2 the cold ones.
+#ifndef ISTGCN_X_NT
+#define ISTGCN_X_NT 1
+#endif
+template <typename T, int VW, bool COLD = false>
 __device__ static inline void load_vec(const T* p, float (&f)[VW]) {
+  constexpr bool NTL = ISTGCN_X_NT == 1 || (ISTGCN_X_NT == 2 && COLD);
   if constexpr (VW == Elem<T>::EPL) {
-    typename Elem<T>::frag r = *reinterpret_cast<const typename Elem<T>::frag*>(p);
+    typename Elem<T>::frag r;
+    if constexpr (NTL) r = __builtin_nontemporal_load(reinterpret_cast<const typename Elem<T>::frag*>(p));
+    else r = *reinterpret_cast<const typename Elem<T>::frag*>(p);
 #pragma unroll
     for (int j = 0; j < VW; ++j) f[j] = Elem<T>::to_f(r[j]);
   } else {
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
     }
     float zv[VW], rv[VW], m[VW];
     load_vec<T, VW>(z + e0, zv);
-    if (res) load_vec<T, VW>(res + e0, rv);
+    if (res) load_vec<T, VW, true>(res + e0, rv);
     if (D.on) {
       if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
@@ -170,8 +183,8 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
     } else {
       load_vec<T, VW>(out + e0, ov);
     }
-    load_vec<T, VW>(z + e0, zv);
-    if (HASR) load_vec<T, VW>(r + e0, rv);
+    load_vec<T, VW, true>(z + e0, zv);
+    if (HASR) load_vec<T, VW, true>(r + e0, rv);
     if (D.on) {
       if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
     }
     float dv[VW], xv[VW], m[VW];
     load_vec<T, VW>(d + e0, dv);
-    if (x) load_vec<T, VW>(x + e0, xv);
+    if (x) load_vec<T, VW, true>(x + e0, xv);
     if (D.on) {
       if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
