@@ -21,6 +21,15 @@
 
 extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
 
+// cache policy (raw buffer `aux`: 2 = nt, streaming) of the loads that read a tensor exactly once: x (the block input, from
+// the forward pass -- cold) and the residual addend.  Experiment builds override.
+#ifndef RCB_X_AUX
+#define RCB_X_AUX 0
+#endif
+#ifndef RCB_ADD_AUX
+#define RCB_ADD_AUX 0
+#endif
+
 namespace {
 
 struct RcBwdParams {
@@ -123,8 +132,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       f[0] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u};
       f[1] = u32x4{0u, 0u, 0u, 0u};
     } else {
-      f[0] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff, 0, 0);
-      f[1] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u, 0, 0);
+      f[0] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff, 0, RCB_X_AUX);
+      f[1] = __builtin_amdgcn_raw_buffer_load_b128(r, xoff + 32u, 0, RCB_X_AUX);
     }
   };
 
@@ -189,8 +198,8 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       u32x4 av[2];
       if constexpr (ADD) {
         const rsrc_t ra = make_rsrc(addg + fo, xfrm_b);
-        av[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp) * orow_b, 0, 0);
-        av[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp + 1) * orow_b, 0, 0);
+        av[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp) * orow_b, 0, RCB_ADD_AUX);
+        av[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp + 1) * orow_b, 0, RCB_ADD_AUX);
       }
       const u32x4 u0 = *reinterpret_cast<const u32x4*>(img + rp * BIMG_RS + 8 * chunk);
       const u32x4 u1 = *reinterpret_cast<const u32x4*>(img + rp * BIMG_RS + 8 * chunk + 4);
