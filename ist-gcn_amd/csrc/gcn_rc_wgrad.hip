@@ -22,6 +22,14 @@
 
 extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1, void* stream);
 
+// cache policy (raw buffer `aux`: 2 = nt) of the staging loads; experiment builds override
+#ifndef RCW_X_AUX
+#define RCW_X_AUX 0
+#endif
+#ifndef RCW_DY_AUX
+#define RCW_DY_AUX 0
+#endif
+
 namespace {
 
 struct RcWgParams {
@@ -136,10 +144,10 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_wgrad_kernel(const RcWgParam
       rx[0] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), 0u, 0u};
     } else {
 #pragma unroll
-      for (int j = 0; j < NITX; ++j) rx[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, gx_off[j], 0, 0);
+      for (int j = 0; j < NITX; ++j) rx[j] = __builtin_amdgcn_raw_buffer_load_b128(r0, gx_off[j], 0, RCW_X_AUX);
     }
 #pragma unroll
-    for (int j = 0; j < NITD; ++j) rd[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, gd_off[j], 0, 0);
+    for (int j = 0; j < NITD; ++j) rd[j] = __builtin_amdgcn_raw_buffer_load_b128(r1, gd_off[j], 0, RCW_DY_AUX);
   };
   auto commit = [&](int half, u32x4 (&rx)[NITX], u32x4 (&rd)[NITD]) __attribute__((always_inline)) {
     T* bufp = lds + half * BUF;

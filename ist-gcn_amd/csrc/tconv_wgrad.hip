@@ -708,6 +708,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // One raw s_barrier per tile.  Loads of tile k+2 are issued after the commit of tile k+1 (so the commit's wait is simply
 // "everything outstanding" and the number of loads per tile may vary).
 // ======================================================================================================================
+// cache policy of the wave-specialised kernel's global loads (experiment builds: -DTWG_NT_U / -DTWG_NT_DZ = streaming loads)
+#ifdef TWG_NT_U
+#define TWG_LD_U(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+#else
+#define TWG_LD_U(p) (*reinterpret_cast<const u32x4*>(p))
+#endif
+#ifdef TWG_NT_DZ
+#define TWG_LD_DZ(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
+#else
+#define TWG_LD_DZ(p) (*reinterpret_cast<const u32x4*>(p))
+#endif
 constexpr int WS_NROLE = 256;
 constexpr int WS_NTH = 2 * WS_NROLE;
 constexpr int WS_UZ = 4;              // dz vectors per memory thread and tile: 128 rows x 8 vectors / 256
@@ -934,9 +945,9 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       const T* ub = gg + (t.valid ? (t.row0 + t.lo) * P.Cin + i0 : 0);              // first row that exists
       if (interior(t)) {
 #pragma unroll
-        for (int u = 0; u < WS_UZ; ++u) RZ[u] = *reinterpret_cast<const u32x4*>(zb + zoffm[u]);
+        for (int u = 0; u < WS_UZ; ++u) RZ[u] = TWG_LD_DZ(zb + zoffm[u]);
 #pragma unroll
-        for (int u = 0; u < WS_US; ++u) RS[u] = *reinterpret_cast<const u32x4*>(ub + uoffm[u]);
+        for (int u = 0; u < WS_US; ++u) RS[u] = TWG_LD_U(ub + uoffm[u]);
         return;
       }
       const unsigned ushift = (unsigned)(t.lo * P.Cin);
@@ -944,13 +955,13 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       for (int u = 0; u < WS_UZ; ++u) {
         const int r = (ltid >> 3) + u * (WS_NROLE / 8);
         const bool live = zlive_q && r < t.rows;
-        RZ[u] = *reinterpret_cast<const u32x4*>(zb + (live ? zoff[u] : 0u));
+        RZ[u] = TWG_LD_DZ(zb + (live ? zoff[u] : 0u));
       }
 #pragma unroll
       for (int u = 0; u < WS_US; ++u) {
         const int r = (ltid >> 3) + u * (WS_NROLE / 8);
         const bool live = ulive_q && r >= t.lo && r < t.hi;
-        RS[u] = *reinterpret_cast<const u32x4*>(ub + (live ? uoff[u] - ushift : 0u));
+        RS[u] = TWG_LD_U(ub + (live ? uoff[u] - ushift : 0u));
       }
     };
     auto commit = [&](int k, const TPos& c, int w, bool fresh, u32x4 (&RZ)[WS_UZ], u32x4 (&RS)[WS_US]) __attribute__((always_inline)) {
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
         for (int u = 0; u < WS_UF - WS_US; ++u) {
           const int r = (ltid >> 3) + u * (WS_NROLE / 8);
           const bool live = ulive_q && r >= f.lo && r < f.hi;
-          RX[u] = *reinterpret_cast<const u32x4*>(ub + (live ? uoff[u] - ushift : 0u));
+          RX[u] = TWG_LD_U(ub + (live ? uoff[u] - ushift : 0u));
         }
 #pragma unroll
         for (int u = 0; u < WS_UF - WS_US; ++u) {
@@ -1534,10 +1545,10 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
       const T* xb = xg + pos0 * P.Cin + (valid ? i0 : 0);
 #pragma unroll
       for (int u = 0; u < UZ; ++u)
-        RZ[u] = *reinterpret_cast<const u32x4*>(zb + ((zlive_q && rz0 + u * RZS < rows) ? zoff[u] : 0u));
+        RZ[u] = TWG_LD_DZ(zb + ((zlive_q && rz0 + u * RZS < rows) ? zoff[u] : 0u));
 #pragma unroll
       for (int u = 0; u < WS_UZ; ++u)
-        RX[u] = *reinterpret_cast<const u32x4*>(xb + ((xlive_q && rx0 + u * RXS < rows) ? xoff[u] : 0u));
+        RX[u] = TWG_LD_U(xb + ((xlive_q && rx0 + u * RXS < rows) ? xoff[u] : 0u));
     };
     auto commit = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
       if (k >= ntile) return;
