@@ -327,9 +327,22 @@ __global__ __launch_bounds__(NT) void pool_bwd_kernel(const float* dfeat, T* dy,
   }
 }
 
-static inline int ew_grid(size_t items) {
+// Persistent-grid caps (workgroups of 256 threads) of the streaming passes, measured over the whole step (config 2, ms/step
+// of the family; the cap decides how many concurrent sequential streams HBM sees): affine2 512: 1.66, 768: 1.51, 1024: 1.50,
+// 1536: 1.52, 2048: 1.61, 4096: 1.49, 8192: 1.46 (but block_out_fwd 0.94 there); block_out_fwd 512: 0.83, 768 / 1024: 0.73,
+// 2048: 0.78; block_out_bwd 512: 1.07, 768: 0.92, 1024: 0.98, 1536: 1.05, 3072: 1.57.  -DISTGCN_X_*CAP override (experiments).
+#ifndef ISTGCN_X_EWCAP
+#define ISTGCN_X_EWCAP 2048
+#endif
+#ifndef ISTGCN_X_BOFCAP
+#define ISTGCN_X_BOFCAP 1024
+#endif
+#ifndef ISTGCN_X_AFFCAP
+#define ISTGCN_X_AFFCAP 1024
+#endif
+static inline int ew_grid(size_t items, size_t cap = ISTGCN_X_EWCAP) {
   size_t g = (items + NT - 1) / NT;
-  if (g > 2048) g = 2048;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -434,7 +447,7 @@ extern "C" int istgcn_block_out_fwd(const void* z, const float* coef2, const voi
   // the mask is one byte per WHOLE vector: both directions must use the vector map (istgcn_relu_mask_ok)
   if (relu_mask && !istgcn_relu_mask_ok(C, dtype)) return ISTGCN_EINVAL;
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
-  const dim3 grid(ew_grid((size_t)rows * (C / vw)));
+  const dim3 grid(ew_grid((size_t)rows * (C / vw), ISTGCN_X_BOFCAP));
   EW_CASES(DISPATCH_VW(block_out_fwd_kernel, ET, VWB, grid, (const ET*)z, coef2, (const ET*)res, coefr, (ET*)out,
                        relu_mask, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
@@ -457,7 +470,11 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const uns
   size_t g = ((size_t)rows + rpb - 1) / rpb;
   // persistent grid = the resident workgroups: 4 per CU with the residual BatchNorm's constants in registers (120 VGPRs),
   // 6 per CU without them (75)
-  const size_t gcap = r ? 1024 : 1536;
+#ifdef ISTGCN_X_BOBCAP
+  const size_t gcap = ISTGCN_X_BOBCAP;
+#else
+  const size_t gcap = 768;               // (measured, above; was 1536 / 1024 with the residual BatchNorm)
+#endif
   if (g > gcap) g = gcap;
   const dim3 grid((int)g);
   BnTail tail{};
@@ -482,7 +499,7 @@ extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, vo
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
-  const dim3 grid(ew_grid((size_t)rows * (C / vw)));
+  const dim3 grid(ew_grid((size_t)rows * (C / vw), ISTGCN_X_AFFCAP));
   EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
