@@ -56,6 +56,15 @@ PROFILE = None
 PROFILE_ONLY = None     # if set: only launches of this entry point are timed (keeps the event overhead off the others)
 
 
+# Experiment hook: ISTGCN_GRID_CAPS="istgcn_bneck_in=512,istgcn_gcn_fwd=128" replaces a grid_cap of 0 (= as many workgroups as are
+# resident) in the named entry points' wrappers (tools: sweeps of the persistent-grid sizes over a whole step).
+GRID_CAPS = {k: int(v) for k, v in (kv.split('=') for kv in os.environ.get('ISTGCN_GRID_CAPS', '').split(',') if '=' in kv)}
+
+
+def _gcap(name, grid_cap):
+    return grid_cap if grid_cap else GRID_CAPS.get(name, 0)
+
+
 def _call(fn_name, *args, work=None, dev=None, family=None):
     """dev: device of the tensors (from _check_dev).  The library launches on the CURRENT HIP device, so when the
     tensors live elsewhere (a model moved with .to('cuda:1') while cuda:0 is current) the call runs under a device
@@ -178,7 +187,7 @@ def gcn_forward(x, A, wp, cout, bterm=None, addend=None, out=None, stats=None, T
     dv = _check_dev(x, A, wp, bterm, addend, out, stats)
     _call('istgcn_gcn_fwd', _ptr(x), _ptr(A), _ptr(wp), _ptr(bterm), _ptr(addend), _ptr(out), _ptr(stats),
           0 if stats is None else stats.shape[0], _ptr(status), NM, Tin, Tout, Tlog, V, Cin, cout, K,
-          in_t_stride, out_t_stride, int(nnz_cap), dtype_code(x), grid_cap, _stream(x),
+          in_t_stride, out_t_stride, int(nnz_cap), dtype_code(x), _gcap('istgcn_gcn_fwd', grid_cap), _stream(x),
           work=(2.0 * NM * Tlog * V * cout * K * Cin + 2.0 * NM * Tlog * V * V * K * cout,      # 1x1 conv + dense einsum
                 float(NM * Tlog * V) * (Cin + cout * (2 if addend is not None else 1)) * _esz(x)), dev=dv)
     if status is not None and int(status.item()) != 0:
@@ -256,7 +265,7 @@ def tconv(x, wp, cout, tap_off, bias=None, pre=None, pre_relu=False, aux=None, m
     dv = _check_dev(x, wp, bias, pre, aux, maux, out, stats)
     _call('istgcn_tconv', _ptr(x), _ptr(wp), _ptr(bias), _ptr(pre), int(bool(pre_relu)), _ptr(aux), _ptr(maux),
           _ptr(out), _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, Cin, cout,
-          len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), grid_cap, _stream(x),
+          len(tap_off), _int_array(tap_off), in_mul, out_mul, out_off, dtype_code(x), _gcap('istgcn_tconv', grid_cap), _stream(x),
           work=(2.0 * NM * Mlog * V * cout * Cin * len(tap_off),
                 float(NM * V) * (min(Tin, Mlog * in_mul) * Cin + Mlog * cout * (2 if (mode == 1 or aux is not None) else 1)) * _esz(x)), dev=dv)
     return out
@@ -288,7 +297,7 @@ def bneck_in(x, W, Wp, bias=None, pre=None, pre_relu=False, grid_cap=0):
     dv = _check_dev(x, bias, pre, y)
     assert W.device == x.device                              # (strided view: not for _check_dev's contiguity test)
     _call('istgcn_bneck_in', _ptr(x), _ptr(W), ctypes.c_longlong(W.stride(0)), ctypes.c_longlong(W.stride(1)), _ptr(bias),
-          _ptr(pre), int(bool(pre_relu)), _ptr(y), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(x), grid_cap, _stream(x),
+          _ptr(pre), int(bool(pre_relu)), _ptr(y), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(x), _gcap('istgcn_bneck_in', grid_cap), _stream(x),
           work=(2.0 * rows * C * Wn, float(rows) * (C + Wp) * _esz(x)), dev=dv, family='istgcn_bneck')
     return y
 
@@ -323,7 +332,7 @@ def bneck_out(q, Wt, tap_sel, off0, We, C, bt=None, be=None, aux=None, maux=None
           ctypes.c_longlong(Wt.stride(2)), _int_array(tap_sel), len(tap_sel), int(off0), _ptr(bt), _ptr(yb), _ptr(We),
           ctypes.c_longlong(We.stride(0)), ctypes.c_longlong(We.stride(1)), _ptr(be), _ptr(z), _ptr(aux), _ptr(maux),
           _ptr(stats), 0 if stats is None else stats.shape[0], mode, NM, Tin, Tout, Mlog, V, C, Wn, Wp, in_mul, out_mul,
-          out_off, dtype_code(q), grid_cap, _stream(q),
+          out_off, dtype_code(q), _gcap('istgcn_bneck_out', grid_cap), _stream(q),
           work=(2.0 * NM * Mlog * V * Wn * (Wn * len(tap_sel) + C),
                 float(NM * V) * (min(Tin, Mlog * in_mul) * Wp + Mlog * (Wp + C * (2 if mode == 1 else 1))) * _esz(q)),
           dev=dv, family='istgcn_bneck')
@@ -344,7 +353,7 @@ def bneck_wgrad(wide, nrw, wide_is_out, pre=None, pre_relu=False, want_bias=True
     db = torch.zeros((C if wide_is_out else Wp,), dtype=torch.float32, device=wide.device) if want_bias else None
     dv = _check_dev(wide, nrw, pre, dW, db)
     _call('istgcn_bneck_wgrad', _ptr(wide), _ptr(nrw), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db),
-          int(bool(wide_is_out)), int(bool(wide_is_out)), ctypes.c_longlong(rows), C, Wp, dtype_code(wide), grid_cap,
+          int(bool(wide_is_out)), int(bool(wide_is_out)), ctypes.c_longlong(rows), C, Wp, dtype_code(wide), _gcap('istgcn_bneck_wgrad', grid_cap),
           _ptr(_wgrad_ws(wide.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(wide),
           work=(2.0 * rows * C * Wp, float(rows) * (C + Wp) * _esz(wide)), dev=dv, family='istgcn_bneck_wgrad')
     return dW, db
@@ -359,7 +368,7 @@ def bneck_wgrad_taps(dy, q, ntaps, off0, in_mul=1, want_bias=True, grid_cap=0):
     db = torch.zeros((Wp,), dtype=torch.float32, device=dy.device) if want_bias else None
     dv = _check_dev(dy, q, dW, db)
     _call('istgcn_bneck_wgrad_taps', _ptr(dy), _ptr(q), _ptr(dW), _ptr(db), NM, Tin, Tz, V, Wp, ntaps, int(off0), in_mul,
-          dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dy.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
+          dtype_code(dy), _gcap('istgcn_bneck_wgrad_taps', grid_cap), _ptr(_wgrad_ws(dy.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
           work=(2.0 * NM * Tz * V * Wp * Wp * ntaps, float(NM * V) * (Tz + Tin) * Wp * _esz(dy)), dev=dv,
           family='istgcn_bneck_wgrad')
     return dW, db
@@ -387,7 +396,7 @@ def bneck_bwd_in(dres, z, abc, yb, W, Wp, p_drop=0.0, seed=0, epoch=None, grid_c
     assert W.device == dres.device
     _call('istgcn_bneck_bwd_in', _ptr(dres), _ptr(z), _ptr(abc), ctypes.c_float(p_drop), ctypes.c_ulonglong(seed),
           _epoch_ptr(epoch, dres), _ptr(yb), _ptr(W), ctypes.c_longlong(W.stride(0)), ctypes.c_longlong(W.stride(1)),
-          _ptr(dyb), _ptr(dW), _ptr(db), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(dres), grid_cap,
+          _ptr(dyb), _ptr(dW), _ptr(db), ctypes.c_longlong(rows), C, Wn, Wp, dtype_code(dres), _gcap('istgcn_bneck_bwd_in', grid_cap),
           _ptr(_wgrad_ws(dres.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dres),
           work=(4.0 * rows * C * Wp + 4.0 * rows * C, float(rows) * (2 * C + 2 * Wp) * _esz(dres)), dev=dv, family='istgcn_bneck')
     return dyb, dW, db
@@ -473,7 +482,7 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
         db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
     dv = _check_dev(dz, g, pre, dW, db)
     _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
-          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), grid_cap,
+          V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), _gcap('istgcn_tconv_wgrad', grid_cap),
           _ptr(_wgrad_ws(dz.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dz),
           work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)), dev=dv)
     return dW, db
@@ -567,7 +576,7 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
                            '4096 pattern entries (got nnz_cap = %d): pass a sparser `pattern`' % (V, nnz_cap))
     dv = _check_dev(dy, x, A, pattern, wb, addend, dx, dA)
     _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(pattern), _ptr(wb), _ptr(addend), _ptr(dx),
-          _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), grid_cap, _stream(dy),
+          _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), _gcap('istgcn_gcn_bwd_data', grid_cap), _stream(dy),
           work=(2.0 * NM * T * V * Cout * K * Cin + 2.0 * NM * T * V * V * K * Cin,
                 float(NM * T * V) * (Cout + Cin * (1 + (1 if want_dA else 0) + (1 if addend is not None else 0))) * _esz(dy)), dev=dv)
     return dx, dA
@@ -590,7 +599,7 @@ def gcn_wgrad(dy, x, A, want_S=True, nnz_cap=None, grid_cap=0, out=None):
         nnz_cap = K * V * V
     dv = _check_dev(dy, x, A, dW, S)
     _call('istgcn_gcn_wgrad', _ptr(dy), _ptr(x), _ptr(A), _ptr(dW), _ptr(S), NM, T, V, Cin, Cout, K, int(nnz_cap),
-          dtype_code(dy), grid_cap, _ptr(_wgrad_ws(dev)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
+          dtype_code(dy), _gcap('istgcn_gcn_wgrad', grid_cap), _ptr(_wgrad_ws(dev)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dy),
           work=(2.0 * NM * T * V * Cout * K * Cin, float(NM * T * V) * (Cout + Cin) * _esz(dy)), dev=dv)
     return dW, S
 
