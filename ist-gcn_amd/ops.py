@@ -14,7 +14,7 @@ from . import _lib
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 _DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}
-STATS_REP = 8          # replicated BatchNorm partial-sum rows (spreads the fp64 atomics)
+STATS_REP = int(os.environ.get('ISTGCN_STATS_REP', '8'))          # replicated BatchNorm partial-sum rows (spreads the fp64 atomics)
 
 
 def dtype_code(t):
