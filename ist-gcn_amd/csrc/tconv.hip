@@ -35,6 +35,7 @@
 // (round 1: two 4-wave workgroups per CU, each running stage -> barrier -> MFMA -> barrier -> epilogue in sequence) 40 %
 // of the time was un-overlapped staging and epilogue.
 #include "common.hpp"
+#include "gcn_rc.hpp"     // rsrc_t / make_rsrc
 #include "bn_tail.hpp"
 #include <cstdlib>
 #include <type_traits>
@@ -65,6 +66,7 @@ struct TconvParams {
   unsigned tps_magic, nch_magic;
   int us_stride, out_stride, off_stat, off_u0, off_u1, off_o;
   int cin_pad;           // nch * CC: length of the LDS copies of the `pre` rows
+  unsigned long long* dbg;   // experiment builds (-DISTGCN_TCONV_STAMP): cycle stamps of workgroup 0 (null otherwise)
   int abl;               // diagnostic ablation (ISTGCN_TCONV_ABL): 1 = no input loads, 2 = no MFMAs; results are then wrong
   BnTail tail;           // "last workgroup finalises" the BatchNorm behind these sums (bn_tail.hpp), when the caller armed it
 };
@@ -85,6 +87,11 @@ __device__ static inline void lds_barrier() {
 constexpr bool TCONV_X_NOMFMA = true;
 #else
 constexpr bool TCONV_X_NOMFMA = false;
+#endif
+#ifdef ISTGCN_TCONV_STAMP   /* experiment build: where the cycles of one compute wave and one memory wave of workgroup 0 go */
+#define TSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define TSTAMP(i)
 #endif
 constexpr int UL = 8;     // 16-byte vectors of a staged chunk per memory-wave thread (rows x vectors <= UL * 256, checked on the host)
 
@@ -172,6 +179,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
 #ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
   if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
 #endif
+#ifdef ISTGCN_TCONV_STAMP
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   if (is_compute) {
     // =========================================== compute waves ===========================================
     // One wave per SIMD issues all the MFMAs, so nothing may stall it: the weight fragments come from L2 (500-900 cycles)
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     for (int d = 0; d < DA - 1; ++d) load_a(a[d]);         // in flight while the first chunk is being staged
     lds_barrier();                                          // item 0 staged (the memory waves' prologue)
     int ch = 0, k = 0;
+    TSTAMP(5)
     for (int it = 0; it < total_items; ++it) {
       if (ch == 0) {
         // tile start: accumulators = conv bias (rows of the D tile = output channels: 4 consecutive per register quad),
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       sb = 0; kgb = 0; soffb = roff0 * P.us_stride;         // taps are an arithmetic progression (checked on the host)
 #pragma unroll
       for (int d = 0; d < PD; ++d) load_b(b[d]);
+      TSTAMP(0)                                             // tile start + ring prologue
       // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations two steps ahead),
       // which are independent of each other: sched_group_barrier asks for them to be INTERLEAVED -- one MFMA, then a few
       // of the other instructions in the 32-cycle shadow of that MFMA -- instead of a clump of ~50 address / load
@@ -298,8 +310,10 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         TCONV_STEP(0, true) TCONV_STEP(1, true) TCONV_STEP(2, true) TCONV_STEP(3, true) TCONV_STEP(4, true) TCONV_STEP(5, true)
       }
 #undef TCONV_STEP
+      TSTAMP(1)                                             // the steps
       us = ubuf((it + 1) & 1);
       lds_barrier();                                        // item done: this half of the tile buffer may be refilled
+      TSTAMP(2)                                             // wait at the item barrier
       if (++ch == nch) {
         ch = 0;
         ++k;
@@ -323,11 +337,16 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
               }
             }
           }
+          TSTAMP(3)                                         // accumulators -> image
           lds_barrier();                                    // image of pass ps complete
           if (ps < NPASS - 1) lds_barrier();                // ... and streamed out by the memory waves: reusable
+          TSTAMP(4)                                         // wait at the image barrier
         }
       }
     }
+#ifdef ISTGCN_TCONV_STAMP
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i]; P.dbg[6] = (unsigned long long)total_items; }
+#endif
   } else {
     // =========================================== memory waves ============================================
     const int Q = P.CC / EPL;                               // 16-byte vectors per staged row: 2 or 4 (power of two)
@@ -335,24 +354,34 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
     const int q = ltid & (Q - 1), r0 = ltid >> lq, RS = NROLE >> lq;
     // ---- global loads of item j -> registers: all UL loads of a thread are in flight together, and they stay in flight
     //      while the previous tile's output image is streamed out (the loads are only waited for in `commit`) ----
+    // byte offset of this thread's u-th vector inside a staged window (row r0 + u*RS, channel vector q of the chunk)
+    unsigned voff[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u)      // (rows past the window's capacity are never staged: permanently out of range, no traffic)
+      voff[u] = r0 + u * RS < P.Fin * V ? (unsigned)(((r0 + u * RS) * P.Cin + q * EPL) * (int)sizeof(T)) : 0x80000000u;
     auto issue = [&](int j, u32x4 (&R)[UL]) __attribute__((always_inline)) {
       const int k = udiv(j, nch, P.nch_magic), ch = j - k * nch;
       const Tile t = tile_of(k);
       const int cb = ch * P.CC;
-      const bool qlive = t.valid && (q * EPL < P.Cin - cb);
-      const T* base = ing + (t.row0 * P.Cin + cb + q * EPL);
+      if constexpr (VEC) {
+        // ONE buffer descriptor per sequence, no per-load predicate: window rows in front of the sequence (negative byte
+        // offset: wraps to > the size) and behind it fall outside the descriptor and read as zeros without touching memory;
+        // past the last item (and under the no-loads ablation) the descriptor is empty.  A constant number of loads per item
+        // is what lets the compiler wait for "all but the UL youngest" instead of for everything.  (Default cache policy
+        // on purpose: the halo rows are re-read by the neighbouring tile from L2; streaming loads measured 14.30 vs 14.03
+        // ms/step.)  A channel vector past Cin in the last chunk reads its row's neighbour; `commit` zeroes it.
+        const unsigned bytes = (t.valid && P.abl != 1) ? (unsigned)(P.Tin * V * P.Cin * (int)sizeof(T)) : 0u;
+        const rsrc_t rs = make_rsrc(ing + (size_t)t.n * P.Tin * V * P.Cin, bytes);
+        const unsigned base = (unsigned)((t.fin0 * V * P.Cin + cb) * (int)sizeof(T));
 #pragma unroll
-      for (int u = 0; u < UL; ++u) {
-        const int r = r0 + u * RS;
-        const bool live = qlive && r >= t.r_lo && r < t.r_hi;
-        if (VEC) {
-          // UNCONDITIONAL load (dead slots read the tensor's first vector and are zeroed in `commit`): a constant number
-          // of loads per item is what lets the compiler wait for "all but the UL youngest" instead of for everything
-          const T* p = (live && P.abl != 1) ? base + (long long)r * P.Cin : ing;
-          // (default cache policy on purpose: the halo rows are re-read by the neighbouring tile from L2; streaming
-          //  loads here measured 14.30 vs 14.03 ms/step)
-          R[u] = *reinterpret_cast<const u32x4*>(p);
-        } else {
+        for (int u = 0; u < UL; ++u) R[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[u] + base, 0, 0));
+      } else {
+        const bool qlive = t.valid && (q * EPL < P.Cin - cb);
+        const T* base = ing + (t.row0 * P.Cin + cb + q * EPL);
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+          const int r = r0 + u * RS;
+          const bool live = qlive && r >= t.r_lo && r < t.r_hi;
           frag_t v;
           zero_frag<T>(v);
           if (live) {
@@ -365,6 +394,10 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       }
     };
     // ---- registers of item j -> BatchNorm affine + ReLU -> LDS tile (zero rows outside the sequence / chunk) ----
+    // Branch-free per vector: every vector is transformed (pairs of elements on the packed-math pipe) and the rows that do
+    // not exist are masked to zero afterwards -- they are rare (sequence edges), and a branch around the transform of each
+    // vector was four branches and ~70 instructions per vector; which of (no transform | affine | affine + ReLU) applies
+    // is decided once per item, outside the sweep
     auto commit = [&](int j, u32x4 (&R)[UL], T* us) __attribute__((always_inline)) {
       const int k = udiv(j, nch, P.nch_magic), ch = j - k * nch;
       const Tile t = tile_of(k);
@@ -380,26 +413,34 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { scv[e4 + e] = sc4[e]; shv[e4 + e] = sh4[e]; }
       }
+      auto sweep = [&](auto has_pre, auto relu) __attribute__((always_inline)) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int u = 0; u < UL; ++u) {
-        const int r = r0 + u * RS;
-        if (r < t.in_rows) {
+        for (int u = 0; u < UL; ++u) {
+          const int r = r0 + u * RS;
           const bool live = qlive && r >= t.r_lo && r < t.r_hi;
           frag_t v = __builtin_bit_cast(frag_t, R[u]);
-          if (!live) zero_frag<T>(v);
-          else if (P.pre) {
+          if constexpr (decltype(has_pre)::value) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              if (VEC || q * EPL + e < c_lim) {
-                float fv = E::to_f(v[e]) * scv[e] + shv[e];
-                if (P.pre_relu) fv = fmaxf(fv, 0.f);
-                v[e] = E::from_f(fv);
-              }
+            for (int e = 0; e < EPL; e += 2) {
+              f32x2 fv = {E::to_f(v[e]), E::to_f(v[e + 1])};
+              const f32x2 sc2 = {scv[e], scv[e + 1]}, sh2 = {shv[e], shv[e + 1]};
+              fv = fv * sc2 + sh2;
+              if constexpr (decltype(relu)::value) fv = __builtin_elementwise_max(fv, f32x2{0.f, 0.f});
+              if (VEC || q * EPL + e < c_lim) v[e] = E::from_f(fv[0]);
+              if (VEC || q * EPL + e + 1 < c_lim) v[e + 1] = E::from_f(fv[1]);
             }
           }
-          *reinterpret_cast<frag_t*>(us + r * P.us_stride + q * EPL) = v;
+          u32x4 w = __builtin_bit_cast(u32x4, v);
+          const unsigned keep = live ? 0xffffffffu : 0u;
+          w &= u32x4{keep, keep, keep, keep};
+          if (r < t.in_rows) *reinterpret_cast<u32x4*>(us + r * P.us_stride + q * EPL) = w;
         }
-      }
+      };
+      using yes = std::integral_constant<bool, true>;
+      using no = std::integral_constant<bool, false>;
+      if (P.pre) { if (P.pre_relu) sweep(yes{}, yes{}); else sweep(yes{}, no{}); }
+      else sweep(no{}, no{});
     };
 
     // ---- output image of pass ps -> HBM with the epilogue math; per-channel sums stay in registers across tiles ----
@@ -562,10 +603,14 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       __builtin_amdgcn_sched_barrier(0);
       issue(it + 2, Rf);                                    // (past the last item: dead slots, same number of loads)
       __builtin_amdgcn_sched_barrier(0);
+      TSTAMP(0)
       if (it + 1 < total_items && P.abl != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
       __builtin_amdgcn_sched_barrier(0);
+      TSTAMP(1)
       if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AV); pending = false; }
+      TSTAMP(2)
       lds_barrier();                                        // item `it` computed, item it+1 staged
+      TSTAMP(3)
       if (ch == nch - 1) {                                  // tile end: take over the output image
         const Tile t = tile_of(k);
 #pragma unroll
@@ -580,8 +625,10 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         }
         pending = true;
         pend = t;
+        TSTAMP(4)
       }
     };
+    TSTAMP(5)
     for (int it = 0; it < total_items; it += 2) {
       iteration(it, RB, RA);
       if (it + 1 < total_items) iteration(it + 1, RA, RB);
@@ -591,6 +638,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       aux_prefetch(pend, NPASS - 1, AVl);
       store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AVl);
     }
+#ifdef ISTGCN_TCONV_STAMP
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) for (int i = 0; i < 6; ++i) P.dbg[8 + i] = tacc[i];
+#endif
 
     // ---- BatchNorm partial sums: registers -> lanes sharing a channel vector -> LDS ----
     if (P.stats) {
@@ -706,6 +756,9 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
   const size_t lds = G.lds;
   const char* e_abl = getenv("ISTGCN_TCONV_ABL");
   P.abl = e_abl ? atoi(e_abl) : 0;
+#ifdef ISTGCN_TCONV_STAMP
+  { const char* e_dbg = getenv("ISTGCN_TCONV_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
+#endif
   // compute-wave layout: two channel groups x two row groups wherever there are two channel tiles to split
 #define CASE(MTv, NTv, WMv) if (G.MT == MTv && G.NT == NTv) return launch4<T, MTv, NTv, WMv>(P, grid_cap, G.gy, lds, stream)
 #ifdef ISTGCN_TCONV_ONE          /* ISA inspection builds: one instantiation */
@@ -769,6 +822,8 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   for (int j = 2; j < ntaps; ++j)      // taps must be equally spaced (every forward / data-gradient phase of a conv is)
     if (tap_off[j] - tap_off[j - 1] != tap_off[1] - tap_off[0]) return ISTGCN_EINVAL;
   if (NM == 0 || Mlog == 0) return ISTGCN_OK;
+  // (the staging loads address one sequence through a 32-bit buffer descriptor)
+  if ((long long)Tin * V * Cin * (dtype == 0 ? 4 : 2) >= (1ll << 31)) return ISTGCN_EINVAL;
   if (tconv_use_v1(Cin, Cout))
     return istgcn_tconv_v1(in, Wp, bias, pre, pre_relu, aux, maux, out, stats, stats_rep, mode, NM, Tin, Tout, Mlog, V, Cin, Cout,
                            ntaps, tap_off, in_mul, out_mul, out_off, dtype, grid_cap, stream);

@@ -14,7 +14,7 @@ constexpr int DA = 6, DB = 3, PD = DB - 1, MTW = 2, NTW = 4;
 constexpr int ROWS = 456, ROWB = 80, LDS_BYTES = ROWS * ROWB;       // staged chunk of a 256-row tile with the 9-tap halo, V = 25
 constexpr int NIT = 18;                                             // steps per item: 9 taps x 2 k-groups
 
-template <bool GLD, bool LDSR, bool POS, int WPS, bool RT = false, bool BAR = false>
+template <bool GLD, bool LDSR, bool POS, int WPS, int RT = 0, bool BAR = false>   // RT: 1 = loop counts at run time, 2 = opaque row offsets, 3 = both
 __global__ __launch_bounds__(256, WPS) void mix(const u32x4* __restrict__ W, int nfrag_steps, float* out, int chunks, int V, int nit_rt, int nkg_rt, int stag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   for (int i = threadIdx.x; i < LDS_BYTES / 16; i += 256) {
@@ -29,9 +29,9 @@ __global__ __launch_bounds__(256, WPS) void mix(const u32x4* __restrict__ W, int
   int brow[NTW];
   for (int t = 0; t < NTW; ++t) {
     brow[t] = (wr * 128 + t * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-    if (RT) asm volatile("" : "+v"(brow[t]));      // as in the kernel: per-row table lookups, not base + constant
+    if (RT & 2) asm volatile("" : "+v"(brow[t]));      // as in the kernel: per-row table lookups, not base + constant
   }
-  const int nit = RT ? nit_rt : NIT, nkg = RT ? nkg_rt : 2;
+  const int nit = (RT & 1) ? nit_rt : NIT, nkg = (RT & 1) ? nkg_rt : 2;
   const u32x4* abase = W + (size_t)(wm * MTW) * 64 + lane;
   const size_t astride = 4 * 64;                                     // four channel tiles per step
   const size_t alimit = (size_t)nfrag_steps * astride;
@@ -96,7 +96,7 @@ static u32x4* g_W;
 static float* g_out;
 static int g_cus;
 
-template <bool GLD, bool LDSR, bool POS, int WPS, bool RT = false, bool BAR = false>
+template <bool GLD, bool LDSR, bool POS, int WPS, int RT = 0, bool BAR = false>
 void run(const char* tag, int items, int stag = 0) {
   auto k = mix<GLD, LDSR, POS, WPS, RT, BAR>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -136,9 +136,11 @@ int main(int argc, char** argv) {
   run<true, true, true, 1>("everything (the tconv compute loop)", items);
   run<true, false, true, 1>("+ weight ring (L2), CUs out of phase", items, 7);
   run<true, true, true, 1>("everything, CUs out of phase", items, 7);
-  run<true, true, true, 1, true>("everything, run-time loop parameters", items);
-  run<true, true, true, 1, false, true>("everything + barrier per item", items);
-  run<true, true, true, 1, true, true>("everything, run-time parameters + barrier", items);
+  run<true, true, true, 1, 1>("everything, run-time loop counts", items);
+  run<true, true, true, 1, 2>("everything, opaque row offsets", items);
+  run<true, true, true, 1, 3>("everything, run-time loop parameters", items);
+  run<true, true, true, 1, 0, true>("everything + barrier per item", items);
+  run<true, true, true, 1, 3, true>("everything, run-time parameters + barrier", items);
   run<false, false, false, 2>("MFMAs only", items);
   run<true, false, true, 2>("+ weight ring, walking 590 KB (L2)", items);
   run<false, true, true, 2>("+ activation ring, walking taps (LDS)", items);
