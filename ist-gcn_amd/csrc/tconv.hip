@@ -95,7 +95,7 @@ constexpr bool TCONV_X_NOMFMA = false;
 #endif
 constexpr int UL = 8;     // 16-byte vectors of a staged chunk per memory-wave thread (rows x vectors <= UL * 256, checked on the host)
 
-template <typename T, int MT, int NT, bool VEC, int MODE, int WM>
+template <typename T, int MT, int NT, bool VEC, int MODE, int WM, bool SK>
 __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
   using E = Elem<T>;
   constexpr int EPL = E::EPL;
@@ -248,8 +248,30 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       kgb = adv ? (wrap ? 0 : kgb + 1) : kgb;
       sb += adv ? 1 : 0;
     };
+    // SK ("static k-structure"): two k-groups per tap and a whole number of six-step chunks per item (9 and 15 taps, every
+    // trunk layer) -- a chunk is three taps x two k-groups, so the (tap, k-group) of a step is its position in the unrolled
+    // chunk: the activation offset of a step is chunk base + {0,1,2,3} tap strides (four scalars) + an immediate, the weight
+    // walk a 32-bit offset with one wrap test, and there are no ghost steps.  The generic path's running positions are
+    // ~26 scalar instructions per step (tools/mfma_mix.hip: 6 % of the loop with eight MFMAs per step, twice that with four).
+    // The activation prefetch of an item's last two steps runs one tap past the item: reads of staged-buffer / image bytes
+    // inside the workgroup's LDS whose values are never used (the slots are reloaded by the next item's prologue).
+    unsigned ao = 0;
+    const unsigned astr = (unsigned)astride, alim = (unsigned)alimit;
+    auto load_as = [&](u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int d = 0; d < DA - 1; ++d) load_a(a[d]);         // in flight while the first chunk is being staged
+      for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + ao + (unsigned)(m * 64 * EPL));
+      const unsigned an = ao + astr;
+      ao = an == alim ? 0u : an;
+    };
+    const int ts1 = rstep * P.us_stride;
+    const int tsk[4] = {0, ts1, 2 * ts1, 3 * ts1};
+    int soffc = 0;
+    auto load_bs = [&](u32x4 (&dst)[NTW], int soff) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) dst[tt] = *reinterpret_cast<const u32x4*>(us + brow[tt] + soff);
+    };
+#pragma unroll
+    for (int d = 0; d < DA - 1; ++d) { if constexpr (SK) load_as(a[d]); else load_a(a[d]); }   // in flight while the first chunk is being staged
     lds_barrier();                                          // item 0 staged (the memory waves' prologue)
     int ch = 0, k = 0;
     TSTAMP(5)
@@ -275,6 +297,32 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
           brow[tt] = (p < t.rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0) * P.us_stride + hoff;
         }
       }
+      if constexpr (SK) {
+        soffc = roff0 * P.us_stride;
+#pragma unroll
+        for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
+        TSTAMP(0)                                           // tile start + ring prologue
+#define TCONV_STEP_S(D)                                                                                  \
+        {                                                                                                \
+          load_as(a[((D) + DA - 1) % DA]);                                                               \
+          load_bs(b[((D) + PD) % DB], soffc + tsk[((D) + PD) >> 1] + (((D) + PD) & 1) * KGS);            \
+          _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                \
+            _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) mma_kgroup(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); \
+          _Pragma("unroll") for (int i_ = 0; i_ < MTW * NTW; ++i_) {                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                           \
+          }                                                                                              \
+          __builtin_amdgcn_sched_barrier(0);                                                             \
+        }
+        const int nchunk = nit / DA;
+        for (int c = 0; c < nchunk; ++c) {
+          TCONV_STEP_S(0) TCONV_STEP_S(1) TCONV_STEP_S(2) TCONV_STEP_S(3) TCONV_STEP_S(4) TCONV_STEP_S(5)
+          soffc += tsk[3];
+        }
+#undef TCONV_STEP_S
+      } else {
       sb = 0; kgb = 0; soffb = roff0 * P.us_stride;         // taps are an arithmetic progression (checked on the host)
 #pragma unroll
       for (int d = 0; d < PD; ++d) load_b(b[d]);
@@ -310,6 +358,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         TCONV_STEP(0, true) TCONV_STEP(1, true) TCONV_STEP(2, true) TCONV_STEP(3, true) TCONV_STEP(4, true) TCONV_STEP(5, true)
       }
 #undef TCONV_STEP
+      }
       TSTAMP(1)                                             // the steps
       us = ubuf((it + 1) & 1);
       lds_barrier();                                        // item done: this half of the tile buffer may be refilled
@@ -364,8 +413,8 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       const Tile t = tile_of(k);
       const int cb = ch * P.CC;
       if constexpr (VEC) {
-        // ONE buffer descriptor per sequence, no per-load predicate: window rows in front of the sequence (negative byte
-        // offset: wraps to > the size) and behind it fall outside the descriptor and read as zeros without touching memory;
+        // ONE buffer descriptor per sequence: window rows behind the sequence (and, by an explicit offset, in front of it)
+        // fall outside the descriptor and read as zeros without touching memory;
         // past the last item (and under the no-loads ablation) the descriptor is empty.  A constant number of loads per item
         // is what lets the compiler wait for "all but the UL youngest" instead of for everything.  (Default cache policy
         // on purpose: the halo rows are re-read by the neighbouring tile from L2; streaming loads measured 14.30 vs 14.03
@@ -373,8 +422,13 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         const unsigned bytes = (t.valid && P.abl != 1) ? (unsigned)(P.Tin * V * P.Cin * (int)sizeof(T)) : 0u;
         const rsrc_t rs = make_rsrc(ing + (size_t)t.n * P.Tin * V * P.Cin, bytes);
         const unsigned base = (unsigned)((t.fin0 * V * P.Cin + cb) * (int)sizeof(T));
+        // (rows in FRONT of the sequence get an explicit far-out-of-range offset: their wrapped negative offsets end within
+        //  16 bytes of 2^32, where offset + size overflows 32 bits -- not left to how the range check is evaluated)
 #pragma unroll
-        for (int u = 0; u < UL; ++u) R[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[u] + base, 0, 0));
+        for (int u = 0; u < UL; ++u) {
+          const unsigned off = r0 + u * RS >= t.r_lo ? voff[u] + base : 0x7ffffff0u;
+          R[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
       } else {
         const bool qlive = t.valid && (q * EPL < P.Cin - cb);
         const T* base = ing + (t.row0 * P.Cin + cb + q * EPL);
@@ -677,18 +731,32 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
 template <typename T, int MT, int NT, int WM>
 int launch4(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
-#define GO(VV, MD)                                                                                           \
+  // static k-structure (see the kernel): 16-bit storage, whole channel vectors, two k-groups per tap, taps in threes
+  static const bool sk_off = [] { const char* e = getenv("ISTGCN_TCONV_SK"); return e && atoi(e) == 0; }();
+  // Where it pays (measured, us generic -> SK at NM=128, bf16; profiles/r03_tconv_static_k.txt): the data gradient at every
+  // width (64 ch 136 -> 126, 128 ch 183 -> 171, 256 ch 287 -> 270) and the 64-channel forward (117 -> 113).  NOT the
+  // 128 / 256-channel forward (145 -> 152, 258 -> 272): there the memory waves' BatchNorm + ReLU transform is vector-ALU
+  // work on the same SIMDs, the denser MFMA stream starves it (stamps: `commit` 2297 -> 3857 ticks at 256 channels) and
+  // the compute waves end up waiting longer at the item barrier than the leaner loop saved.
+  const bool sk = sizeof(T) == 2 && vec && P.NKG == 2 && P.ntaps % 3 == 0 && !sk_off && (P.mode == 1 || (P.mode == 0 && MT == 2));
+#define GO(VV, MD, SKV)                                                                                      \
   do {                                                                                                      \
-    auto kfn = tconv_kernel<T, MT, NT, VV, MD, WM>;                                                         \
+    auto kfn = tconv_kernel<T, MT, NT, VV, MD, WM, SKV>;                                                    \
     static std::atomic<unsigned long long> optin{0};                                                        \
     if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;                                    \
     int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTH, lds)) / gy;           \
     gx = round_up(gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx), 8);  /* XCD-affine order: multiple of 8 */ \
     ISTGCN_LAUNCH(kfn, dim3(gx, gy), dim3(NTH), lds, stream, P);                                            \
   } while (0)
-  if (P.mode == 1) { if (vec) GO(true, 1); else GO(false, 1); }
-  else if (P.mode == 2) { if (vec) GO(true, 2); else GO(false, 2); }
-  else { if (vec) GO(true, 0); else GO(false, 0); }
+#define GOV(MD)                                                                                              \
+  do {                                                                                                      \
+    if constexpr (sizeof(T) == 2 && MT >= 2 && (MD == 1 || (MD == 0 && MT == 2))) { if (sk) { GO(true, MD, true); break; } } \
+    if (vec) GO(true, MD, false); else GO(false, MD, false);                                                \
+  } while (0)
+  if (P.mode == 1) GOV(1);
+  else if (P.mode == 2) GOV(2);
+  else GOV(0);
+#undef GOV
 #undef GO
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;

@@ -249,11 +249,19 @@ def test_model_bf16_storage_close_to_fp32(golden, tag):
     assert torch.isfinite(b).all()
     assert gate16('model_bf16 %s whole-gradient rel-L2 vs fp32 HIP' % tag, float((a - b).norm() / a.norm()), gg)
     top = max(float(t.norm()) for t in g32[0] if t is not None)
-    worst = 0.0
+    worst, wsum, wnorm = 0.0, 0.0, 0.0
     for ta, tb in zip(g32[0], g16[0]):
         if ta is not None and float(ta.norm()) > 1e-2 * top:
-            worst = max(worst, 1.0 - float((ta * tb).sum() / (ta.norm() * tb.norm())))
+            d = 1.0 - float((ta * tb).sum() / (ta.norm() * tb.norm()))
+            worst = max(worst, d)
+            wsum += float(ta.norm()) * d
+            wnorm += float(ta.norm())
+    # the worst tensor is a maximum over ~100 tensors of a quantity that moves with the order of the atomics (which ReLU
+    # masks flip): over 12 runs in one process it ranged 0.087-0.164 for st_gcn_mstcn_1x1 (and once left 0.2 in a suite
+    # run), so its gate is a coarse one; the norm-weighted mean of the same quantity is the stable statistic
     assert gate16('model_bf16 %s worst (1 - cosine) over sizeable parameter gradients' % tag, worst, gc)
+    assert gate16('model_bf16 %s norm-weighted mean (1 - cosine) over sizeable parameter gradients' % tag, wsum / wnorm,
+                  BF16_MODEL_COS_MEAN_GATE[tag])
 
 
 def test_extract_feature_shapes():
@@ -589,7 +597,9 @@ def test_model_fp16_storage_close_to_fp32(golden, tag):
 # measured round 3 (bf16: logits .0025/.0023/.0024, gradient .098/.172/.121, 1-cos .060/.088/.098; fp16: logits 4.0e-4/2.8e-4,
 # gradient .055/.036)
 BF16_MODEL_GATE = {'st_gcn_msgcn': (5e-3, 0.2, 0.125), 'st_gcn_multi3_fix_3A_mstcn': (5e-3, 0.25, 0.18),
-                   'st_gcn_mstcn_1x1': (5e-3, 0.25, 0.2)}
+                   'st_gcn_mstcn_1x1': (5e-3, 0.25, 0.4)}
+# (norm-weighted mean, 12 runs each: 0.0180-0.0183 / 0.0349-0.0357 / 0.0343-0.0370 -> gates at 2x)
+BF16_MODEL_COS_MEAN_GATE = {'st_gcn_msgcn': 0.036, 'st_gcn_multi3_fix_3A_mstcn': 0.07, 'st_gcn_mstcn_1x1': 0.072}
 FP16_MODEL_GATE = {'st_gcn_mstcn_1x1_deep': (8e-4, 0.08), 'st_gcn_msgcn': (6e-4, 0.072)}
 FULL_BATCH = [('st_gcn_msgcn', 64, 300, torch.bfloat16), ('st_gcn_msgcn', 64, 300, torch.float16),
               ('st_gcn_multi3_fix_3A_mstcn', 64, 300, torch.bfloat16), ('st_gcn_mstcn_1x1', 256, 300, torch.bfloat16)]
