@@ -110,7 +110,10 @@ def test_blocks_golden(golden, kind, dt):
     #  the 16-bit format -- measured 0.11 in float16 -- so both formats share the gradient gate; outputs are 4x tighter)
     # measured round 3 (max over all fixtures, gpurun_out/err16_measured.txt): bf16 outputs .0062, gradients .149; fp16 outputs
     # 8.3e-4, gradients .058 -> gates at <= 2x
-    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (1.25e-2, 0.15), torch.float16: (1.7e-3, 0.12)}[dt]
+    # (the bf16 gradient gate was 0.15 against a largest entry of 0.1486 -- tcn_end.0.bias of the full IST-GCN block, the same
+    #  value in five runs on the final build: deterministic, but 1 % from the gate; 0.2 keeps it a gate on the entries at
+    #  0.08-0.13 without hanging the suite on the last digit of one ReLU-mask flip)
+    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (1.25e-2, 0.2), torch.float16: (1.7e-3, 0.12)}[dt]
     if dt != torch.float32 and kind == 'st_gcn_mstcn_1x1':
         # the fixture's bottleneck is int(sqrt(16)) = 4 channels wide: 16-bit storage of a 4-channel tensor is mostly noise
         # (measured .259 / .045)
