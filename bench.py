@@ -47,7 +47,7 @@ FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit G
           'istgcn_bneck_wgrad': 'bneck_wgrad (+ taps: bottleneck weight gradients)'}
 
 
-PMC_KEY = {'istgcn_tconv': 'tconv_kernel', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
+PMC_KEY = {'istgcn_tconv': 'tconv kernels', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
            'istgcn_gcn_bwd_data': 'gcn_rc_bwd_kernel', 'istgcn_gcn_wgrad': 'gcn_rc_wgrad_kernel',
            'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
            'istgcn_affine2': 'affine2_kernel', 'istgcn_bneck': 'bneck_in/out kernels', 'istgcn_bneck_wgrad': 'bneck_wgrad kernels'}
@@ -283,7 +283,15 @@ def main():
     roof['algorithmic_bytes_per_launch'] = round(nbytes / n)
     pf = pmc_file(args.model, args.dtype, B)
     if pf and T == (600 if args.model.endswith('deep') else 300):
-        pmc = json.load(open(pf))['kernels'].get(PMC_KEY.get(dom, ''))
+        summary = json.load(open(pf))
+        pmc = summary['kernels'].get(PMC_KEY.get(dom, ''))
+        # the counters are quoted only next to the library they were collected on: the summary carries the hash of the
+        # kernel sources (tools/profile_summarise.py), the loaded library knows the tree it was built from
+        from istgcn_amd import _lib
+        if summary.get('csrc_hash') != _lib.build_id():
+            roof['pmc_stale'] = 'counters in %s were collected on build %s, this library is %s' % (
+                os.path.relpath(pf, ROOT), summary.get('csrc_hash'), _lib.build_id())
+            pmc = None
         if pmc:
             roof['traffic'] = pmc.get('hbm_bytes_avg')
             roof['mfma_util'] = pmc.get('mfma_util')

@@ -275,9 +275,14 @@ int istgcn_input_bwd(const float* raw, const int* shift, const double* move, con
  * buffer the data-parallel all-reduce ran on).  grad_scale folds the 1/world of a SUM all-reduce and the 1/loss_scale
  * of float16 training into the update.  momentum_buf starts at zero (first step: m = g', as torch initialises it).
  * found_inf (device int or NULL): set to 1 if any gradient element is inf / NaN; such elements leave their parameter
- * and momentum untouched (torch.optim.SGD would write the NaN into both for good). */
+ * and momentum untouched (torch.optim.SGD would write the NaN into both for good).
+ * skip_if (device int or NULL): when *skip_if != 0 at launch the WHOLE step is a no-op (and *found_inf is raised) -- the
+ * flag istgcn_grad_nonfinite computed over the same gradient buffer, i.e. torch.cuda.amp.GradScaler's "skip the step on
+ * overflow" for the float16 configuration (static loss scale, BASELINE config 5). */
 int istgcn_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, float lr, float momentum,
-                    float weight_decay, int nesterov, float grad_scale, int* found_inf, void* stream);
+                    float weight_decay, int nesterov, float grad_scale, int* found_inf, const int* skip_if, void* stream);
+/* *flag |= 1 if any of the n gradients is inf / NaN (flag: device int the caller zeroed; grads 16-byte aligned). */
+int istgcn_grad_nonfinite(const float* grads, long long n, int* flag, void* stream);
 
 /* Bottleneck temporal unit of the "1x1" models (16-bit storage; csrc/bneck_rc.hip), replacing the reference's
  *   tcn_start -> conv_1x1_start -> tcn_1/2/3 (x mstcn_importance, summed) -> conv_1x1_end -> tcn_end sums

@@ -31,8 +31,53 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _deps(src, seen=None):
+    """`src` and the csrc headers it includes (transitively): a header edit rebuilds only the sources that see it --
+    tconv.hip alone takes five minutes."""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), re.M):
+        _deps(os.path.join(CSRC, inc), seen)
+    return seen
+
+
+def source_flags(src):
+    """Extra hipcc flags a source asks for in a `// hipcc-flags: ...` line (e.g. tconv_lean.hip: -fno-slp-vectorize)."""
+    import re
+    m = re.search(r'^//\s*hipcc-flags:\s*(.+)$', open(src).read(), re.M)
+    return m.group(1).split() if m else []
+
+
+def csrc_hash():
+    """First 16 hex digits of a SHA-256 over the kernel sources (names + contents, build_id.hip excluded): what
+    `istgcn_build_id()` of a library built from this tree returns."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.hpp'))):
+        if os.path.basename(f) == 'build_id.hip':
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """`istgcn_build_id()` of the LOADED library (the tree hash it was built from), or None for a library without it."""
+    lib = load()
+    if not hasattr(lib, 'istgcn_build_id'):
+        return None
+    lib.istgcn_build_id.restype = ctypes.c_char_p
+    return lib.istgcn_build_id().decode()
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
+        return True
+    idf = LIB_PATH + '.build_id'         # next to the library: it travels to the GPU box with it (the object directory does not)
+    if not os.path.exists(idf) or open(idf).read().strip() != csrc_hash():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.hpp'))
@@ -50,6 +95,9 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(objdir, exist_ok=True)
     flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-I', CSRC]
     procs, objs = [], []
+    tree = csrc_hash()
+    idf = LIB_PATH + '.build_id'
+    stale_id = not os.path.exists(idf) or open(idf).read().strip() != tree
     jobs = jobs or min(8, os.cpu_count() or 1)
     pending = list(sources())
     running = []
@@ -71,12 +119,14 @@ def build(force=False, verbose=False, jobs=None):
     for src in pending:
         obj = os.path.join(objdir, os.path.basename(src) + '.o')
         objs.append(obj)
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and all(os.path.getmtime(obj) > os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.hpp')))):
+        is_id = os.path.basename(src) == 'build_id.hip'
+        if (not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in _deps(src))
+                and not (is_id and stale_id)):
             continue
         while len(running) >= jobs:
             reap(True)
-        p = subprocess.Popen([hipcc] + flags + ['-c', src, '-o', obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        extra = (['-DISTGCN_BUILD_ID="%s"' % tree] if is_id else []) + source_flags(src)
+        p = subprocess.Popen([hipcc] + flags + extra + ['-c', src, '-o', obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         running.append((p, src))
     while running:
         reap(True)
@@ -86,6 +136,8 @@ def build(force=False, verbose=False, jobs=None):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout.decode(errors='replace'))
+    with open(idf, 'w') as f:
+        f.write(tree + '\n')
     return LIB_PATH
 
 

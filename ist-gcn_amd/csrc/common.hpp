@@ -8,6 +8,14 @@
 #include <stdint.h>
 #include <atomic>
 
+// Wave-specialised kernels (one 8-wave workgroup per CU, two roles): which HALF of the workgroup gets which role.  The two
+// waves of a SIMD compete for its vector-issue port and the port goes to the OLDER wave (waves 0-3; s_setprio does not
+// change it: tools/valu_beside_mfma.hip).  256 = the role code written for waves 4-7 runs on waves 0-3 and vice versa
+// (a relabelling of the thread index, nothing else changes).
+#ifndef ISTGCN_ROLE_FLIP
+#define ISTGCN_ROLE_FLIP 0
+#endif
+
 #define ISTGCN_OK 0
 #define ISTGCN_EINVAL 1
 #define ISTGCN_ELAUNCH 2

@@ -13,6 +13,15 @@
 // the (k,i) outputs of the current input-channel chunk are the MFMA rows.  Weight fragments stream from L2 one k-group
 // ahead of the MFMAs that consume them.
 #include "common.hpp"
+// Diagnostic hooks (ablation masks whose results are WRONG, in-kernel cycle stamps with their debug buffer) exist only in
+// experiment builds (-DISTGCN_EXPERIMENT through tools/build_variant.sh); the shipped library reads no such switch.
+#ifdef ISTGCN_EXPERIMENT
+#define X_ABL(P) ((P).abl)
+#define X_DBG(P) ((P).dbg)
+#else
+#define X_ABL(P) 0
+#define X_DBG(P) ((unsigned long long*)nullptr)
+#endif
 
 namespace {
 
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
   T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);
   // dx images of the items, [2][TR][DS] (item parity): the stores of item s-1 overlap the aggregation of item s
 
-  const int tid = threadIdx.x, lane = tid & 63, ltid = tid & (WB_NROLE - 1);
+  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63, ltid = tid & (WB_NROLE - 1);
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_mem = wave8 >= 4;
   const int V = P.V, F = P.F;
@@ -569,8 +578,8 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[kk][r] = 0.f;
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-  if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[6] = tlast - t_begin;
-#define BSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) X_DBG(P)[6] = tlast - t_begin;
+#define BSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 
   if (!is_mem) {
     // ================================================ compute role ================================================
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
       }
     }
     gb_barrier();                                           // the last item's dx image is complete
-    if (P.dbg && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i]; P.dbg[7] = (unsigned long long)nsteps; }
+    if (X_DBG(P) && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 6; ++i) X_DBG(P)[i] = tacc[i]; X_DBG(P)[7] = (unsigned long long)nsteps; }
   } else {
     // ================================================ memory role ================================================
     const int q = ltid & 7, r0 = ltid >> 3;                 // this thread's 16-byte vector of a 64-channel row; rows r0 + 32u
@@ -827,7 +836,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
         BSTAMP(1)
         gb_barrier();                                       // dxa written, x tile staged
         BSTAMP(0)
-        if (P.dA && !(P.abl & 1)) {
+        if (P.dA && !(X_ABL(P) & 1)) {
           const int mw = wave8 - 4;
           const unsigned char* xa = smem + P.off_xb + ((lane & 31) * DS + 16 * mw + 8 * (lane >> 5)) * (int)sizeof(T);
           const unsigned char* db = dxa + (mw >> 1) * TR * 64;
@@ -864,13 +873,13 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
     gb_barrier();
     store_half(0);
     store_half(2);
-    if (P.dbg && blockIdx.x == 0 && ltid == 0) for (int i = 0; i < 6; ++i) P.dbg[8 + i] = tacc[i];
+    if (X_DBG(P) && blockIdx.x == 0 && ltid == 0) for (int i = 0; i < 6; ++i) X_DBG(P)[8 + i] = tacc[i];
   }
 #undef BSTAMP
 
   // ---- adjacency gradient: the four channel-slice shares -> workgroup sums (LDS) -> global, pattern entries only ----
   const unsigned long long t_flush = __builtin_amdgcn_s_memtime();
-  if (P.dbg && blockIdx.x == 0 && tid == 0) P.dbg[14] = t_flush - t_begin;
+  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) X_DBG(P)[14] = t_flush - t_begin;
   if (P.dA) {
     if (is_mem) {
       const int w = lane & 31;
@@ -887,7 +896,7 @@ __global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P
     for (int e = tid; e < K * V * V; e += WB_NTH)
       if (patg[e] != 0.f) atomicAdd(P.dA + e, dal[e]);
   }
-  if (P.dbg && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); P.dbg[15] = __builtin_amdgcn_s_memtime() - t_begin; }
+  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); X_DBG(P)[15] = __builtin_amdgcn_s_memtime() - t_begin; }
 }
 
 template <typename T, int NCHC, bool RESW>
@@ -913,8 +922,9 @@ int launch_ws_n(GbdParams& P, int grid_cap, hipStream_t stream) {
     if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
     int gx = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, WB_NTH, off);
     gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);
-    { const char* e = getenv("ISTGCN_GCNBWD_ABL"); P.abl = e ? atoi(e) : 0; }
     unsigned long long* dbuf = nullptr;
+#ifdef ISTGCN_EXPERIMENT
+    { const char* e = getenv("ISTGCN_GCNBWD_ABL"); P.abl = e ? atoi(e) : 0; }
     if (getenv("ISTGCN_GCNBWD_DBG")) {
       static unsigned long long* dbuf_s = nullptr;
       if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
@@ -922,6 +932,7 @@ int launch_ws_n(GbdParams& P, int grid_cap, hipStream_t stream) {
       (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
       P.dbg = dbuf;
     }
+#endif
     ISTGCN_LAUNCH(kfn, dim3(gx), dim3(WB_NTH), off, stream, P);
     ISTGCN_CHECK_LAUNCH();
     if (dbuf) {
@@ -1049,8 +1060,14 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
   {
-    const char* e = getenv("ISTGCN_GCN_RC");
-    if ((!e || atoi(e) != 0) && V <= 32 && !(dA && Cout > 128 && !getenv("ISTGCN_RC_SPLIT")) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
+    // dispatch override ISTGCN_GCN_RC=0 (the round-2 kernels: A/B timing, one process per setting), read once
+    static const bool rc_on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
+#ifdef ISTGCN_EXPERIMENT
+    static const bool rc_split = getenv("ISTGCN_RC_SPLIT") != nullptr;     // the split-role variant for 256 channels with dA (measured slower)
+#else
+    constexpr bool rc_split = false;
+#endif
+    if (rc_on && V <= 32 && !(dA && Cout > 128 && !rc_split) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
         (Cin != 3 ? dx != nullptr : (!dx && dA && !addend))) {
       const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
       if (off >= 0)

@@ -29,6 +29,15 @@
 // ~45 scalar bookkeeping instructions per contraction step (ring position, chunk wrap, ghost steps); hence the LDS copy
 // of A below and the round-based ring whose loads carry immediate offsets from two uniform base pointers.
 #include "common.hpp"
+// Diagnostic hooks (ablation masks whose results are WRONG, in-kernel cycle stamps with their debug buffer) exist only in
+// experiment builds (-DISTGCN_EXPERIMENT through tools/build_variant.sh); the shipped library reads no such switch.
+#ifdef ISTGCN_EXPERIMENT
+#define X_ABL(P) ((P).abl)
+#define X_DBG(P) ((P).dbg)
+#else
+#define X_ABL(P) 0
+#define X_DBG(P) ((unsigned long long*)nullptr)
+#endif
 
 namespace {
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   constexpr int KGS = E::KGS;
   typedef typename E::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (P.abl & 256) return;
+  if (X_ABL(P) & 256) return;
 
   int* csr_off = reinterpret_cast<int*>(smem);                       // [K*V+1]
   unsigned char* csr_v = smem + P.off_csr_v;                         // [nnz_cap]
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   T* outs = reinterpret_cast<T*>(smem + P.off_o);                    // [128][OSTR]
   constexpr int OSTR = MT * 32 + EPL;                                // image row stride in elements
 
-  const int tid = threadIdx.x;
+  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP);
   const int lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform by construction; tell the compiler
   const bool is_compute = wave8 < 4;
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
     }
   }
   __syncthreads();
-  if (P.abl & 512) return;
+  if (X_ABL(P) & 512) return;
 
   const T* xg = reinterpret_cast<const T*>(P.x);
   const T* Wp = reinterpret_cast<const T*>(P.Wp);
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   const int NC = CT * K;                                                      // unit columns (channel tile, partition)
   const unsigned rcpK = (65536u + K - 1) / K;                                 // c / K for c < 256 as (c * rcpK) >> 16
   auto aggregate = [&](const T* xs, int nf, int w8) __attribute__((always_inline)) {
-    if (P.abl & 1) return;
+    if (X_ABL(P) & 1) return;
     if constexpr (sizeof(T) == 2) if (V <= 32) {
       // 16-bit: aggregation on the matrix cores.  Per unit (column c = (channel tile ct, partition k), frame f):
       // D[i][w] = sum_v x[(f,v)][i] * A_k[v][w], x^T read straight from the row-major tile with ds_read_b64_tr_b16 (rows
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
   };
 
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
-#define STAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#define STAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 
   if (is_compute) {
     // =========================================== compute waves ===========================================
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
         }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
       }
-      const int nround = (P.abl & 2) ? 0 : R;
+      const int nround = (X_ABL(P) & 2) ? 0 : R;
       for (int r = 0; r < nround; ++r) {
         const T* bp[NTW];
 #pragma unroll
@@ -532,8 +541,8 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
       lds_barrier();                                        // B1(it+1): contraction done (+ image), next chunk staged
       STAMP(5)
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-      for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i];
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+      for (int i = 0; i < 6; ++i) X_DBG(P)[i] = tacc[i];
   } else {
     // =========================================== memory waves ============================================
     // Everything a thread needs per item is a wave-uniform base (from the item's cursor) plus per-thread constants:
@@ -710,8 +719,8 @@ __global__ __launch_bounds__(NTH, 2) void gcn_fwd_kernel(const GcnFwdParams P) {
       if (it + 1 < total_items) iteration(it + 1, RA);
     }
     if (pending) store_image(pend_n, pend_tq);
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0)
-      for (int i = 0; i < 6; ++i) P.dbg[8 + i] = tacc[i];
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0)
+      for (int i = 0; i < 6; ++i) X_DBG(P)[8 + i] = tacc[i];
 
     if (P.stats) {
 #pragma unroll
@@ -823,6 +832,7 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
   if (off > 160 * 1024) return ISTGCN_EINVAL;
   P.a_lds = (size_t)P.K * P.V * P.V * 4 <= off - (size_t)P.off_xs0 ? 1 : 0;
   if (P.total_tiles < 1) return ISTGCN_OK;
+#ifdef ISTGCN_EXPERIMENT
   { const char* e = getenv("ISTGCN_GCN_ABL"); P.abl = e ? atoi(e) : 0; }
   if (getenv("ISTGCN_GCN_DBG")) {
     static unsigned long long* dbuf = nullptr;
@@ -838,6 +848,7 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
             P.Cin, P.Cout, P.total_tiles * P.nch / 256, h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
     return rc;
   }
+#endif
   switch (G.MT) {
     case 1: return launch_mt<T, 1>(P, grid_x_cap, G.gy, off, stream);
     case 2: return launch_mt<T, 2>(P, grid_x_cap, G.gy, off, stream);
@@ -866,9 +877,9 @@ extern "C" int istgcn_gcn_fwd_rc(const void* x, const float* A, const void* Wq, 
 extern "C" int istgcn_gcn_fwd_rc_f32(const void* x, const float* A, const void* Wq, const float* bterm, void* y, double* stats,
                                      int stats_rep, int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,
                                      int in_t_stride, int out_t_stride, int grid_cap, void* stream);
-static bool gcn_use_rc() {
-  const char* e = getenv("ISTGCN_GCN_RC");        // read per call: tools/gcn_exp.py A/B-times the two kernels in one process
-  return !e || atoi(e) != 0;
+static bool gcn_use_rc() {       // dispatch override ISTGCN_GCN_RC=0 (A/B timing: one process per setting), read once
+  static const bool on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
+  return on;
 }
 static bool gcn_use_v1(int dtype) {
   static const int forced = [] { const char* e = getenv("ISTGCN_GCN_V1"); return e ? atoi(e) : -1; }();

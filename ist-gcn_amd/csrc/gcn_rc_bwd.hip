@@ -360,8 +360,12 @@ int rc_bwd_nct(const RcBwdParams& P, int grid_cap, hipStream_t stream) {
   // tiles of dx per workgroup: 4 where the slice's weights (K * Cout * 32 * NCT 16-bit elements) fit LDS, else 2
   constexpr bool four = (size_t)K * 16 * SO * 128 * 2 <= 100 * 1024;
   if constexpr (four) {
-    const char* e = getenv("ISTGCN_RC_NCT");            // experiment switch: 2 = two tiles per workgroup slice everywhere
-    if (P.Cin % 128 == 0 && !(e && atoi(e) == 2)) return rc_bwd_flags<T, SO, K, 4>(P, grid_cap, stream);
+#ifdef ISTGCN_EXPERIMENT
+    static const bool two = [] { const char* e = getenv("ISTGCN_RC_NCT"); return e && atoi(e) == 2; }();   // 2 = two tiles per slice everywhere
+#else
+    constexpr bool two = false;
+#endif
+    if (P.Cin % 128 == 0 && !two) return rc_bwd_flags<T, SO, K, 4>(P, grid_cap, stream);
   }
   return rc_bwd_flags<T, SO, K, 2>(P, grid_cap, stream);
 }

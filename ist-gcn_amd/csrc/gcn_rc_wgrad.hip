@@ -361,9 +361,13 @@ int rc_wg_launch(RcWgParams P, int grid_cap, hipStream_t stream) {
 template <typename T, int K>
 int rc_wg_ct(const RcWgParams& P, int grid_cap, hipStream_t stream) {
   if (P.Cin == 3) return rc_wg_launch<T, K, 2, 3>(P, grid_cap, stream);
-  // two output tiles per wave where the flush image of a frame group fits LDS (K <= 3); ISTGCN_GWG_OT=1: one (A/B timing)
-  const char* e = getenv("ISTGCN_GWG_OT");
-  const bool ot2 = K <= 3 && !(e && atoi(e) == 1);
+  // two output tiles per wave where the flush image of a frame group fits LDS (K <= 3)
+#ifdef ISTGCN_EXPERIMENT
+  static const bool one = [] { const char* e = getenv("ISTGCN_GWG_OT"); return e && atoi(e) == 1; }();     // 1: one tile (A/B timing)
+#else
+  constexpr bool one = false;
+#endif
+  const bool ot2 = K <= 3 && !one;
   if constexpr (K <= 3) {
     if (ot2) {
       if (P.Cout % 128 == 0) return rc_wg_launch<T, K, 4, 0, 2>(P, grid_cap, stream);

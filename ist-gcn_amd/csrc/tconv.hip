@@ -37,13 +37,24 @@
 #include "common.hpp"
 #include "gcn_rc.hpp"     // rsrc_t / make_rsrc
 #include "bn_tail.hpp"
+#include "tconv_geom.hpp"
+// Diagnostic ablations (results WRONG) exist only in experiment builds (-DISTGCN_EXPERIMENT, tools/build_variant.sh);
+// the cycle stamps only under -DISTGCN_TCONV_STAMP.  The shipped library reads neither switch.
+#ifdef ISTGCN_EXPERIMENT
+#define X_ABL(P) ((P).abl)
+#else
+#define X_ABL(P) 0
+#endif
 #include <cstdlib>
 #include <type_traits>
 
 
 namespace {
 
-constexpr int NROLE = 256;           // threads per role (4 waves)
+using tconv_geo::NROLE;               // threads per role (4 waves)
+using tconv_geo::UL;
+using tconv_geo::TconvGeom;
+using tconv_geo::tconv_geom;
 constexpr int NTH = 2 * NROLE;       // compute waves 0-3, memory waves 4-7
 constexpr int MAX_TAPS = 16;
 
@@ -93,7 +104,6 @@ constexpr bool TCONV_X_NOMFMA = false;
 #else
 #define TSTAMP(i)
 #endif
-constexpr int UL = 8;     // 16-byte vectors of a staged chunk per memory-wave thread (rows x vectors <= UL * 256, checked on the host)
 
 template <typename T, int MT, int NT, bool VEC, int MODE, int WM, bool SK>
 __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
   auto ubuf = [&](int half) __attribute__((always_inline)) { return reinterpret_cast<T*>(smem + (half ? P.off_u1 : P.off_u0)); };
   T* outs = reinterpret_cast<T*>(smem + P.off_o);                            // [TR][out_stride]
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63;
   const bool is_compute = tid < NROLE;
   const int ltid = tid & (NROLE - 1), wave = ltid >> 6;
   const int V = P.V;
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
         // is what lets the compiler wait for "all but the UL youngest" instead of for everything.  (Default cache policy
         // on purpose: the halo rows are re-read by the neighbouring tile from L2; streaming loads measured 14.30 vs 14.03
         // ms/step.)  A channel vector past Cin in the last chunk reads its row's neighbour; `commit` zeroes it.
-        const unsigned bytes = (t.valid && P.abl != 1) ? (unsigned)(P.Tin * V * P.Cin * (int)sizeof(T)) : 0u;
+        const unsigned bytes = (t.valid && X_ABL(P) != 1) ? (unsigned)(P.Tin * V * P.Cin * (int)sizeof(T)) : 0u;
         const rsrc_t rs = make_rsrc(ing + (size_t)t.n * P.Tin * V * P.Cin, bytes);
         const unsigned base = (unsigned)((t.fin0 * V * P.Cin + cb) * (int)sizeof(T));
         // (rows in FRONT of the sequence get an explicit far-out-of-range offset: their wrapped negative offsets end within
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
           }
         }
       }
-      if (!col_live || P.abl == 4) return;
+      if (!col_live || X_ABL(P) == 4) return;
       // UB rows per batch: their LDS reads and (modes 1, 2) aux loads are all issued before the first is used
       constexpr int UB = 4;
       static_assert(NR % UB == 0 || NR < UB, "rows per thread come in whole batches");
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_kernel(const TconvParams P) {
       issue(it + 2, Rf);                                    // (past the last item: dead slots, same number of loads)
       __builtin_amdgcn_sched_barrier(0);
       TSTAMP(0)
-      if (it + 1 < total_items && P.abl != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
+      if (it + 1 < total_items && X_ABL(P) != 4) commit(it + 1, Rn, ubuf((it + 1) & 1));
       __builtin_amdgcn_sched_barrier(0);
       TSTAMP(1)
       if (pending) { store_pass(pend, NPASS - 1, st1[NPASS - 1], st2[NPASS - 1], AV); pending = false; }
@@ -762,56 +772,6 @@ int launch4(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t 
   return ISTGCN_OK;
 }
 
-// Tiling decision shared by the launcher and the geometry query (the host packs weights to match).
-struct TconvGeom { int CC, nch, NKG, MT, MTtot, gy, NT, F, Fin, min_off, lds, off_stat, off_u0, off_u1, off_o, us_stride, out_stride; };
-
-// nt_max = 1: the short-tile variant (128 rows) for launches too small to give every CU a 256-row tile; the launcher takes
-// it only when the channel chunking -- which the packed weights depend on -- comes out the same as for nt_max = 2.
-inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, TconvGeom* G, int nt_max = 2) {
-  const int epl = dtype == 0 ? 4 : 8, kgs = 2 * epl, esz = dtype == 0 ? 4 : 2;
-  int mn = tap_off[0], mx = tap_off[0];
-  for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
-  G->min_off = mn;
-  G->MT = Cout <= 32 ? 1 : Cout <= 64 ? 2 : 4;
-  G->gy = ceil_div(Cout, G->MT * 32);
-  G->MTtot = G->gy * G->MT;
-  const int ow = 256 / esz;
-  G->out_stride = ow + epl;
-  // double-buffered chunk tile + output image + tables in one CU's LDS; the widest chunk and the tallest tile that fit
-  // (a staged row is CC + EPL elements: 80 bytes at the full chunk width, conflict-free for the 16-byte fragment reads)
-  const int cc_max = dtype == 0 ? 16 : 32;
-  const int budget = 160 * 1024;
-  int best_nt = 0, best_cc = 0;
-  for (int nt = nt_max; nt >= 1 && !best_nt; --nt) {
-    const int F = nt * 128 / V;
-    if (F < 1) continue;
-    for (int cc = cc_max; cc >= kgs; cc >>= 1) {
-      int cce = Cin < cc ? round_up(Cin, kgs) : cc;
-      const int Fin = in_mul * (F - 1) + (mx - mn) + 1;
-      const long rows = (long)Fin * V;
-      const long tables = 1024 + (long)(3 * G->MT * 32 + 2 * round_up(Cin, cce)) * 4 + 64;
-      const long need = tables + 2 * rows * (cce + epl) * esz + (long)128 * nt * G->out_stride * esz;
-      if (need <= budget && rows * (cce / epl) <= UL * NROLE) { best_nt = nt; best_cc = cce; break; }
-    }
-  }
-  if (!best_nt) return ISTGCN_EINVAL;
-  const int cc = best_cc;
-  G->NT = best_nt; G->CC = cc; G->nch = ceil_div(Cin, cc); G->NKG = cc / kgs;
-  if (G->NKG & (G->NKG - 1)) return ISTGCN_EINVAL;
-  G->F = best_nt * 128 / V;
-  G->Fin = in_mul * (G->F - 1) + (mx - mn) + 1;
-  G->us_stride = cc + epl;
-  size_t off = (size_t)2 * 128 * best_nt * sizeof(unsigned short);
-  off = (off + 15) & ~(size_t)15; G->off_stat = (int)off;
-  off += (size_t)(3 * G->MT * 32 + 2 * G->nch * cc) * 4;                     // BN partial sums, conv bias, `pre` rows
-  const size_t ubytes = (((size_t)G->Fin * V * G->us_stride * esz) + 15) & ~(size_t)15;
-  off = (off + 15) & ~(size_t)15; G->off_u0 = (int)off; off += ubytes;
-  G->off_u1 = (int)off; off += ubytes;
-  G->off_o = (int)off; off += (size_t)128 * best_nt * G->out_stride * esz;
-  G->lds = (int)off;
-  return off <= 160 * 1024 ? ISTGCN_OK : ISTGCN_EINVAL;
-}
-
 template <typename T>
 int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t stream) {
   P.F = G.F; P.CC = G.CC; P.nch = G.nch; P.NKG = G.NKG; P.MTtot = G.MTtot; P.min_off = G.min_off; P.Fin = G.Fin;
@@ -822,8 +782,9 @@ int launch_T(TconvParams& P, const TconvGeom& G, int grid_cap, hipStream_t strea
   P.total_tiles = P.NM * P.tiles_per_seq;
   P.tps_magic = (unsigned)(((1ull << 32) + P.tiles_per_seq - 1) / (unsigned long long)P.tiles_per_seq);
   const size_t lds = G.lds;
-  const char* e_abl = getenv("ISTGCN_TCONV_ABL");
-  P.abl = e_abl ? atoi(e_abl) : 0;
+#ifdef ISTGCN_EXPERIMENT
+  { const char* e_abl = getenv("ISTGCN_TCONV_ABL"); P.abl = e_abl ? atoi(e_abl) : 0; }
+#endif
 #ifdef ISTGCN_TCONV_STAMP
   { const char* e_dbg = getenv("ISTGCN_TCONV_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
 #endif
@@ -919,6 +880,9 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
     }
   }
   if (stats) istgcn_bn_tail_take(stats, &P.tail);
+  if (tconv_lean_ok(G, mode, Tin, V, Cin, Cout, ntaps, out_mul, dtype))
+    return tconv_lean_launch(in, Wp, bias, pre, pre_relu, aux, maux, out, stats, stats_rep, mode, NM, Tin, Tout, Mlog, V, Cin, Cout,
+                             ntaps, tap_off, in_mul, out_off, dtype, grid_cap, G, P.tail, (hipStream_t)stream);
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);

@@ -13,6 +13,15 @@
 // position axis straight from the row-major image); fp32 operand registers are double buffered so LDS latency
 // hides behind the MFMAs of the previous k-step.
 #include "common.hpp"
+// Diagnostic hooks (ablation masks whose results are WRONG, in-kernel cycle stamps with their debug buffer) exist only in
+// experiment builds (-DISTGCN_EXPERIMENT through tools/build_variant.sh); the shipped library reads no such switch.
+#ifdef ISTGCN_EXPERIMENT
+#define X_ABL(P) ((P).abl)
+#define X_DBG(P) ((P).dbg)
+#else
+#define X_ABL(P) 0
+#define X_DBG(P) ((unsigned long long*)nullptr)
+#endif
 #include <cstdio>
 #include <cstdlib>
 
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
   constexpr int RB = CB * (int)sizeof(T);                  // bytes per sub-tile row (64)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem + P.off_S);                          // [64] conv-bias column sums
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wave8 < 4;
   const int ltid = tid & (WS_NROLE - 1);
@@ -766,7 +775,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
   const T* gg = reinterpret_cast<const T*>(P.g);
   const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
   const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
-  const int ntile = (t_end > t_begin && !(P.abl & 1)) ? t_end - t_begin : 0;
+  const int ntile = (t_end > t_begin && !(X_ABL(P) & 1)) ? t_end - t_begin : 0;
   const int adv = P.F, keep = P.Fin - adv;                 // frames a window advances by / shares with its predecessor
   // window schedule, computed identically by both roles: tile k is FRESH (window at frame 0, staged whole) at the start of
   // the walk, at a sequence start, or when sliding on would leave the region; otherwise its window is adv frames further on
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
 
   f32x16 acc[JT];
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
-#define WSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#define WSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 #ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
   if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       }
       WSTAMP(1)
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[0] = tacc[0]; P.dbg[1] = tacc[1]; P.dbg[7] = (unsigned long long)ntile; }
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { X_DBG(P)[0] = tacc[0]; X_DBG(P)[1] = tacc[1]; X_DBG(P)[7] = (unsigned long long)ntile; }
   } else {
     // =========================================== memory waves ============================================
     const int q = ltid & 7;                                 // this thread's channel vector of a 64-channel row (both tensors)
@@ -1071,7 +1080,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       iteration(k, ZB, SB, ZA, SA);
       if (k + 1 < ntile) iteration(k + 1, ZA, SA, ZB, SB);
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) { P.dbg[8] = tacc[0]; P.dbg[9] = tacc[1]; P.dbg[10] = tacc[2]; }
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) { X_DBG(P)[8] = tacc[0]; X_DBG(P)[9] = tacc[1]; X_DBG(P)[10] = tacc[2]; }
     if (P.dbias) {
       // threads sharing a channel vector: lanes q, q+8, ... of every memory wave -> LDS (once per kernel)
 #pragma unroll
@@ -1168,8 +1177,9 @@ int launch_ws(TwgParams& P, int grid_cap, hipStream_t stream) {
     const int nsl = gx;
     if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;   // too small / atomics are as fast
     P.ws_slice = n0 + n1;
-    { const char* e = getenv("ISTGCN_WGRAD_ABL"); P.abl = e ? atoi(e) : 0; }
     unsigned long long* dbuf = nullptr;
+#ifdef ISTGCN_EXPERIMENT
+    { const char* e = getenv("ISTGCN_WGRAD_ABL"); P.abl = e ? atoi(e) : 0; }
     if (getenv("ISTGCN_WGRAD_DBG")) {
       static unsigned long long* dbuf_s = nullptr;
       if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
@@ -1177,6 +1187,7 @@ int launch_ws(TwgParams& P, int grid_cap, hipStream_t stream) {
       (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
       P.dbg = dbuf;
     }
+#endif
     ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(WS_NTH), off, stream, P);
     ISTGCN_CHECK_LAUNCH();
     if (dbuf) {
@@ -1247,7 +1258,11 @@ int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   dim3 grid(gx, blocks);
+#ifdef ISTGCN_EXPERIMENT
   static const bool dbg = getenv("ISTGCN_DEBUG") != nullptr;
+#else
+  constexpr bool dbg = false;
+#endif
   if (dbg)
     fprintf(stderr, "[istgcn] wgrad<%s JT=%d OT=%d IT=%d PS=%d TS=%d %s> Cin=%d Cout=%d taps=%d grid=(%d,%d) lds=%zu capf=%d Fin=%d\n",
             esz == 2 ? "16bit" : "f32", JT, OT, IT, PS, TS, AGG ? "agg" : "conv", P.Cin, P.Cout, P.ntaps, gx, blocks, off,
@@ -1347,7 +1362,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
   float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][SLS]
   T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // [K][2][64][8] fragments of A_k
   T* img = reinterpret_cast<T*>(smem + P.off_u);                                  // [2 sub][K][TR][CB]
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_compute = wave8 < 4;
   const int ltid = tid & (WS_NROLE - 1);
@@ -1430,7 +1445,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
 
   f32x16 acc[OTW][KT];
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
-#define GSTAMP(i) if (P.dbg) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#define GSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 #ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
   if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1516,7 +1531,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
       ws_barrier();                                         // B done: images free, tile k+1 staged
       GSTAMP(3)
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 4; ++i) P.dbg[i] = tacc[i]; P.dbg[7] = (unsigned long long)ntile; }
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 4; ++i) X_DBG(P)[i] = tacc[i]; X_DBG(P)[7] = (unsigned long long)ntile; }
     if (s_wave && (lane & 31) < V) {
       // D tile rows = output channel (registers), cols = joint (lanes) -> S_l[w][c] for the common flush below
 #pragma unroll
@@ -1597,7 +1612,7 @@ __global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
       iteration(k, ZB, XB, ZA, XA);
       if (k + 1 < ntile) iteration(k + 1, ZA, XA, ZB, XB);
     }
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) for (int i = 0; i < 5; ++i) P.dbg[8 + i] = tacc[i];
+    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) for (int i = 0; i < 5; ++i) X_DBG(P)[8 + i] = tacc[i];
   }
 #undef GSTAMP
   __syncthreads();
@@ -1686,6 +1701,7 @@ int launch_gws_o(TwgParams& P, int grid_cap, hipStream_t stream) {
     if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;
     P.ws_slice = n0 + n1;
     unsigned long long* dbuf = nullptr;
+#ifdef ISTGCN_EXPERIMENT
     if (getenv("ISTGCN_WGRAD_DBG")) {
       static unsigned long long* dbuf_s = nullptr;
       if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
@@ -1693,6 +1709,7 @@ int launch_gws_o(TwgParams& P, int grid_cap, hipStream_t stream) {
       (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
       P.dbg = dbuf;
     }
+#endif
     ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(WS_NTH), off, stream, P);
     ISTGCN_CHECK_LAUNCH();
     if (dbuf) {
@@ -1764,8 +1781,7 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
     // 32-row frame tiles cost 28 % more matrix work than its 125-of-128-row tiles), and the 16-tap variant has no
     // registers left for its staging pipeline -- those stay with the round-2 kernels.
     // ISTGCN_TWG_RC=0: round-2 kernels everywhere (A/B timing); =2: the frame-tiled kernel wherever it applies
-    const char* e = getenv("ISTGCN_TWG_RC");
-    const int mode = e ? atoi(e) : 1;
+    static const int mode = [] { const char* e = getenv("ISTGCN_TWG_RC"); return e ? atoi(e) : 1; }();   // dispatch override, read once
     if (mode != 0 && istgcn_tconv_wgrad_rc_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype) &&
         (mode == 2 || (in_mul == 2 && ntaps <= 10)))
       return istgcn_tconv_wgrad_rc(dz, g, pre, pre_relu, dW, dbias, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype,
@@ -1813,10 +1829,11 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || T == 0) return ISTGCN_OK;
   {
-    const char* e = getenv("ISTGCN_GCN_RC");        // 0: the round-2 kernels (A/B timing, tools/gcn_exp.py)
-    if ((!e || atoi(e) != 0) && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
+    // dispatch override ISTGCN_GCN_RC=0: the round-2 kernels (A/B timing, one process per setting), read once
+    static const bool rc_on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
+    if (rc_on && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
       return istgcn_gcn_wgrad_rc(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, dtype, grid_cap, ws, ws_floats, stream);
-    if ((!e || atoi(e) != 0) && dtype == 0 && V <= 32 && V >= 20 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
+    if (rc_on && dtype == 0 && V <= 32 && V >= 20 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
       return istgcn_gcn_wgrad_rc_f32(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, grid_cap, ws, ws_floats, stream);
   }
   TwgParams P{};

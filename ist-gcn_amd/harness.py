@@ -4,6 +4,8 @@ Models: optimizer construction, step-LR schedule and one training iteration.  Th
 h5py / tensorboard / prettytable to import and so that bench.py and the parity tests share one definition of a step.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -35,7 +37,7 @@ class FlatSGD:
     before `step()` raises); under hipGraph capture the early launch is skipped and `step()` reduces everything."""
 
     def __init__(self, params, lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-4, loss_scale=1.0, update_fn=None,
-                 overlap=True, early_fraction=0.75):
+                 overlap=True, early_fraction=0.75, skip_nonfinite=None, poll_every=32):
         self.params = [p for p in params if p.requires_grad]
         self.param_groups = [dict(params=self.params, lr=lr, momentum=momentum, nesterov=nesterov,
                                   weight_decay=weight_decay)]
@@ -44,10 +46,21 @@ class FlatSGD:
         self._update = update_fn
         self.P = self.G = self.M = None
         self.found_inf = None              # int32[1] on the device: raised by a non-finite gradient (see check_overflow)
+        # GradScaler's rule for a scaled backward pass: ANY inf / NaN in the (all-reduced) gradients skips the WHOLE update
+        # (a pre-pass over the flat gradient buffer raises a device flag, the update kernel is a no-op when it is set; no
+        # host sync).  Default: on whenever a loss scale is in use (float16 storage).  Off: only the non-finite elements
+        # themselves are left out.  `poll_overflow()` -- called by train_step / GraphedStep -- reads the flag back every
+        # `poll_every` steps and backs the loss scale off.
+        self.skip_nonfinite = (self.loss_scale != 1.0) if skip_nonfinite is None else bool(skip_nonfinite)
+        self.poll_every = int(poll_every)
+        self._nf = None                    # int32[2]: the skip flag of this step / of the previous one (cleared a step later)
+        self._steps = 0
         self._pending_M = None             # momentum loaded before the layout existed (load_state_dict on a fresh optimizer)
         self._pending_order = None         # ... and the layout order it was saved in
         self._live, self._gviews, self._late = [], [], {}
-        self.overlap, self.early_fraction = bool(overlap), float(early_fraction)
+        # ISTGCN_OVERLAP=0: one bucket, all-reduced in step() (the A/B switch for the multi-GPU scaling run)
+        self.overlap = bool(overlap) and os.environ.get('ISTGCN_OVERLAP', '1') != '0'
+        self.early_fraction = float(early_fraction)
         self._arrival, self._seen = [], set()      # first backward: indices into self.params in the order the gradients became final
         self._order = None                 # layout order (indices into self.params) of the live parameters
         self._pos = {}                     # index into self.params -> position in the layout
@@ -117,6 +130,7 @@ class FlatSGD:
             self.G.zero_()
             for p, gv in zip(self._live, self._gviews):
                 p.grad = gv
+            self._arrived = 0
             return
         for p in self.params:
             p.grad = None
@@ -172,6 +186,10 @@ class FlatSGD:
                 if o >= self.early_fraction * total:
                     self._early_n, self._early_end = n, o
                     break
+        if self.sync is not None and self.sync.world > 1:
+            # whether there IS an early bucket depends on rank-local state (which hooks fired): rank 0's cut on every rank,
+            # or one rank would launch two collectives per step and another one (mismatched collectives hang)
+            self._early_n, self._early_end = self.sync.agree_on([self._early_n, self._early_end], dev)
 
     @property
     def bucket_bytes(self):
@@ -209,10 +227,19 @@ class FlatSGD:
             from . import ops
             if self.found_inf is None:
                 self.found_inf = torch.zeros(1, dtype=torch.int32, device=self.P.device)
+            skip = None
+            if self.skip_nonfinite:
+                if self._nf is None:
+                    self._nf = torch.zeros(2, dtype=torch.int32, device=self.P.device)
+                par = self._steps & 1
+                skip = self._nf[par:par + 1]
+                skip.zero_()                                         # (last read by the update of two steps ago)
+                ops.grad_nonfinite(self.G, skip)                     # after the all-reduce: every rank reaches the same verdict
             ops.sgd_step(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale,
-                         found_inf=self.found_inf)
+                         found_inf=self.found_inf, skip_if=skip)
         else:
             upd(self.P, self.G, self.M, grp['lr'], grp['momentum'], grp['weight_decay'], grp['nesterov'], scale)
+        self._steps += 1
         for p in self.params:                                        # slow path: first gradient after the layout was fixed
             if p.grad is not None and id(p) not in self._live_ids:
                 g = p.grad.float() * scale
@@ -225,10 +252,18 @@ class FlatSGD:
                 self._late[id(p)] = buf
                 p.data.add_(g + grp['momentum'] * buf if grp['nesterov'] else buf, alpha=-grp['lr'])
 
+    def poll_overflow(self, backoff=0.5):
+        """check_overflow() every `poll_every` steps (one host sync each time), nothing in between: what train_step and
+        GraphedStep call after every step.  Steps with non-finite gradients in between were skipped on the device."""
+        if self.skip_nonfinite and self.poll_every > 0 and self._steps % self.poll_every == 0:
+            return self.check_overflow(backoff)
+        return False
+
     def check_overflow(self, backoff=0.5):
         """Host poll (one sync) of the non-finite flag the update kernel raises: True if any gradient element since the
-        last poll was inf / NaN (those elements were skipped, parameters and momentum stayed finite).  With a loss scale
-        in use (float16 storage) the scale is multiplied by `backoff`, as a dynamic loss scaler would."""
+        last poll was inf / NaN (with `skip_nonfinite` those steps were skipped as a whole, otherwise the non-finite
+        elements were; parameters and momentum stayed finite either way).  With a loss scale in use (float16 storage)
+        the scale is multiplied by `backoff`, as a dynamic loss scaler would."""
         if self.found_inf is None or int(self.found_inf.item()) == 0:
             return False
         self.found_inf.zero_()
@@ -310,6 +345,8 @@ def train_step(model, optimizer, data, label, grad_sync=None):
     if grad_sync is not None and getattr(optimizer, 'sync', None) is not grad_sync:
         grad_sync()                                       # (FlatSGD with attach_sync all-reduces its own flat buffer)
     optimizer.step()
+    if hasattr(optimizer, 'poll_overflow'):
+        optimizer.poll_overflow()                         # float16 storage: every poll_every steps, back the loss scale off
     return loss.detach()
 
 
@@ -370,6 +407,9 @@ class GraphedStep:
         with torch.cuda.stream(self.stream):
             self.graph.replay()
             self.opt.step()                                # (all-reduce of the flat gradient buffer,) one-launch update
+            if self.opt.poll_overflow():
+                # the scale is baked into the captured backward pass: the graph keeps the OLD scale, so the update must too
+                self.opt.loss_scale = self.ls
         from . import ops
         ops.bump_weights_epoch()                           # the replay wrote BatchNorm running statistics (no Python ran)
         if cur != self.stream:

@@ -951,17 +951,28 @@ def tcn_fold_bwd(dtaps, dbias, w1, w2, w3, b1, b2, b3, mst, scale):
 # ----------------------------------------------------------------------------------------------
 # optimizer (optim.hip)
 # ----------------------------------------------------------------------------------------------
-def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0, found_inf=None):
+def sgd_step(params, grads, momentum_buf, lr, momentum, weight_decay, nesterov, grad_scale=1.0, found_inf=None, skip_if=None):
     """istgcn_sgd_step over three flat fp32 buffers of equal length (in place on params / momentum_buf).  found_inf:
-    int32[1] device tensor raised by a non-finite gradient (those elements are not applied) or None."""
+    int32[1] device tensor raised by a non-finite gradient (those elements are not applied) or None.  skip_if: int32[1]
+    device tensor; non-zero at launch = the whole step is skipped (the flag `grad_nonfinite` computed) or None."""
     n = params.numel()
     assert grads.numel() == n and momentum_buf.numel() == n
     assert params.dtype == grads.dtype == momentum_buf.dtype == torch.float32
-    dv = _check_dev(params, grads, momentum_buf, found_inf)
+    for f in (found_inf, skip_if):
+        assert f is None or (f.dtype == torch.int32 and f.numel() == 1)
+    dv = _check_dev(params, grads, momentum_buf, found_inf, skip_if)
     _call('istgcn_sgd_step', _ptr(params), _ptr(grads), _ptr(momentum_buf), ctypes.c_longlong(n), ctypes.c_float(lr),
           ctypes.c_float(momentum), ctypes.c_float(weight_decay), int(bool(nesterov)), ctypes.c_float(grad_scale),
-          _ptr(found_inf), _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)
+          _ptr(found_inf), _ptr(skip_if), _stream(params), work=(5.0 * n, 20.0 * n), dev=dv)
     bump_weights_epoch()                  # parameters written through raw pointers: cached inference plans are stale
+
+
+def grad_nonfinite(grads, flag):
+    """istgcn_grad_nonfinite: flag (int32[1], zeroed by the caller) |= any(!isfinite(grads)); no host sync."""
+    assert grads.dtype == torch.float32 and flag.dtype == torch.int32 and flag.numel() == 1
+    dv = _check_dev(grads, flag)
+    _call('istgcn_grad_nonfinite', _ptr(grads), ctypes.c_longlong(grads.numel()), _ptr(flag), _stream(grads),
+          work=(float(grads.numel()), 4.0 * grads.numel()), dev=dv)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -56,3 +56,56 @@ def det_tensor(name, shape, scale=1.0, salt=0):
 
 def det_labels(name, n, num_class, salt=0):
     return torch.randint(0, num_class, (n,), generator=_gen(name, salt))
+
+
+SUB_N = 16384
+
+
+def subsample_index(name, numel, n=SUB_N):
+    """Indices (sorted) of the deterministic subsample the WIDE fixtures (G2W / G3W: the channel widths the bench kernels
+    serve) keep of a tensor with more than n elements; None = the tensor is kept whole.  A kernel bug moves whole tiles /
+    taps / channel groups, so n random entries out of 10^5 see it; the fixtures also keep the full tensor's L2 norm."""
+    if numel <= n:
+        return None
+    return torch.randperm(numel, generator=_gen('sub.' + name, 0))[:n].sort().values
+
+
+def subsample(name, t, n=SUB_N):
+    flat = t.detach().reshape(-1)
+    idx = subsample_index(name, flat.numel(), n)
+    return flat if idx is None else flat[idx]
+
+
+# ---- the WIDE fixtures (units_g2w.npz, block_g3w_*.npz): shapes and seeded inputs, shared by make_golden.py (which runs
+#      the reference on them) and by the tests (which run the oracle and the HIP product on the same tensors) ----
+WIDE_UNITS = [(64, 64, 25), (64, 128, 25), (128, 256, 25), (64, 64, 18)]     # (C_in, C_out, V); N = 2, T = 16, K = 3
+WIDE_BLOCKS = [(64, 64, 1, 25), (64, 128, 2, 25), (64, 64, 1, 18)]           # (C_in, C_out, stride, V); residual, N = 2, T = 16
+WIDE_T = 16
+
+
+def wide_unit_inputs(ci, K=3, n=2):
+    cin, cout, V = WIDE_UNITS[ci]
+    x = det_tensor('g2w.x.%d' % ci, (n, cin, WIDE_T, V))
+    r = det_tensor('g2w.r.%d' % ci, (n, cout, WIDE_T, V))
+    W = det_tensor('g2w.W.%d' % ci, (K * cout, cin, 1, 1), scale=cin ** -0.5)
+    b = det_tensor('g2w.b.%d' % ci, (K * cout,), scale=0.1)
+    return x, r, W, b
+
+
+def wide_unit_names(ci):
+    """GCN-unit variants the fixture holds for case ci (the folded-adjacency variants once, V = 18 the plain unit only)."""
+    V = WIDE_UNITS[ci][2]
+    names = ['tgcn'] + (['3a', 'inc', 'incnew'] if V == 25 else [])
+    return names + (['multi3', 'multi3fix', 'only3'] if ci == 0 else [])
+
+
+def wide_block_inputs(si, n=2):
+    cin, cout, stride, V = WIDE_BLOCKS[si]
+    base = 'w%d.' % si
+    x = det_tensor('g3w.x' + base, (n, cin, WIDE_T, V))
+    r = det_tensor('g3w.r' + base, (n, cout, WIDE_T // stride, V))
+    return x, r
+
+
+def wide_block_has(kind, si):
+    return WIDE_BLOCKS[si][3] == 25 or kind in ('st_gcn_mstcn_1x1', 'st_gcnold')

@@ -22,7 +22,8 @@ sys.path.insert(0, HERE)
 sys.path.insert(1, REF)
 sys.dont_write_bytecode = True
 
-from detinit import det_fill_, det_tensor, det_labels  # noqa: E402
+from detinit import (det_fill_, det_tensor, det_labels, subsample, WIDE_UNITS, WIDE_BLOCKS, WIDE_T, wide_unit_inputs,  # noqa: E402
+                     wide_unit_names, wide_block_inputs, wide_block_has)
 
 torch.set_num_threads(8)
 
@@ -214,6 +215,110 @@ def g3_blocks():
         save('block_g3_%s.npz' % kind, **out)
 
 
+
+# ----------------------------------------------------------------------------- G2W / G3W: the bench kernels' widths
+# Units and blocks at (C_in, C_out) = (64,64), (64,128), (128,256): the shapes the register-chained graph-conv kernels,
+# the lean temporal conv and the bottleneck stream kernels serve (G2 / G3 above have 16-40 channels and never reach them).
+# Inputs, upstream gradients and weights are regenerated from detinit by name (nothing but OUTPUTS is stored); tensors
+# with more than 16384 elements are stored as a deterministic subsample (detinit.subsample_index) plus their L2 norm.
+def _put(out, key, t, n=16384):
+    out[key] = subsample(key, t, n).to(torch.float32)
+    out[key + '#norm'] = np.asarray([float(t.detach().double().norm()), float(t.numel())])
+
+
+def g2w_units():
+    import importlib
+    out = {}
+    for ci, (cin, cout, V) in enumerate(WIDE_UNITS):
+        A, A2, A3 = _A_for(V, 'spatial_3')
+        K = A.shape[0]
+        x, r, W, b = wide_unit_inputs(ci, K)
+        imps = [0.5 + torch.rand((K, V, V), generator=torch.Generator().manual_seed(300 + ci * 3 + j)) for j in range(3)]
+        base = 'w%d.' % ci
+        for j in range(3):
+            out[base + 'imp%d' % (j + 1)] = imps[j]
+
+        def run(unit_mod, cls, call):
+            mod = importlib.import_module(unit_mod)
+            u = getattr(mod, cls)(cin, cout, K)
+            conv = u.conv if hasattr(u, 'conv') else u.branch.conv
+            with torch.no_grad():
+                conv.weight.copy_(W)
+                conv.bias.copy_(b)
+            xx = x.clone().requires_grad_(True)
+            leaves = [t.clone().requires_grad_(True) for t in imps]
+            y = call(u, xx, leaves)
+            (y * r).sum().backward()
+            return y, xx.grad, conv.weight.grad, conv.bias.grad, [t.grad for t in leaves]
+
+        units = [('tgcn', 'net.utils.tgcn', 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A * L[0])[0])]
+        if V == 25:
+            units += [('3a', 'net.utils.tgcn_multi3_fix_3A', 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A, L[0], L[1], L[2])[0]),
+                      ('inc', 'net.utils.inceptionv2_gcn', 'Inception2', lambda u, xx, L: u(xx, A * L[0], A2 * L[1], A3 * L[2])[0]),
+                      ('incnew', 'net.utils.inceptionv2_gcn_new', 'Inception2', lambda u, xx, L: u(xx, A * L[0], A2 * L[1], A3 * L[2])[0])]
+        if ci == 0:
+            units += [('multi3', 'net.utils.tgcn_multi3', 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A * L[0])[0]),
+                      ('multi3fix', 'net.utils.tgcn_multi3_fix', 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A * L[0])[0]),
+                      ('only3', 'net.utils.tgcn_only3', 'ConvTemporalGraphical', lambda u, xx, L: u(xx, A * L[0])[0])]
+        assert [u_[0] for u_ in units] == wide_unit_names(ci)
+        for tag, modname, cls, call in units:
+            y, dx, dW, db, dimp = run(modname, cls, call)
+            _put(out, base + tag + '.y', y)
+            _put(out, base + tag + '.dx', dx)
+            _put(out, base + tag + '.dW', dW, 8192)
+            _put(out, base + tag + '.db', db)
+            for j in range(3):
+                if dimp[j] is not None:
+                    _put(out, base + tag + '.dimp%d' % (j + 1), dimp[j])
+    save('units_g2w.npz', **out)
+
+
+def g3w_blocks():
+    import importlib
+    for kind, modname in BLOCK_KINDS.items():
+        mod = importlib.import_module(modname)
+        out = {}
+        for si, (cin, cout, stride, V) in enumerate(WIDE_BLOCKS):
+            if not wide_block_has(kind, si):
+                continue                                   # (V = 18 is BASELINE config 3: the bottleneck model; + the plain block)
+            A, A2, A3 = _A_for(V, 'spatial_3')
+            K = A.shape[0]
+            n, T = 2, WIDE_T
+            base = 'w%d.' % si
+            blk = mod.st_gcn(cin, cout, (9, K), stride, dropout=0, residual=True)
+            sd = blk.state_dict()
+            det_fill_(sd, salt=100 + si)
+            blk.load_state_dict(sd)
+            x, r = wide_block_inputs(si)
+            imps = [(0.5 + torch.rand((K, V, V), generator=torch.Generator().manual_seed(17 + j))).requires_grad_(True)
+                    for j in range(3)]
+            mst = (0.5 + torch.rand(3, generator=torch.Generator().manual_seed(21))).requires_grad_(True)
+            out[base + 'shape'] = np.asarray([cin, cout, stride, V, n, T])
+            out[base + 'mst'] = mst.detach().clone()
+            for j in range(3):
+                out[base + 'imp%d' % (j + 1)] = imps[j].detach().clone()
+            blk.eval()
+            with torch.no_grad():
+                _put(out, base + 'y_eval', blk(x, *block_args(kind, A, A2, A3, imps, mst))[0])
+            blk.train()
+            xx = x.clone().requires_grad_(True)
+            y = blk(xx, *block_args(kind, A, A2, A3, imps, mst))[0]
+            (y * r).sum().backward()
+            _put(out, base + 'y_train', y)
+            _put(out, base + 'dx', xx.grad)
+            for k, p in blk.named_parameters():
+                if p.grad is not None:
+                    _put(out, base + 'grad.' + k, p.grad, 8192)
+            for j in range(3):
+                if imps[j].grad is not None:
+                    _put(out, base + 'dimp%d' % (j + 1), imps[j].grad)
+            if mst.grad is not None:
+                out[base + 'dmst'] = mst.grad
+            for k, v in blk.state_dict().items():
+                if 'running' in k:
+                    out[base + 'after.' + k] = v.clone()
+        save('block_g3w_%s.npz' % kind, **out)
+
 # ----------------------------------------------------------------------------- G4/G5 models
 MODELS = {
     # tag: (module, graph_args, num_class, (N,T,V) for the eval fixture)
@@ -376,7 +481,7 @@ def g8_mstcn():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7', 'g8']
+    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7', 'g8', 'g2w', 'g3w']
     if 'g1' in what:
         g1_graph()
     if 'g2' in what:
@@ -391,3 +496,7 @@ if __name__ == '__main__':
         g7_feeder_tools()
     if 'g8' in what:
         g8_mstcn()
+    if 'g2w' in what:
+        g2w_units()
+    if 'g3w' in what:
+        g3w_blocks()

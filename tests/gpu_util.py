@@ -77,3 +77,29 @@ def gate16(name, value, gate):
     with open(os.path.join(OUT, 'err16_measured.txt'), 'a') as f:
         f.write('%-70s measured %.4g gate %.4g\n' % (name, value, gate))
     return value < gate
+
+
+def sub_close(name, got, g, key, tol, dt):
+    """`close()` against a WIDE fixture entry (tests/golden/detinit.py: a deterministic subsample of the reference tensor
+    plus its L2 norm): fp32 -- scale-aware max error on the subsample and the norm; 16-bit storage -- relative L2 error on
+    the subsample (recorded next to its gate in gpurun_out/err16_measured.txt)."""
+    from detinit import subsample
+    ref = torch.from_numpy(g[key]).double()
+    got = got.detach().double().cpu()
+    s = subsample(key, got, ref.numel())
+    assert s.shape == ref.shape, (key, tuple(s.shape), tuple(ref.shape))
+    norm, numel = g[key + '#norm']
+    assert int(numel) == got.numel(), key
+    if dt == torch.float32:
+        e = float((s - ref).abs().max() / max(1.0, float(ref.abs().max())))
+        en = abs(float(got.norm()) - float(norm)) / max(1.0, float(norm))
+        ok = max(e, en) < tol and bool(torch.isfinite(got).all())
+        if not ok:
+            diag(name, s, ref, 0.0)
+        return ok
+    if float(ref.norm()) < 1e-3 * max(1, ref.numel()) ** 0.5:
+        return bool(got.abs().max() < 0.5)                  # structurally-zero gradient (see close())
+    ok = gate16(name + ' rel-L2 ' + str(dt)[6:], l2rel(s, ref), tol) and bool(torch.isfinite(got).all())
+    if not ok:
+        diag(name, s, ref, 0.0)
+    return ok

@@ -10,8 +10,8 @@ import torch
 import torch.nn.functional as F
 
 from conftest import GOLDEN, rel_err
-from detinit import det_fill_, det_tensor, det_labels
-from gpu_util import dev, diag, close, l2rel
+from detinit import det_fill_, det_tensor, det_labels, WIDE_BLOCKS, wide_block_inputs, wide_block_has
+from gpu_util import dev, diag, close, l2rel, sub_close
 
 pytestmark = pytest.mark.gpu
 SD = json.load(open(os.path.join(GOLDEN, 'state_dict_g5.json')))
@@ -163,6 +163,72 @@ def test_blocks_golden(golden, kind, dt):
         for k, v in blk.state_dict().items():
             if 'running' in k:
                 assert close(name + '_' + k, v, g[b + 'after.' + k], tol_f, dt), k
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('kind', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn'])
+def test_blocks_wide_golden(golden, kind, dt):
+    """every block variant at the trunk's widths -- 64 -> 64 (stride 1), 64 -> 128 (stride 2; bottleneck widths
+    8 and 11), V = 25 and (config 3's bottleneck block, the plain block) V = 18 -- against REFERENCE-generated outputs,
+    input / parameter / importance gradients and running statistics (block_g3w_*.npz from net/st_gcnold.py:197-203,
+    st_gcn_msgcn.py:231-237, st_gcn_mstcn.py:235-249, st_gcn_mstcn_1x1.py:250-266, st_gcn_multi3_fix_3A_mstcn.py:206-220).
+    These shapes take the register-chained graph-conv kernels, the lean temporal conv and (16-bit `1x1`) the bottleneck
+    stream kernels.  800 positions x 64-128 channels average the ReLU-mask flips out: 16-bit gradient gates of 0.1 / 0.06
+    for every variant (the 16-channel fixtures of test_blocks_golden need 0.2 / 0.4)."""
+    from istgcn_amd import ops, functional
+    from istgcn_amd.net.utils.graph import Graph
+    g = golden('block_g3w_%s.npz' % kind)
+    mod = importlib.import_module('istgcn_amd.net.' + kind)
+    d = dev()
+    tol_f, tol_g = {torch.float32: (3e-5, 2e-4), torch.bfloat16: (1.25e-2, 0.1), torch.float16: (1.7e-3, 0.06)}[dt]
+    seen = 0
+    for si, (cin, cout, stride, V) in enumerate(WIDE_BLOCKS):
+        if not wide_block_has(kind, si):
+            continue
+        seen += 1
+        b = 'w%d.' % si
+        gr = Graph('ntu-rgb+d' if V == 25 else 'openpose', 'spatial_3')
+        A, A2, A3 = (torch.tensor(a, dtype=torch.float32, device=d) for a in (gr.A, gr.A2, gr.A3))
+        K = A.shape[0]
+        x, r = wide_block_inputs(si)
+        blk = mod.st_gcn(cin, cout, (9, K), stride, dropout=0, residual=True)
+        blk.load_state_dict(det_fill_(blk.state_dict(), salt=100 + si), strict=True)
+        blk.to(d)
+        if kind == 'st_gcn_mstcn_1x1' and dt != torch.float32:
+            w = int(cout ** 0.5)
+            assert ops.bneck_ok(V, cout, w, functional._pad_width(w, dt), dt), 'the bottleneck stream kernels serve this block'
+        imps = [torch.from_numpy(g[b + 'imp%d' % j]).to(d).requires_grad_(True) for j in (1, 2, 3)]
+        mst = torch.from_numpy(g[b + 'mst']).to(d).requires_grad_(True)
+        xin = x.to(d, dt)
+        name = 'blkw_%s_w%d_%s' % (kind, si, str(dt)[6:])
+        blk.eval()
+        with torch.no_grad():
+            y = blk(xin, *_block_args(kind, A, A2, A3, imps, mst))[0]
+        assert sub_close(name + '_yeval', y.float(), g, b + 'y_eval', tol_f, dt)
+        blk.train()
+        xx = xin.clone().requires_grad_(True)
+        y = blk(xx, *_block_args(kind, A, A2, A3, imps, mst))[0]
+        assert sub_close(name + '_ytrain', y.float(), g, b + 'y_train', tol_f, dt)
+        (y.float() * r.to(d)).sum().backward()
+        assert sub_close(name + '_dx', xx.grad.float(), g, b + 'dx', tol_g, dt)
+        n_grad = 0
+        for k, p in blk.named_parameters():
+            if b + 'grad.' + k in g.files:
+                assert p.grad is not None, k
+                assert sub_close(name + '_grad_' + k, p.grad, g, b + 'grad.' + k, tol_g, dt), k
+                n_grad += 1
+            else:
+                assert p.grad is None, k
+        assert n_grad > 0
+        for j in (1, 2, 3):
+            if b + 'dimp%d' % j in g.files:
+                assert sub_close(name + '_dimp%d' % j, imps[j - 1].grad, g, b + 'dimp%d' % j, tol_g, dt)
+        if b + 'dmst' in g.files:
+            assert close(name + '_dmst', mst.grad, g[b + 'dmst'], tol_g, dt)
+        for k, v in blk.state_dict().items():
+            if 'running' in k:
+                assert close(name + '_' + k, v, g[b + 'after.' + k], tol_f, dt), k
+    assert seen >= 2
 
 
 # ------------------------------------------------------------------------------------------------ models (G4/G5)
@@ -413,25 +479,45 @@ def test_flat_sgd_kernel_matches_torch_sgd():
 
 
 def test_flat_sgd_skips_non_finite_gradients_and_resumes_exactly():
-    """(a) an inf / NaN gradient element (an overflowed float16 activation gradient) leaves its parameter and
-    momentum untouched and raises the flag check_overflow() polls, which backs the loss scale off; (b) load_state_dict on
-    a fresh optimizer puts the momentum in place before the first update: a resumed run continues bit for bit."""
+    """(a) with a loss scale in use an inf / NaN anywhere in the gradients skips the WHOLE update
+    (GradScaler's rule: no partial step with an overflowed scale) and raises the flag check_overflow() polls, which backs
+    the loss scale off; the step after it is applied normally; with skip_nonfinite=False only the non-finite elements
+    are left out; (b) load_state_dict on a fresh optimizer puts the momentum in place before the first update: a resumed
+    run continues bit for bit."""
     from istgcn_amd import harness
     d = dev()
     g = torch.Generator().manual_seed(3)
     init = [torch.randn(33, generator=g), torch.randn(4, 5, generator=g)]
     grads = [[torch.randn(t.shape, generator=g) for t in init] for _ in range(4)]
-    pa = [torch.nn.Parameter(t.clone().to(d)) for t in init]
-    oa = harness.FlatSGD(pa, lr=0.1, loss_scale=1024.0)
-    for p, gr in zip(pa, grads[0]):
-        p.grad = (gr * 1024.0).to(d)
-    pa[0].grad[5] = float('inf')
-    pa[1].grad[2, 3] = float('nan')
-    oa.step()
-    assert torch.isfinite(oa.P).all() and torch.isfinite(oa.M).all()
-    assert float(pa[0][5]) == float(init[0][5]) and float(pa[1][2, 3]) == float(init[1][2, 3])     # skipped elements
-    assert float(pa[0][6]) != float(init[0][6])                                                       # the rest was applied
+
+    def poisoned(skip):
+        ps = [torch.nn.Parameter(t.clone().to(d)) for t in init]
+        o = harness.FlatSGD(ps, lr=0.1, loss_scale=1024.0, skip_nonfinite=skip, poll_every=0)
+        for p, gr in zip(ps, grads[0]):
+            p.grad = (gr * 1024.0).to(d)
+        o.step()                                           # a clean step fixes the layout (and gives the momentum a value)
+        before = [p.detach().clone() for p in ps]
+        mom = o.M.clone()
+        for p, gr in zip(ps, grads[1]):
+            p.grad = (gr * 1024.0).to(d)
+        ps[0].grad[5] = float('inf')
+        ps[1].grad[2, 3] = float('nan')
+        o.step()
+        return ps, o, before, mom
+
+    pa, oa, before, mom = poisoned(None)                   # default with a loss scale: skip the whole step
+    assert oa.skip_nonfinite
+    assert all(torch.equal(p.detach(), b) for p, b in zip(pa, before)) and torch.equal(oa.M, mom)
     assert oa.check_overflow() and oa.loss_scale == 512.0 and not oa.check_overflow()
+    for p, gr in zip(pa, grads[2]):                        # the next (finite) step is applied
+        p.grad = (gr * 512.0).to(d)
+    oa.step()
+    assert all(not torch.equal(p.detach(), b) for p, b in zip(pa, before)) and not oa.check_overflow()
+    pe, oe, before, mom = poisoned(False)                  # element-wise: only the non-finite elements are left out
+    assert torch.isfinite(oe.P).all() and torch.isfinite(oe.M).all()
+    assert float(pe[0][5]) == float(before[0][5]) and float(pe[1][2, 3]) == float(before[1][2, 3])
+    assert float(pe[0][6]) != float(before[0][6])
+    assert oe.check_overflow() and oe.loss_scale == 512.0 and not oe.check_overflow()
     # exact resume: two steps, save, two more  ==  two steps, save | fresh optimizer + load, two more
     def run(resume):
         ps = [torch.nn.Parameter(t.clone().to(d)) for t in init]

@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from conftest import rel_err
-from gpu_util import dev, to_ntvc, to_nctv, diag, OUT
+from gpu_util import dev, to_ntvc, to_nctv, diag, OUT, sub_close
+from detinit import WIDE_UNITS, wide_unit_inputs, wide_unit_names
 from oracle import stgcn_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -140,6 +141,72 @@ def test_gcn_fwd_random_vs_oracle(ops, shape, dt):
     s = stats.sum(0).cpu()
     assert rel_err(s[0], yf.sum((0, 1, 2))) < 1e-5
     assert rel_err(s[1], (yf * yf).sum((0, 1, 2))) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ G2W: the bench widths
+def _wide_graph(V):
+    from istgcn_amd.net.utils.graph import Graph
+    g = Graph('ntu-rgb+d' if V == 25 else 'openpose', 'spatial_3')
+    return tuple(torch.tensor(a, dtype=torch.float32) for a in (g.A, g.A2, g.A3))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('ci', range(len(WIDE_UNITS)))
+def test_gcn_unit_wide_golden(ops, golden, ci, dt):
+    """the register-chained graph-conv kernels (csrc/gcn_rc*.hip: 64 / 128 / 256 channels) against
+    REFERENCE-generated outputs and gradients (units_g2w.npz: net/utils/tgcn.py:76-89, tgcn_multi3_fix_3A.py:76-92,
+    inceptionv2_gcn.py:64-89 run at (64,64), (64,128), (128,256) channels), all three storage types: y, dx, dW, db and the
+    importance gradients, with the check that the register-chained entries were the ones dispatched."""
+    import ctypes
+    from istgcn_amd import _lib
+    g = golden('units_g2w.npz')
+    cin, cout, V = WIDE_UNITS[ci]
+    A, A2, A3 = _wide_graph(V)
+    K = A.shape[0]
+    x, r, W, bias = wide_unit_inputs(ci, K)
+    b = 'w%d.' % ci
+    lib = _lib.load()
+    # the dispatchers' own predicates (gcn_fwd.hip / gcn_bwd.hip / tconv_wgrad.hip): 16-bit -> gcn_rc*, fp32 -> gcn_rc_f32 for V >= 20
+    if dt != torch.float32 or V >= 20:
+        assert lib.istgcn_gcn_rc_layout(cin, cout, K, ops._DT[dt]) == 1
+        assert lib.istgcn_gcn_wgrad_rc_ok(V, cin, cout, K, ops._DT[dt]) == 1 or dt == torch.float32
+    d = dev()
+    tol_y = TOL[dt]
+    tol_g = 3e-5 if dt == torch.float32 else 1e-2
+    for unit in wide_unit_names(ci):
+        imps = [torch.from_numpy(g[b + 'imp%d' % j]).clone().requires_grad_(True) for j in (1, 2, 3)]
+        if unit == 'tgcn':
+            Aeff = A * imps[0]
+        elif unit == '3a':
+            Aeff = A * imps[0] + A ** 2 * imps[1] + A ** 3 * imps[2]
+        elif unit in ('inc', 'incnew'):
+            Aeff = A * imps[0] + A2 * imps[1] + A3 * imps[2]
+        else:
+            Ai = A * imps[0]
+            Aeff = {'multi3': Ai + Ai ** 2 + Ai ** 3, 'multi3fix': (Ai + Ai ** 2 + Ai ** 3) / 3, 'only3': Ai ** 3}[unit]
+        Ad = Aeff.detach().to(d).contiguous()
+        cap = int((Aeff != 0).sum())
+        Wk = W.view(K, cout, cin)
+        wr = Wk.permute(1, 0, 2).contiguous().to(d)
+        bterm = torch.einsum('kc,kw->wc', bias.view(K, cout), Aeff.detach().sum(1)).contiguous().to(d)
+        xg, dyg = to_ntvc(x).to(d, dt), to_ntvc(r).to(d, dt)
+        name = 'gcnw_%s_w%d_%s' % (unit, ci, str(dt)[6:])
+        k = b + unit
+        y = ops.gcn_forward(xg, Ad, ops.pack_gcn_weight(wr, dt), cout, bterm=bterm, nnz_cap=cap)
+        assert sub_close(name + '_y', to_nctv(y.float()), g, k + '.y', tol_y if dt == torch.float32 else 1e-2, dt), unit
+        dW, S = ops.gcn_wgrad(dyg, xg, Ad, nnz_cap=cap)
+        dx, dA = ops.gcn_bwd_data(dyg, Ad, Wk.contiguous().to(d), x=xg, nnz_cap=cap)
+        torch.cuda.synchronize()
+        assert sub_close(name + '_dx', to_nctv(dx.float()), g, k + '.dx', tol_y if dt == torch.float32 else 1e-2, dt), unit
+        dW, dA, S = dW.cpu(), dA.cpu(), S.cpu()
+        assert sub_close(name + '_dW', dW.view(K * cout, cin, 1, 1), g, k + '.dW', tol_g, dt), unit
+        db = torch.einsum('kw,wc->kc', Aeff.detach().sum(1), S).reshape(-1)
+        assert sub_close(name + '_db', db, g, k + '.db', tol_g, dt), unit
+        dA_full = dA + torch.einsum('kc,wc->kw', bias.view(K, cout), S)[:, None, :] * (Aeff.detach() != 0)
+        Aeff.backward(dA_full)
+        for j in (1, 2, 3):
+            if k + '.dimp%d' % j in g.files:
+                assert sub_close(name + '_dimp%d' % j, imps[j - 1].grad, g, k + '.dimp%d' % j, tol_g, dt), (unit, j)
 
 
 def test_gcn_strided_and_accumulate(ops):

@@ -39,6 +39,21 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), n
 
 
+def test_shipped_library_has_no_experiment_hooks_and_knows_its_sources(lib):
+    """ablation masks (`*_ABL`: results wrong), debug buffers (`*_DBG`: hipMalloc inside an entry point) and
+    the experiment-only variant switches exist behind -DISTGCN_EXPERIMENT only; the default library reads dispatch
+    overrides (documented in INTEGRATION.md), once.  #7: the library carries the hash of the sources it was built from."""
+    import re
+    from istgcn_amd import _lib
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    names = set(m.group(0).decode() for m in re.finditer(rb'ISTGCN_[A-Z0-9_]{3,}', blob))
+    bad = [n for n in names if n.endswith('_ABL') or '_DBG' in n or n in ('ISTGCN_RC_NCT', 'ISTGCN_GWG_OT', 'ISTGCN_RC_SPLIT', 'ISTGCN_DEBUG')]
+    assert not bad, bad
+    assert names <= {'ISTGCN_GCN_RC', 'ISTGCN_GCN_V1', 'ISTGCN_GCNBWD_WS', 'ISTGCN_WGRAD_WS', 'ISTGCN_TWG_RC', 'ISTGCN_TCONV_SK',
+                     'ISTGCN_TCONV_V1', 'ISTGCN_TCONV_LEAN'}, names
+    assert _lib.build_id() == _lib.csrc_hash() and len(_lib.csrc_hash()) == 16
+
+
 def test_geometry_and_packing_agree(lib):
     from istgcn_amd import ops
     for dt, epl in ((torch.float32, 4), (torch.bfloat16, 8)):

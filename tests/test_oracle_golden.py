@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from conftest import GOLDEN, rel_err
-from detinit import det_fill_, det_tensor, det_labels
+from detinit import (det_fill_, det_tensor, det_labels, subsample, WIDE_UNITS, WIDE_BLOCKS, wide_unit_inputs, wide_unit_names,
+                     wide_block_inputs, wide_block_has)
 from oracle.graph_ref import GraphRef
 from oracle import stgcn_ref as R
 
@@ -144,6 +145,108 @@ def test_blocks(kind, golden):
         for k, v in blk.state_dict().items():
             if 'running' in k:
                 assert rel_err(v, g[b + 'after.' + k]) < 1e-5, k
+
+
+# ---------------------------------------------------------------------------- G2W / G3W: the bench kernels' widths
+def wide_graph(V):
+    g = GraphRef('ntu-rgb+d' if V == 25 else 'openpose', 'spatial_3')
+    return tuple(torch.tensor(a, dtype=torch.float32) for a in (g.A, g.A2, g.A3))
+
+
+def sub_err(key, got, g):
+    """max |got - ref| / max(1, max|ref|) on the fixture's deterministic subsample of `got`, and the relative error of the
+    full tensor's L2 norm (the fixture stores both; tests/golden/detinit.py)."""
+    ref = torch.from_numpy(g[key]).double()
+    got = got.detach().double().cpu()
+    s = subsample(key, got, ref.numel())
+    assert s.shape == ref.shape, (key, tuple(s.shape), tuple(ref.shape))
+    norm, numel = g[key + '#norm']
+    assert int(numel) == got.numel(), key
+    e = float((s - ref).abs().max() / max(1.0, float(ref.abs().max())))
+    en = abs(float(got.norm()) - float(norm)) / max(1.0, float(norm))
+    return max(e, en)
+
+
+@pytest.mark.parametrize('ci', range(len(WIDE_UNITS)))
+def test_gcn_units_wide(ci, golden):
+    """the seven GCN-unit variants at (64,64), (64,128), (128,256) channels (V = 25) and the plain unit at V = 18"""
+    g = golden('units_g2w.npz')
+    cin, cout, V = WIDE_UNITS[ci]
+    A, A2, A3 = wide_graph(V)
+    K = A.shape[0]
+    x, r, W, bias = wide_unit_inputs(ci, K)
+    b = 'w%d.' % ci
+    for unit in wide_unit_names(ci):
+        imps = [torch.from_numpy(g[b + 'imp%d' % j]).clone().requires_grad_(True) for j in (1, 2, 3)]
+        kind = {'tgcn': 'plain', '3a': '3a', 'inc': 'incep', 'incnew': 'incep'}.get(unit, 'plain')
+        u = R.RefGCN(kind, cin, cout, K)
+        conv = u.branch.conv if kind == 'incep' else u.conv
+        with torch.no_grad():
+            conv.weight.copy_(W)
+            conv.bias.copy_(bias)
+        xx = x.clone().requires_grad_(True)
+        if unit == 'tgcn':
+            adj = (A * imps[0],)
+        elif unit == '3a':
+            adj = (A, imps[0], imps[1], imps[2])
+        elif unit in ('inc', 'incnew'):
+            adj = (A * imps[0], A2 * imps[1], A3 * imps[2])
+        else:
+            Ai = A * imps[0]
+            adj = ({'multi3': Ai + Ai ** 2 + Ai ** 3, 'multi3fix': (Ai + Ai ** 2 + Ai ** 3) / 3, 'only3': Ai ** 3}[unit],)
+        y = u(xx, adj)
+        (y * r).sum().backward()
+        k = b + unit
+        assert sub_err(k + '.y', y, g) < 1e-5 and sub_err(k + '.dx', xx.grad, g) < 1e-5, unit
+        assert sub_err(k + '.dW', conv.weight.grad, g) < 1e-5 and sub_err(k + '.db', conv.bias.grad, g) < 1e-5, unit
+        for j in (1, 2, 3):
+            if k + '.dimp%d' % j in g.files:
+                assert sub_err(k + '.dimp%d' % j, imps[j - 1].grad, g) < 1e-5, (unit, j)
+
+
+@pytest.mark.parametrize('kind', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn'])
+def test_blocks_wide(kind, golden):
+    """every st_gcn block variant at 64 -> 64 (stride 1) and 64 -> 128 (stride 2) channels: the widths of the trunk"""
+    g = golden('block_g3w_%s.npz' % kind)
+    seen = 0
+    for si, (cin, cout, stride, V) in enumerate(WIDE_BLOCKS):
+        if not wide_block_has(kind, si):
+            continue
+        seen += 1
+        b = 'w%d.' % si
+        A, A2, A3 = wide_graph(V)
+        K = A.shape[0]
+        x, r = wide_block_inputs(si)
+        blk = R.RefBlock(kind, cin, cout, K, stride, dropout=0, residual=True)
+        blk.load_state_dict(det_fill_(blk.state_dict(), salt=100 + si))
+        imps = [torch.from_numpy(g[b + 'imp%d' % j]).clone().requires_grad_(True) for j in (1, 2, 3)]
+        mst = torch.from_numpy(g[b + 'mst']).clone().requires_grad_(True)
+        blk.eval()
+        with torch.no_grad():
+            assert sub_err(b + 'y_eval', blk(x, _block_adj(kind, A, A2, A3, imps), mst), g) < 1e-5
+        blk.train()
+        xx = x.clone().requires_grad_(True)
+        y = blk(xx, _block_adj(kind, A, A2, A3, imps), mst)
+        (y * r).sum().backward()
+        assert sub_err(b + 'y_train', y, g) < 1e-5
+        assert sub_err(b + 'dx', xx.grad, g) < 1e-4
+        n_grad = 0
+        for k, p in blk.named_parameters():
+            if b + 'grad.' + k in g.files:
+                assert sub_err(b + 'grad.' + k, p.grad, g) < 1e-4, k
+                n_grad += 1
+            else:
+                assert p.grad is None, k
+        assert n_grad > 0
+        for j in (1, 2, 3):
+            if b + 'dimp%d' % j in g.files:
+                assert sub_err(b + 'dimp%d' % j, imps[j - 1].grad, g) < 1e-4
+        if b + 'dmst' in g.files:
+            assert rel_err(mst.grad, g[b + 'dmst']) < 1e-4
+        for k, v in blk.state_dict().items():
+            if 'running' in k:
+                assert rel_err(v, g[b + 'after.' + k]) < 1e-5, k
+    assert seen >= 2
 
 
 @pytest.mark.parametrize('tag', sorted(MODEL_CFG))

@@ -17,6 +17,8 @@ def fam(name):
         return 'bneck_wgrad kernels'
     if 'bneck_in_kernel' in n or 'bneck_out_kernel' in n:
         return 'bneck_in/out kernels'
+    if 'tconv_lean_kernel' in n or 'tconv_kernel' in n:      # (one C-ABI entry point, istgcn_tconv, dispatches to both)
+        return 'tconv kernels'
     for key in ('gcn_rc_fwd_kernel', 'gcn_rc_bwd_kernel', 'gcn_rc_wgrad_kernel', 'twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
                 'block_out_bwd_kernel', 'affine2_kernel', 'bn_finalize_kernel', 'bn_bwd_coef_kernel', 'fold_fwd_kernel', 'fold_bwd_kernel',
                 'sgd_step_kernel', 'pool_fwd_kernel', 'pool_bwd_kernel', 'tcn_fold_fwd_kernel', 'tcn_fold_bwd_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
@@ -42,7 +44,13 @@ if stats:
 fetch, nf = counters('fetch')
 write, nw = counters('write')
 sq, ns = counters('sq')
-res = {'command': 'rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} -- python3 bench.py --steps 4 --warmup 2 '
+sys.path.insert(0, ROOT)
+import importlib.util
+_spec = importlib.util.spec_from_file_location('istgcn_lib', os.path.join(ROOT, 'ist-gcn_amd', '_lib.py'))
+_lib = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_lib)
+res = {'csrc_hash': _lib.csrc_hash(),       # the kernel sources these counters were collected on (== istgcn_build_id() of the library)
+       'command': 'rocprofv3 {--kernel-trace --stats | --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*} -- python3 bench.py --steps 4 --warmup 2 '
                   '--no-cpu-baseline %s (four separate passes)' % BENCH_ARGS,
        'units': 'FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them; hbm_bytes = 2*FETCH*1024 + WRITE*1024 per launch',
        'kernels': {}}
