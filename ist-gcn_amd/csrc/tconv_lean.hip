@@ -126,8 +126,6 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
   constexpr int MTW = MT / WM, NTW = 2 * WM;
   typedef typename E::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned short* row_f = reinterpret_cast<unsigned short*>(smem);          // [TR]
-  unsigned short* row_v = row_f + TR;                                        // [TR]
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
   float* bias_l = stat + 2 * MT * 32;                                        // [MT*32]
   float* pre_l = bias_l + MT * 32;                                           // [2][Cin]
@@ -149,11 +147,6 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
   const int mt0 = blockIdx.y * MT;
   const int cbase_blk = mt0 * 32;
 
-  for (int r = tid; r < TR; r += NTH) {
-    int f = r / V;
-    row_f[r] = (unsigned short)f;
-    row_v[r] = (unsigned short)(r - f * V);
-  }
   for (int c = tid; c < 2 * MT * 32; c += NTH) stat[c] = 0.f;
   for (int c = tid; c < MT * 32; c += NTH) bias_l[c] = P.bias ? P.bias[cbase_blk + c] : 0.f;
   for (int c = tid; c < 2 * P.Cin; c += NTH) {
@@ -240,60 +233,97 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
     };
 #pragma unroll
     for (int d = 0; d < DA - 1; ++d) load_as(a[d]);         // in flight while the first chunk is being staged
-    lds_barrier();                                          // item 0 staged (the memory waves' prologue)
-    int ch = 0, k = 0;
-    TSTAMP(5)
-    for (int it = 0; it < total_items; ++it) {
-      if (ch == 0) {
-        const TileL t = tile_of(k);
+    // per-lane LDS element offset of each output row's fragment at tap offset 0 (row p of the tile = frame p / V, joint
+    // p % V; input frame = in_mul * frame): the same for every tile.  Rows past a short last tile are NOT clamped: they read
+    // rows of the staged buffer that nobody wrote for this tile (inside its UL * 64 rows) and produce garbage in their own
+    // accumulator columns only, which the epilogue masks before the sums and whose stores fall outside the tile's descriptor
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) {
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int p = wr * (32 * NTW) + tt * 32 + (lane & 31);
+      const int f = p / V;
+      brow[tt] = ((P.in_mul * f) * V + (p - f * V)) * US + hoff;
+    }
+    auto acc_init = [&]() __attribute__((always_inline)) {   // accumulators = conv bias (rows of the D tile = output channels)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + (wm * MTW + m) * 32 + 8 * q4 + 4 * (lane >> 5));
+      for (int m = 0; m < MTW; ++m) {
 #pragma unroll
-            for (int tt = 0; tt < NTW; ++tt)
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + (wm * MTW + m) * 32 + 8 * q4 + 4 * (lane >> 5));
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj) acc[m][tt][4 * q4 + jj] = b4[jj];
-          }
-        }
+          for (int tt = 0; tt < NTW; ++tt)
 #pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) {
-          const int p = wr * (32 * NTW) + tt * 32 + (lane & 31);
-          brow[tt] = (p < t.rows ? (P.in_mul * row_f[p]) * V + row_v[p] : 0) * US + hoff;
+            for (int jj = 0; jj < 4; ++jj) acc[m][tt][4 * q4 + jj] = b4[jj];
         }
       }
-      soffc = roff0 * US;
-#pragma unroll
-      for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
-      TSTAMP(0)                                             // tile start + activation-ring prologue
-#define TL_STEP(D)                                                                                       \
+    };
+    // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations PD steps ahead);
+    // sched_group_barrier interleaves one MFMA with the loads in its shadow.  LB = false: no activation prefetch (the last
+    // PD steps of an item: their targets lie past the item).  MM = false: loads only -- the MFMAs of an item's LAST step
+    // are issued after the item barrier, behind the first fragment reads of the NEXT item (TL_MMAS): the operands of that
+    // step are in registers (weight ring slot DA-1, activation ring slot DB-1, which the next item's prologue does not
+    // touch), so the matrix pipe works through them while the new item's first fragments are on their way from LDS --
+    // that latency used to be exposed once per item (~10 % of a 64-channel item).
+#define TL_MMAS(D)                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                  \
+          _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) { TL_MMA(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); TL_PAD }
+#define TL_STEP(D, LB, MM)                                                                               \
       {                                                                                                  \
         load_as(a[((D) + DA - 1) % DA]);                                                                 \
-        load_bs(b[((D) + PD) % DB], soffc + tsk[((D) + PD) >> 1] + (((D) + PD) & 1) * KGS);              \
-        _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                  \
-          _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) { TL_MMA(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); TL_PAD } \
-        _Pragma("unroll") for (int i_ = 0; i_ < MTW * NTW; ++i_) {                                       \
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                             \
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                             \
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                             \
-          __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                             \
+        if (LB) load_bs(b[((D) + PD) % DB], soffc + tsk[((D) + PD) >> 1] + (((D) + PD) & 1) * KGS);      \
+        if (MM) {                                                                                        \
+          TL_MMAS(D)                                                                                     \
+          _Pragma("unroll") for (int i_ = 0; i_ < MTW * NTW; ++i_) {                                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                           \
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                           \
+          }                                                                                              \
         }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
       }
-      const int nchunk = nit / DA;
-      for (int c = 0; c < nchunk; ++c) {
-        TL_STEP(0) TL_STEP(1) TL_STEP(2) TL_STEP(3) TL_STEP(4) TL_STEP(5)
+    static_assert(PD <= 2 && (DA - 1) % DB == DB - 1, "the deferred step's activation slot is the one the prologue leaves alone");
+    const int nchunk = nit / DA;
+    lds_barrier();                                          // item 0 staged (the memory waves' prologue)
+    int ch = 0, k = 0;
+    if (total_items > 0) {
+      acc_init();
+      soffc = roff0 * US;
+#pragma unroll
+      for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
+    }
+    TSTAMP(5)
+    for (int it = 0; it < total_items; ++it) {
+      for (int c = 0; c < nchunk - 1; ++c) {
+        TL_STEP(0, true, true) TL_STEP(1, true, true) TL_STEP(2, true, true) TL_STEP(3, true, true) TL_STEP(4, true, true) TL_STEP(5, true, true)
         soffc += tsk[3];
       }
-#undef TL_STEP
-      TSTAMP(1)                                             // the steps
+      TL_STEP(0, true, true) TL_STEP(1, true, true) TL_STEP(2, true, true) TL_STEP(3, true, true)
+      TL_STEP(4, PD < 2, true) TL_STEP(5, false, false)
+      TSTAMP(1)                                             // the steps (all but the last one's MFMAs)
       us = reinterpret_cast<const T*>(smem + (((it + 1) & 1) ? P.off_u1 : P.off_u0));
       lds_barrier();                                        // item done: this half of the tile buffer may be refilled
       TSTAMP(2)                                             // wait at the item barrier
-      if (++ch == nch) {
+      const bool tile_end = ++ch == nch;
+      const bool more = it + 1 < total_items;
+      if (tile_end) {
         ch = 0;
         ++k;
+      }
+      // (the row bases are loop invariants now; made opaque per item, or the compiler materialises every `base + tap offset`
+      //  sum of the item in its own register -- ~20 of them -- and spills them around the loop: reloads with vmcnt(0)
+      //  waits at every item start, i.e. a drained weight ring)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) asm volatile("" : "+v"(brow[tt]));
+      if (more) {                                           // the next item's first fragment reads ...
+        soffc = roff0 * US;
+#pragma unroll
+        for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      TL_MMAS(5)                                            // ... and, in their shadow, the MFMAs of this item's last step
+      __builtin_amdgcn_sched_barrier(0);
+      TSTAMP(0)                                             // item start
+      if (tile_end) {
         // ---- tile end: accumulators -> LDS output image (row-major, channels innermost) ----
 #pragma unroll
         for (int tt = 0; tt < NTW; ++tt) {
@@ -310,9 +340,12 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
         }
         TSTAMP(3)                                           // accumulators -> image
         lds_barrier();                                      // image complete
+        acc_init();
         TSTAMP(4)
       }
     }
+#undef TL_STEP
+#undef TL_MMAS
 #ifdef ISTGCN_TCONV_STAMP
     if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i]; P.dbg[6] = (unsigned long long)total_items; }
 #endif
@@ -616,7 +649,7 @@ int launch_lean(const TlParams& P, int grid_cap, int gy, size_t lds, hipStream_t
 struct LeanLds { int off_stat, off_u0, off_u1, off_o, lds; };
 static LeanLds lean_lds(const tconv_geo::TconvGeom& G, int Cin) {
   LeanLds L;
-  size_t off = (size_t)2 * 256 * sizeof(unsigned short);
+  size_t off = 0;
   L.off_stat = (int)off;
   off += (size_t)(3 * G.MT * 32 + 2 * Cin) * 4;
   off = (off + 15) & ~(size_t)15;
