@@ -253,10 +253,15 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_ONLY = None
     stack.close()
+    per_rank_ms = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        # every rank's own clock around the same K steps (the line's time is their MAX), gathered through the job's
+        # backend: the spread says whether a rank lags (a slow GPU, a rank that shares its card in a rehearsal)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in allt]
+        elapsed = max(float(t.item()) for t in allt)
     loss_val = float(loss)
 
     # ---- per-family totals from the HIP events of the timed region ----
@@ -324,6 +329,9 @@ def main():
                        'launch': 'fwd+bwd replayed from one hipGraph; all-reduce + SGD eager' if use_graph else 'eager',
                        'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
                        'exchange': None if world == 1 else {
+                           'backend': dist.get_backend(), 'world_size_reported': dist.get_world_size(),
+                           'devices_visible_to_rank0': ndev, 'per_rank_ms_per_step': per_rank_ms,
+                           'overlap': bool(getattr(opt, 'overlap', False)),       # ISTGCN_OVERLAP=0: one bucket, reduced in step()
                            'bucket_bytes': opt.bucket_bytes, 'early_bucket_bytes': 4 * getattr(opt, '_early_end', 0),
                            'early_all_reduces_launched_from_backward': getattr(opt, 'early_launches', 0)},
                        'storage': ('%s activations, fp32 accumulate/params, fp64 BN sums%s' % (

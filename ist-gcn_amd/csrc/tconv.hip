@@ -828,6 +828,11 @@ extern "C" int istgcn_tconv_geometry(int V, int Cin, int Cout, int ntaps, const 
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (!tap_off || ntaps < 1 || ntaps > MAX_TAPS || V < 1 || V > 128 || Cin < 1 || Cout < 1 || in_mul < 1) return ISTGCN_EINVAL;
   if (tconv_use_v1(Cin, Cout)) return istgcn_tconv_v1_geometry(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, CC, nch, MTtot, EPL);
+  tconv_geo::LeanGeom L;
+  if (tconv_geo::tconv_lean_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &L)) {     // the lean kernel's packing (tconv_lean.hip)
+    *CC = 32; *nch = L.nch; *MTtot = L.MTtot; *EPL = 8;
+    return ISTGCN_OK;
+  }
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
@@ -862,6 +867,16 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
   P.in_mul = in_mul; P.out_mul = out_mul; P.out_off = out_off; P.pre_relu = pre_relu; P.mode = mode;
   P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
   for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
+  {
+    tconv_geo::LeanGeom L;
+    if (tconv_geo::tconv_lean_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &L) && (ntaps > 5 || tconv_lean_serves(mode, ntaps, L.UL))) {
+      // (9 / 15 taps: the weights are packed for the lean kernel, every mode goes there; 4 / 5 taps: the data gradient)
+      BnTail tail{};
+      if (stats) istgcn_bn_tail_take(stats, &tail);
+      return tconv_lean_launch(in, Wp, bias, pre, pre_relu, aux, maux, out, stats, stats_rep, mode, NM, Tin, Tout, Mlog, V, Cin, Cout,
+                               ntaps, tap_off, in_mul, out_mul, out_off, dtype, grid_cap, L, tail, (hipStream_t)stream);
+    }
+  }
   TconvGeom G;
   int rc = tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G);
   if (rc) return rc;
@@ -880,9 +895,6 @@ extern "C" int istgcn_tconv(const void* in, const void* Wp, const float* bias, c
     }
   }
   if (stats) istgcn_bn_tail_take(stats, &P.tail);
-  if (tconv_lean_ok(G, mode, Tin, V, Cin, Cout, ntaps, out_mul, dtype))
-    return tconv_lean_launch(in, Wp, bias, pre, pre_relu, aux, maux, out, stats, stats_rep, mode, NM, Tin, Tout, Mlog, V, Cin, Cout,
-                             ntaps, tap_off, in_mul, out_off, dtype, grid_cap, G, P.tail, (hipStream_t)stream);
   if (dtype == 0) return launch_T<float>(P, G, grid_cap, (hipStream_t)stream);
   if (dtype == 2) return launch_T<_Float16>(P, G, grid_cap, (hipStream_t)stream);
   return launch_T<__bf16>(P, G, grid_cap, (hipStream_t)stream);

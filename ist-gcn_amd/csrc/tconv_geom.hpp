@@ -2,6 +2,7 @@
 // geometry query the host packs weights by share ONE decision, so both kernels read the same packed weights.
 #pragma once
 #include "common.hpp"
+#include <cstdlib>
 
 namespace tconv_geo {
 
@@ -59,12 +60,57 @@ inline int tconv_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, i
 }
 
 
+// ---- the lean kernel (tconv_lean.hip): ONE decision shared by the geometry query (= the weight packer) and the launcher.
+// Staged rows of 64 bytes (32-channel chunks, swizzled), UL * 64 rows per buffer, 256-row tiles, MT * 32 output channels
+// per workgroup.  A shape is "lean" when every mode a caller can ask for with this packing has a lean instantiation
+// (9 / 15 taps: forward, data gradient, inference) or when tconv.hip packs the same way and serves the rest (4 / 5 taps:
+// the phases of a stride-2 data gradient go to the lean kernel, anything else with those taps to tconv.hip).
+struct LeanGeom { int UL, MT, gy, MTtot, nch, F, Fin, min_off, off_stat, off_u0, off_u1, off_o, lds; };
+
+inline bool tconv_lean_geom(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, LeanGeom* L) {
+  static const bool off = [] { const char* e = getenv("ISTGCN_TCONV_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
+  if (off || dtype == 0 || V < 2 || V > 128 || Cin % 32 != 0 || Cout % 64 != 0) return false;
+  if (ntaps != 4 && ntaps != 5 && ntaps != 9 && ntaps != 15) return false;
+  const int d = tap_off[1] - tap_off[0];               // (equally spaced, ascending or descending: the data gradient lists them flipped)
+  if (d == 0) return false;
+  for (int j = 2; j < ntaps; ++j) if (tap_off[j] - tap_off[j - 1] != d) return false;
+  L->MT = Cout <= 64 ? 2 : 4;
+  if (Cout % (L->MT * 32) != 0) return false;
+  L->gy = Cout / (L->MT * 32);
+  L->MTtot = L->gy * L->MT;
+  L->nch = Cin / 32;
+  if (L->nch < L->MT) return false;                   // the image of a tile is streamed out in MT parts, one per item of the next tile
+  const int t_lo = d > 0 ? tap_off[0] : tap_off[ntaps - 1], t_hi = d > 0 ? tap_off[ntaps - 1] : tap_off[0];
+  L->min_off = t_lo;
+  L->F = 256 / V;
+  L->Fin = in_mul * (L->F - 1) + (t_hi - t_lo) + 1;
+  const int rows = L->Fin * V;
+  if (rows > 11 * 64) return false;
+  L->UL = (ntaps == 15 || rows > 8 * 64) ? 11 : 8;
+  if (ntaps <= 5) {
+    // (tconv.hip must pack these shapes identically: it serves every mode but the data gradient for them)
+    if (L->UL != 8) return false;
+    TconvGeom G;
+    if (tconv_geom(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, &G) != ISTGCN_OK || G.CC != 32 || G.nch != L->nch || G.MTtot != L->MTtot) return false;
+  }
+  size_t o = 0;
+  L->off_stat = 0;
+  o += (size_t)(3 * L->MT * 32 + 2 * Cin) * 4;
+  o = (o + 15) & ~(size_t)15;
+  const size_t ub = (size_t)L->UL * 64 * 64;
+  L->off_u0 = (int)o; o += ub;
+  L->off_u1 = (int)o; o += ub;
+  L->off_o = (int)o; o += (size_t)256 * 136 * 2;
+  L->lds = (int)o;
+  return o <= 160 * 1024;
+}
+
 }  // namespace tconv_geo
 
-// tconv_lean.hip: the kernel with the lean memory role, for the launches tconv_lean_ok() accepts (same packed weights)
+// tconv_lean.hip: the lean kernel's launcher (the caller has checked tconv_lean_geom and tconv_lean_serves)
 struct BnTail;
-bool tconv_lean_ok(const tconv_geo::TconvGeom& G, int mode, int Tin, int V, int Cin, int Cout, int ntaps, int out_mul, int dtype);
+bool tconv_lean_serves(int mode, int ntaps, int ul);
 int tconv_lean_launch(const void* in, const void* Wp, const float* bias, const float* pre, int pre_relu, const void* aux,
                       const float* maux, void* out, double* stats, int stats_rep, int mode, int NM, int Tin, int Tout,
-                      int Mlog, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int out_off, int dtype,
-                      int grid_cap, const tconv_geo::TconvGeom& G, const BnTail& tail, hipStream_t stream);
+                      int Mlog, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int out_mul, int out_off,
+                      int dtype, int grid_cap, const tconv_geo::LeanGeom& G, const BnTail& tail, hipStream_t stream);

@@ -1,36 +1,45 @@
-// Temporal convolution, wave-specialised kernel with a LEAN memory role (round 4) for the trunk layers in 16-bit storage:
-// same arithmetic, same packed weights, same LDS geometry and the same compute role (static k-structure) as tconv.hip --
+// Temporal convolution of the trunk layers in 16-bit storage: the wave-specialised kernel of round 4 ("lean").
 //
-//   out[n, m, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) )
+//   out[n, out_mul*m + out_off, v, o] = epi( sum_j sum_i Wf[j][o][i] * pre(in[n, in_mul*m + tap_off[j], v, i]) )
 //
-// (net/st_gcnold.py:165-175, the 15-tap fold of net/st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215 and their data gradients) --
-// but the four memory waves execute about a third of the instructions.  Why that matters: the stamps of round 3
-// (profiles/r03_tconv_role_stamps.txt) had the compute waves WAITING for the memory waves 20-38 % of every forward
-// launch (`commit`: 52 vector instructions per 16-byte vector) and of every data gradient (`store_pass`), and a wave
-// retires one instruction per ~4 cycles whatever its SIMD partner does: ~650 instructions per (tile, chunk) item are
-// 2600 cycles against 2304 cycles of matrix work at 64 channels.  What changed:
-//   * `pre` (BatchNorm affine + ReLU) is six instructions per dword -- shift / and (unpack two bf16), two fma, one
-//     v_cvt_pk_bf16_f32, one v_pk_max_i16 (ReLU on the packed pair: a negative float is a negative int16) -- written on
-//     scalars so that the compiler cannot re-vectorise it element by element; rows outside the sequence are masked only
-//     in tiles that touch a sequence edge (uniform branch);
-//   * tile decode once per tile and stream (issue / commit / epilogue cursors advanced by adds), per-lane load offsets
-//     fixed per tile (one add per load);
-//   * the epilogue of a tile is SPREAD over the items of the next tile (EPP = 4 image rows per thread and item), so the
-//     memory role's work per item is constant, the data gradient's `aux` rows are requested a whole `commit` ahead of
-//     their use (they used to wait out a memory round trip per batch), and stores go through a buffer descriptor that
-//     covers exactly the tile's rows (no row predicate);
-//   * mode 1 accumulates sum(d) and sum(d * x) -- the centring and the 1/sigma of x-hat are applied to the two sums once
-//     at the end (linear) -- and the ReLU mask is one fma + compare + select per element.
-// Shapes: 16-bit storage, whole channel vectors, CC = 32 (two k-groups per tap), taps in threes, 256-row tiles, 64 / 128
-// output channels per workgroup, out_mul = 1, modes 0 (forward) and 1 (data gradient).  Everything else: tconv.hip.
+// -- the (k,1) Conv2d of net/st_gcnold.py:165-175 with the BatchNorm + ReLU in front of it, the 15-tap fold of the
+// Inception-TCN (net/st_gcn_multi3_fix_3A_mstcn.py:160-180,212-215), their stride-2 forms, their data gradients (one
+// launch per output phase) and the folded inference conv -- the arithmetic of tconv.hip, reorganised around what the
+// instruments of rounds 3 and 4 measured:
+//
+//  * The two waves of a SIMD share its vector-issue port.  Next to a wave issuing back-to-back MFMAs a vector wave gets
+//    one plain instruction per 8-13 cycles (5 alone) and one PACKED fp32 instruction (v_pk_fma_f32, v_pk_add_f32) per 22
+//    (tools/valu_beside_mfma.hip, profiles/r04_valu_beside_mfma.txt); neither s_setprio nor which half of the workgroup
+//    runs which role changes that in the kernel.  So the memory role is written for few, plain vector instructions:
+//      - `pre` (BatchNorm affine + ReLU) per dword: shift / and (unpack two bf16), two fma, ONE v_cvt_pk_bf16_f32, one
+//        v_pk_max_i16 (ReLU on the packed pair: a negative float is a negative int16), on scalars; this file is compiled
+//        with -fno-slp-vectorize (below) -- the SLP vectoriser re-packed the fma / add pairs and `commit` took 5700 cycles
+//        per item with its v_pk_fma_f32, 2400 without (profiles/r04_tconv_lean_stamps.txt);
+//      - rows outside the sequence are masked only in tiles that touch a sequence edge (uniform branch); tile decode once
+//        per tile and stream; per-lane load offsets fixed per tile (one add per load); no predicated LDS store (the
+//        staged buffers have a slot for every vector a thread handles);
+//      - the epilogue of a tile is SPREAD over the items of the next tile (EPP image rows per thread and item): constant
+//        work per item, the data gradient's `aux` rows requested a whole `commit` ahead of their use, stores through a
+//        buffer descriptor that ends with the tile (no row predicate);
+//      - mode 1 accumulates sum(d) and sum(d * x); centring and 1/sigma of x-hat are applied to the two sums at the end.
+//  * The compute role (one wave per SIMD issues every MFMA) has a fully static step structure: the tap count is a template
+//    parameter, a step = (tap, k-group), weight ring DA steps deep straight from L2 (DA divides the steps of an item, so
+//    the ring runs continuously across items with static slots), activation fragments two steps ahead from LDS.  The
+//    MFMAs of an item's LAST step are issued behind the item barrier, after the first fragment reads of the next item:
+//    their LDS latency used to be exposed once per item.
+//  * Staged rows are 64 bytes (32 channels) with the 16-byte vectors XOR-swizzled by the JOINT index (bits 2-3), which a
+//    tap shift leaves unchanged: fragment reads and the memory waves' 16-byte stores are conflict-free without the
+//    80-byte row padding of tconv.hip -- and the buffers of a stride-2 forward (27 input frames) or a 15-tap conv (24)
+//    fit next to the output image with 32-channel chunks (tconv.hip falls back to 16-channel chunks there).
+//
+// Shapes: 16-bit storage, C_in % 32 == 0, C_out % 64 == 0, 4 / 5 / 9 / 15 equally spaced taps, 256-row tiles, 64 or 128
+// output channels per workgroup; modes 0 (forward + BatchNorm sums), 1 (data gradient: ReLU mask from `aux`, BatchNorm-
+// backward sums), 2 (inference: relu(conv + residual)).  tconv_lean_geom() (tconv_geom.hpp) is the one decision the
+// geometry query -- i.e. the weight packer -- and the launcher share.  Everything else: tconv.hip.
 //
 // hipcc-flags: -fno-slp-vectorize
-// (the build passes these to hipcc for this file.  The SLP vectoriser pairs the memory role's scalar fp32 operations into
-//  v_pk_fma_f32 / v_pk_add_f32; next to a wave issuing back-to-back MFMAs on the same SIMD a packed fp32 instruction
-//  takes 22 cycles against 13 for a plain one (tools/valu_beside_mfma.hip), and the stamped kernel had `commit` at 5700
-//  cycles per item with them, 2400 without: profiles/r04_tconv_lean_stamps.txt.)
 #include "common.hpp"
-#include "gcn_rc.hpp"     // rsrc_t / make_rsrc, pack2 / unpack2
+#include "gcn_rc.hpp"     // rsrc_t / make_rsrc, unpack2
 #include "bn_tail.hpp"
 #include "tconv_geom.hpp"
 #include <cstdlib>
@@ -38,26 +47,26 @@
 namespace {
 
 using tconv_geo::NROLE;
-using tconv_geo::UL;
-using tconv_geo::TconvGeom;
+using tconv_geo::LeanGeom;
 constexpr int NTH = 2 * NROLE;
-constexpr int MAX_TAPS = 16;
 constexpr int EPP = 4;               // image rows per thread and item in the spread epilogue
+constexpr int RB = 64;               // bytes per staged row: 32 channels, no padding
+constexpr int OS = 136;              // elements per image row: 128 channels + 8 (rows 4 banks apart)
 
 struct TlParams {
   const void* in;
   const void* Wp;
   const float* bias;     // [Cout] or null
   const float* pre;      // [2][Cin] scale, shift or null
-  const void* aux;       // mode 1: [NM][Tout][V][Cout]
-  const float* maux;     // mode 1: [4][Cout] scale, shift, mean, rstd
+  const void* aux;       // mode 1: [NM][Tout][V][Cout]; mode 2: the same or null
+  const float* maux;     // mode 1: [4][Cout] scale, shift, mean, rstd; mode 2: [2][Cout] scale, shift or null
   void* out;
   double* stats;         // [stats_rep][2][Cout] or null
-  int NM, Tin, Tout, Mlog, V, Cin, Cout, ntaps;
-  int in_mul, out_off, pre_relu, stats_rep;
-  int tap_off[MAX_TAPS];
+  int NM, Tin, Tout, Mlog, V, Cin, Cout;
+  int in_mul, out_mul, out_off, pre_relu, stats_rep;
+  int tap0, tapd;        // first tap offset, tap spacing (frames)
   int F, tiles_per_seq, total_tiles, nch, MTtot, min_off, Fin;
-  unsigned tps_magic;
+  unsigned tps_magic, v_magic;
   int off_stat, off_u0, off_u1, off_o;
   BnTail tail;
   unsigned long long* dbg;   // experiment builds (-DISTGCN_TCONV_STAMP): cycle stamps of workgroup 0 (null otherwise)
@@ -67,11 +76,6 @@ struct TlParams {
 #define TL_MMA(acc, a, b) { asm volatile("" :: "v"(a), "v"(b)); }
 #else
 #define TL_MMA(acc, a, b) mma_kgroup(acc, a, b)
-#endif
-#ifdef TL_X_PAD             /* experiment build: idle cycles in the compute wave after each MFMA (is the partner wave's VALU starved?) */
-#define TL_PAD asm volatile("s_nop %0" :: "n"(TL_X_PAD));
-#else
-#define TL_PAD
 #endif
 #ifdef ISTGCN_TCONV_STAMP   /* experiment build: where the cycles of one compute wave and one memory wave of workgroup 0 go */
 #define TSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
@@ -105,43 +109,30 @@ template <> __device__ inline uint32_t pk2<_Float16>(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
-constexpr int US = 40;               // elements per staged row: CC + EPL (80 bytes: conflict-free 16-byte fragment reads)
-constexpr int OS = 136;              // elements per image row: 128 channels + EPL
-
 struct TileL {
-  int n, m0, rows, in_rows, r_lo, r_hi;
+  int n, m0, nf, rows, in_rows, r_lo, r_hi;
   unsigned base;          // byte offset of the first staged row inside the sequence (wraps when the halo starts in front of it)
   bool valid, edge;
 };
 
-template <typename T, int MT, int MODE, int WM>
+// NTAPS: taps (a step = one (tap, k-group) pair: 2 * NTAPS steps per item).  ULV: 16-byte vectors of a staged chunk per
+// memory-wave thread = 64-row sweeps of the staged window (8: up to 512 rows; 11: up to 704).
+template <typename T, int MT, int MODE, int NTAPS, int ULV>
 __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
   using E = Elem<T>;
-  constexpr int EPL = 8, KGS = 16, CC = 32, NKG = 2;
+  constexpr int EPL = 8, CC = 32;
   constexpr int TR = 256;
-  // compute waves: WM channel groups x 4/WM row groups; a wave owns MT/WM channel tiles x 2*WM row tiles.  WM = 4 (one
-  // channel tile per wave, every wave all 256 rows): each weight fragment is fetched ONCE per CU and step instead of by
-  // both row groups -- the weight stream is vector-memory traffic (1 KB per wave instruction through a 64 B/clk path)
-  static_assert(MT % WM == 0 && 4 % WM == 0, "wave layout");
-  constexpr int MTW = MT / WM, NTW = 2 * WM;
+  constexpr int MTW = MT / 2, NTW = 4;                 // a compute wave: MT/2 channel tiles x 4 row tiles (2 x 2 waves)
+  constexpr int NIT = 2 * NTAPS;                       // steps per item
   typedef typename E::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* stat = reinterpret_cast<float*>(smem + P.off_stat);                 // [2][MT*32]
   float* bias_l = stat + 2 * MT * 32;                                        // [MT*32]
   float* pre_l = bias_l + MT * 32;                                           // [2][Cin]
-  T* outs = reinterpret_cast<T*>(smem + P.off_o);                            // [TR][out_stride]
+  T* outs = reinterpret_cast<T*>(smem + P.off_o);                            // [TR][OS]
 
   const int tid = threadIdx.x, lane = tid & 63;
-  // Roles by age: the MEMORY role runs on waves 0-3.  The two waves of a SIMD compete for its vector-issue port; the port
-  // goes to the older wave (a workgroup's waves 4-7 are the younger half; s_setprio does not change it) -- measured in
-  // isolation (tools/valu_beside_mfma.hip, profiles/r04_valu_beside_mfma.txt): next to a wave issuing back-to-back
-  // MFMAs a YOUNGER vector wave gets one instruction per 13 cycles, an OLDER one per 6.5 (alone: 5.1), and the MFMA
-  // wave runs at 32 cycles per MFMA either way.  The memory role is the one with the vector-ALU work (BatchNorm + ReLU
-  // of the chunk, the epilogue sums); the compute role's stream is MFMAs + loads.
-#ifndef TL_MEM_FIRST
-#define TL_MEM_FIRST 1
-#endif
-  const bool is_compute = TL_MEM_FIRST ? tid >= NROLE : tid < NROLE;
+  const bool is_compute = tid < NROLE;
   const int ltid = tid & (NROLE - 1), wave = ltid >> 6;
   const int V = P.V;
   const int mt0 = blockIdx.y * MT;
@@ -149,9 +140,15 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
 
   for (int c = tid; c < 2 * MT * 32; c += NTH) stat[c] = 0.f;
   for (int c = tid; c < MT * 32; c += NTH) bias_l[c] = P.bias ? P.bias[cbase_blk + c] : 0.f;
-  for (int c = tid; c < 2 * P.Cin; c += NTH) {
-    const int h = c / P.Cin;
-    pre_l[c] = P.pre ? P.pre[c] : (h == 0 ? 1.f : 0.f);
+  if constexpr (MODE == 1) {
+    // data gradient: there is no `pre` (checked by the launcher); its two LDS rows hold the ReLU-mask coefficients of this
+    // workgroup's channels instead (MT * 32 <= C_in by the geometry) -- in registers they were 16 of the memory role's 256
+    for (int c = tid; c < MT * 32; c += NTH) { pre_l[c] = P.maux[cbase_blk + c]; pre_l[P.Cin + c] = P.maux[P.Cout + cbase_blk + c]; }
+  } else {
+    for (int c = tid; c < 2 * P.Cin; c += NTH) {
+      const int h = c / P.Cin;
+      pre_l[c] = P.pre ? P.pre[c] : (h == 0 ? 1.f : 0.f);
+    }
   }
 
   const T* ing = reinterpret_cast<const T*>(P.in);
@@ -171,84 +168,74 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
     const int tile = xcd * chunk + slot0 + (t.valid ? k : 0) * G8;
     t.n = P.tiles_per_seq == 1 ? tile : (int)__umulhi((unsigned)tile, P.tps_magic);
     t.m0 = (tile - t.n * P.tiles_per_seq) * P.F;
-    const int nf = min(P.F, P.Mlog - t.m0);
-    t.rows = nf * V;
+    t.nf = min(P.F, P.Mlog - t.m0);
+    t.rows = t.nf * V;
     const int fin0 = P.in_mul * t.m0 + P.min_off;                           // first staged input frame (may be < 0)
-    t.in_rows = (P.in_mul * (nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V;   // frames actually needed
+    t.in_rows = (P.in_mul * (t.nf - 1) + P.Fin - P.in_mul * (P.F - 1)) * V; // frames actually needed
     t.r_lo = fin0 < 0 ? -fin0 * V : 0;
     t.r_hi = min(t.in_rows, (P.Tin - fin0) * V);
     t.base = (unsigned)(fin0 * V * P.Cin * (int)sizeof(T));
     t.edge = t.r_lo > 0 || t.r_hi < t.in_rows;
     return t;
   };
+  // frame / joint index of a row (x / V by multiplication: V <= 128, rows < 2^16)
+  auto frame_of = [&](int r) __attribute__((always_inline)) { return (int)__umulhi((unsigned)r, P.v_magic); };
   lds_barrier();
 #ifdef ISTGCN_TCONV_STAMP
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef TL_X_PRIO            /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
-  if ((TL_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
-#endif
 
   if (is_compute) {
     // =========================================== compute waves ===========================================
-    // (the static-k loop of tconv.hip: a six-step chunk = three taps x two k-groups; weight ring 5 steps ahead from L2,
-    //  activation fragments 2 steps ahead from LDS; one MFMA, then the loads in its shadow)
-    constexpr int DA = 6, DB = NTW >= 8 ? 2 : 3, PD = DB - 1;
+#ifndef TL_X_MEMONLY        /* ISA inspection builds: the memory role alone (register need) */
+    constexpr int DA = NIT % 6 == 0 ? 6 : NIT % 5 == 0 ? 5 : 4;     // weight ring: DA - 1 steps ahead; divides NIT
+    constexpr int DB = 3, PD = 2;                                    // activation ring: two steps ahead
+    // the last step's MFMAs can move behind the barrier when its activation slot is not one the next item's first two
+    // steps load into, i.e. when the slot numbering does not rotate from item to item
+    constexpr bool DEFER = NIT % DB == 0;
+    static_assert(NIT % DA == 0 && NIT >= DA, "static ring slots");
     f32x16 acc[MTW][NTW];
-    int brow[NTW];
-    const int wr = wave / WM, wm = wave % WM;                // row group, channel group of this wave
-    const int hoff = (lane >> 5) * EPL;
-    const int nit = P.ntaps * NKG;
-    const int roff0 = (P.tap_off[0] - P.min_off) * V;
-    const int rstep = P.ntaps > 1 ? (P.tap_off[1] - P.tap_off[0]) * V : 0;
+    const int wr = wave / 2, wm = wave % 2;                  // row group, channel group of this wave
+    const int h = lane >> 5;
     const unsigned astr = (unsigned)(P.MTtot * 64 * EPL);    // elements between the fragments of consecutive steps
-    const unsigned alim = (unsigned)(nch * nit) * astr;
+    const unsigned alim = (unsigned)(nch * NIT) * astr;
     const T* abase = Wp + ((size_t)(mt0 + wm * MTW) * 64 + lane) * EPL;
     u32x4 a[DA][MTW], b[DB][NTW];
     unsigned ao = 0;
     auto load_as = [&](u32x4 (&dst)[MTW]) __attribute__((always_inline)) {
-#ifdef TL_X_NOA             /* experiment build: no weight-fragment loads at all (results wrong) */
-      return;
-#endif
-#ifdef TL_X_WL1             /* experiment build: every weight fragment is fragment 0 (L1 hits; results wrong) */
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + (unsigned)(m * 64 * EPL));
-#else
 #pragma unroll
       for (int m = 0; m < MTW; ++m) dst[m] = *reinterpret_cast<const u32x4*>(abase + ao + (unsigned)(m * 64 * EPL));
-#endif
       const unsigned an = ao + astr;
       ao = an == alim ? 0u : an;
     };
-    const T* us = reinterpret_cast<const T*>(smem + P.off_u0);
-    const int ts1 = rstep * US;
-    const int tsk[4] = {0, ts1, 2 * ts1, 3 * ts1};
-    int soffc = 0;
-    auto load_bs = [&](u32x4 (&dst)[NTW], int soff) __attribute__((always_inline)) {
-#ifdef TL_X_NOB             /* experiment build: no activation-fragment reads (results wrong) */
-      return;
-#endif
-#pragma unroll
-      for (int tt = 0; tt < NTW; ++tt) dst[tt] = *reinterpret_cast<const u32x4*>(us + brow[tt] + soff);
-    };
-#pragma unroll
-    for (int d = 0; d < DA - 1; ++d) load_as(a[d]);         // in flight while the first chunk is being staged
-    // per-lane LDS element offset of each output row's fragment at tap offset 0 (row p of the tile = frame p / V, joint
-    // p % V; input frame = in_mul * frame): the same for every tile.  Rows past a short last tile are NOT clamped: they read
-    // rows of the staged buffer that nobody wrote for this tile (inside its UL * 64 rows) and produce garbage in their own
-    // accumulator columns only, which the epilogue masks before the sums and whose stores fall outside the tile's descriptor
+    // per-lane LDS byte offset of each output row's fragment at tap offset 0, one per k-group: row p of the tile = frame
+    // p / V, joint p % V, input frame in_mul * frame; the row's vector (2 kg + h) sits at 16 * ((2 kg + h) ^ sw(joint)),
+    // sw = bits 2-3 of the joint -- unchanged by a tap shift (whole frames), so the swizzle is a per-lane constant: kg = 1
+    // is kg = 0 with bit 5 flipped.  Rows past a short last tile are NOT clamped: they read rows of the staged buffer that
+    // nobody wrote for this tile and produce garbage in their own accumulator columns only (masked by the epilogue).
+    unsigned brow[NTW];
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
       const int p = wr * (32 * NTW) + tt * 32 + (lane & 31);
-      const int f = p / V;
-      brow[tt] = ((P.in_mul * f) * V + (p - f * V)) * US + hoff;
+      const int f = frame_of(p), v = p - f * V;
+      brow[tt] = (unsigned)(((P.in_mul * f) * V + v) * RB + 16 * (h ^ ((v >> 2) & 3)));
     }
+    unsigned ubase = (unsigned)P.off_u0;
+    // (tapd may be negative -- the data gradient's taps are listed flipped --: unsigned arithmetic, the sums are in range)
+    const unsigned roff0 = (unsigned)((P.tap0 - P.min_off) * V * RB), rstep = (unsigned)(P.tapd * V * RB);
+    // activation fragments of step s (tap s / 2, k-group s % 2)
+    auto load_bs = [&](u32x4 (&dst)[NTW], int s) __attribute__((always_inline)) {
+      const unsigned so = ubase + roff0 + (unsigned)(s >> 1) * rstep;
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        dst[tt] = *reinterpret_cast<const u32x4*>(smem + (((s & 1) ? brow[tt] ^ 32u : brow[tt]) + so));
+    };
     auto acc_init = [&]() __attribute__((always_inline)) {   // accumulators = conv bias (rows of the D tile = output channels)
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + (wm * MTW + m) * 32 + 8 * q4 + 4 * (lane >> 5));
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + (wm * MTW + m) * 32 + 8 * q4 + 4 * h);
 #pragma unroll
           for (int tt = 0; tt < NTW; ++tt)
 #pragma unroll
@@ -256,72 +243,60 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
         }
       }
     };
-    // One step = this step's MFMAs plus the loads of later steps (weights DA-1 steps ahead, activations PD steps ahead);
-    // sched_group_barrier interleaves one MFMA with the loads in its shadow.  LB = false: no activation prefetch (the last
-    // PD steps of an item: their targets lie past the item).  MM = false: loads only -- the MFMAs of an item's LAST step
-    // are issued after the item barrier, behind the first fragment reads of the NEXT item (TL_MMAS): the operands of that
-    // step are in registers (weight ring slot DA-1, activation ring slot DB-1, which the next item's prologue does not
-    // touch), so the matrix pipe works through them while the new item's first fragments are on their way from LDS --
-    // that latency used to be exposed once per item (~10 % of a 64-channel item).
-#define TL_MMAS(D)                                                                                       \
-        _Pragma("unroll") for (int m = 0; m < MTW; ++m)                                                  \
-          _Pragma("unroll") for (int tt = 0; tt < NTW; ++tt) { TL_MMA(acc[m][tt], __builtin_bit_cast(frag_t, a[D][m]), __builtin_bit_cast(frag_t, b[(D) % DB][tt])); TL_PAD }
-#define TL_STEP(D, LB, MM)                                                                               \
-      {                                                                                                  \
-        load_as(a[((D) + DA - 1) % DA]);                                                                 \
-        if (LB) load_bs(b[((D) + PD) % DB], soffc + tsk[((D) + PD) >> 1] + (((D) + PD) & 1) * KGS);      \
-        if (MM) {                                                                                        \
-          TL_MMAS(D)                                                                                     \
-          _Pragma("unroll") for (int i_ = 0; i_ < MTW * NTW; ++i_) {                                     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                           \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                           \
-            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                           \
-          }                                                                                              \
-        }                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-      }
-    static_assert(PD <= 2 && (DA - 1) % DB == DB - 1, "the deferred step's activation slot is the one the prologue leaves alone");
-    const int nchunk = nit / DA;
+    auto mmas = [&](u32x4 (&aa)[MTW], u32x4 (&bb)[NTW]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) TL_MMA(acc[m][tt], __builtin_bit_cast(frag_t, aa[m]), __builtin_bit_cast(frag_t, bb[tt]));
+    };
+#pragma unroll
+    for (int d = 0; d < DA - 1; ++d) load_as(a[d]);         // in flight while the first chunk is being staged
     lds_barrier();                                          // item 0 staged (the memory waves' prologue)
-    int ch = 0, k = 0;
+    int ch = 0;
     if (total_items > 0) {
       acc_init();
-      soffc = roff0 * US;
 #pragma unroll
-      for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
+      for (int d = 0; d < PD; ++d) load_bs(b[d], d);
     }
     TSTAMP(5)
     for (int it = 0; it < total_items; ++it) {
-      for (int c = 0; c < nchunk - 1; ++c) {
-        TL_STEP(0, true, true) TL_STEP(1, true, true) TL_STEP(2, true, true) TL_STEP(3, true, true) TL_STEP(4, true, true) TL_STEP(5, true, true)
-        soffc += tsk[3];
+      // One step = this step's MFMAs plus the loads of later steps (weights DA - 1 steps ahead, activations PD ahead, none
+      // past the item); sched_group_barrier interleaves one MFMA with the loads in its shadow.
+#pragma unroll
+      for (int s = 0; s < NIT; ++s) {
+        load_as(a[(s + DA - 1) % DA]);
+        if (s + PD < NIT) load_bs(b[(s + PD) % DB], s + PD);
+        if (!(DEFER && s == NIT - 1)) {
+          mmas(a[s % DA], b[s % DB]);
+#pragma unroll
+          for (int i_ = 0; i_ < MTW * NTW; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      TL_STEP(0, true, true) TL_STEP(1, true, true) TL_STEP(2, true, true) TL_STEP(3, true, true)
-      TL_STEP(4, PD < 2, true) TL_STEP(5, false, false)
-      TSTAMP(1)                                             // the steps (all but the last one's MFMAs)
-      us = reinterpret_cast<const T*>(smem + (((it + 1) & 1) ? P.off_u1 : P.off_u0));
+      TSTAMP(1)                                             // the steps
+      ubase = (unsigned)(((it + 1) & 1) ? P.off_u1 : P.off_u0);
       lds_barrier();                                        // item done: this half of the tile buffer may be refilled
       TSTAMP(2)                                             // wait at the item barrier
       const bool tile_end = ++ch == nch;
-      const bool more = it + 1 < total_items;
-      if (tile_end) {
-        ch = 0;
-        ++k;
-      }
-      // (the row bases are loop invariants now; made opaque per item, or the compiler materialises every `base + tap offset`
-      //  sum of the item in its own register -- ~20 of them -- and spills them around the loop: reloads with vmcnt(0)
-      //  waits at every item start, i.e. a drained weight ring)
+      if (tile_end) ch = 0;
+      // (the row bases are loop invariants; made opaque per item, or the compiler materialises every `base + tap offset`
+      //  sum of the item in its own register and spills them around the loop: reloads with vmcnt(0) waits, a drained ring)
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt) asm volatile("" : "+v"(brow[tt]));
-      if (more) {                                           // the next item's first fragment reads ...
-        soffc = roff0 * US;
+      if (it + 1 < total_items) {                           // the next item's first fragment reads ...
 #pragma unroll
-        for (int d = 0; d < PD; ++d) load_bs(b[d], soffc + tsk[d >> 1] + (d & 1) * KGS);
+        for (int d = 0; d < PD; ++d) load_bs(b[d], d);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      TL_MMAS(5)                                            // ... and, in their shadow, the MFMAs of this item's last step
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DEFER) {
+        __builtin_amdgcn_sched_barrier(0);
+        mmas(a[(NIT - 1) % DA], b[(NIT - 1) % DB]);         // ... and, in their shadow, the MFMAs of this item's last step
+        __builtin_amdgcn_sched_barrier(0);
+      }
       TSTAMP(0)                                             // item start
       if (tile_end) {
         // ---- tile end: accumulators -> LDS output image (row-major, channels innermost) ----
@@ -332,7 +307,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
           for (int m = 0; m < MTW; ++m) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-              const int cl = (wm * MTW + m) * 32 + 8 * q4 + 4 * (lane >> 5);
+              const int cl = (wm * MTW + m) * 32 + 8 * q4 + 4 * h;
               float v4[4] = {acc[m][tt][4 * q4], acc[m][tt][4 * q4 + 1], acc[m][tt][4 * q4 + 2], acc[m][tt][4 * q4 + 3]};
               store4(outs + sr * OS + cl, v4);
             }
@@ -344,63 +319,63 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
         TSTAMP(4)
       }
     }
-#undef TL_STEP
-#undef TL_MMAS
 #ifdef ISTGCN_TCONV_STAMP
     if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 6; ++i) P.dbg[i] = tacc[i]; P.dbg[6] = (unsigned long long)total_items; }
+#endif
 #endif
   } else {
     // =========================================== memory waves ============================================
     constexpr int Q = CC / EPL;                             // 4 channel vectors per staged row
-    const int q = ltid & (Q - 1), r0 = ltid >> 2;
+    const int q = ltid & (Q - 1);
+    int r0 = ltid >> 2;                                     // (not const: made opaque once per item, see `iteration`)
     constexpr int RS = NROLE / Q;                           // 64 rows per sweep of the 256 threads
     const int winrows = P.Fin * V;
     const unsigned seq_bytes = (unsigned)(P.Tin * V * P.Cin * (int)sizeof(T));
     const size_t seq_elems = (size_t)P.Tin * V * P.Cin;
-    // byte offset of this thread's u-th vector inside a staged window; rows past the window's capacity are permanently
-    // out of range (0x80000000 + any tile base stays above 2^30 > the sequence: no traffic)
-    // (the LDS half-buffers of this kernel hold UL * RS rows, so every vector has a slot and no store is predicated)
-    unsigned voff[UL], vofft[UL];
+    // byte offset of this thread's u-th vector inside a staged window: voff0 + u * vstep; rows past the window are out of
+    // range for good (0x80000000 + any tile base stays above the 2^30 the launcher guarantees a sequence to be shorter
+    // than: no traffic).  Its LDS slot: row (r0 + 64 u), vector q swizzled by the row's joint -- the buffers hold ULV * 64
+    // rows, so every vector has a slot and no store is predicated; the swizzled vector positions of all ULV rows are kept
+    // as 2-bit fields of ONE register (a register per slot offset cost 2 x ULV registers and the role spilled).
+    unsigned vofft[ULV];
+    const unsigned voff0 = (unsigned)((r0 * P.Cin + q * EPL) * (int)sizeof(T)), vstep = (unsigned)(RS * P.Cin * (int)sizeof(T));
+    unsigned swz = 0;
 #pragma unroll
-    for (int u = 0; u < UL; ++u) {
+    for (int u = 0; u < ULV; ++u) {
       const int r = r0 + u * RS;
-      voff[u] = r < winrows ? (unsigned)((r * P.Cin + q * EPL) * (int)sizeof(T)) : 0x80000000u;
+      const int v = r - frame_of(r) * V;
+      swz |= (unsigned)(q ^ ((v >> 2) & 3)) << (2 * u);
     }
-    const unsigned lds0 = (unsigned)((r0 * US + q * EPL) * (int)sizeof(T));
-    const unsigned ldss = (unsigned)(RS * US * (int)sizeof(T));
+    const unsigned lbase = (unsigned)(r0 * RB);
 
     // ---- issue stream: item (ki, chi) -> registers.  One buffer descriptor per sequence: rows behind the sequence read
     //      as zeros without touching memory; rows in FRONT of it get a far offset once per tile (0xC0000000 + base never
-    //      wraps below the 2^30 the launcher guarantees the sequence to be shorter than). ----
+    //      wraps below 2^30). ----
     TileL ti = tile_of(0);
     int ki = 0, chi = 0;
     auto set_issue_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < UL; ++u) vofft[u] = (r0 + u * RS >= ti.r_lo) ? voff[u] : 0xC0000000u;
+      for (int u = 0; u < ULV; ++u) {
+        const int r = r0 + u * RS;
+        vofft[u] = r < ti.r_lo ? 0xC0000000u : r < winrows ? voff0 + (unsigned)u * vstep : 0x80000000u;
+      }
     };
     set_issue_tile();
-    auto issue = [&](u32x4 (&R)[UL]) __attribute__((always_inline)) {
-#ifdef TL_X_NOLOAD          /* experiment build: empty descriptor, the chunk loads touch no memory (results wrong) */
-      const rsrc_t rs = make_rsrc(ing + (size_t)ti.n * seq_elems, 0u);
-#else
+    auto issue = [&](u32x4 (&R)[ULV]) __attribute__((always_inline)) {
       const rsrc_t rs = make_rsrc(ing + (size_t)ti.n * seq_elems, ti.valid ? seq_bytes : 0u);
-#endif
       const unsigned base = ti.base + (unsigned)(chi * CC * (int)sizeof(T));
 #pragma unroll
-      for (int u = 0; u < UL; ++u) R[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vofft[u] + base, 0, 0));
+      for (int u = 0; u < ULV; ++u) R[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vofft[u] + base, 0, 0));
       if (++chi == nch) { chi = 0; ++ki; ti = tile_of(ki); set_issue_tile(); }
     };
 
     // ---- commit stream: registers of item (kc, chc) -> `pre` -> LDS tile ----
     TileL tc = tile_of(0);
     int kc = 0, chc = 0;
-    auto commit = [&](u32x4 (&R)[UL], unsigned ubytes) __attribute__((always_inline)) {
-#ifdef TL_X_NOCOMMIT        /* experiment build: the staged chunk is never transformed / written (results wrong) */
-      if (false) {
-#else
+    auto commit = [&](u32x4 (&R)[ULV], unsigned ubytes) __attribute__((always_inline)) {
       if (tc.valid) {
-#endif
-        unsigned char* dst = smem + ubytes + lds0;
+        unsigned char* dst = smem + ubytes;
+        asm volatile("" : "+v"(swz));        // (opaque per item: the slot offsets are loop invariants the compiler would keep in 2 x ULV registers)
         auto sweep = [&](auto has_pre, auto relu, auto edge) __attribute__((always_inline)) {
           float sc[EPL], sh[EPL];
           if constexpr (decltype(has_pre)::value) {
@@ -414,13 +389,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
             }
           }
 #pragma unroll
-          for (int u = 0; u < UL; ++u) {
+          for (int u = 0; u < ULV; ++u) {
             uint32_t w[4] = {R[u][0], R[u][1], R[u][2], R[u][3]};
-#ifndef TL_X_NOXFORM        /* experiment build: the chunk is staged untransformed (results wrong) */
             if constexpr (decltype(has_pre)::value) {
-#else
-            if constexpr (false) {
-#endif
 #pragma unroll
               for (int d = 0; d < 4; ++d) {
                 float lo, hi;
@@ -439,7 +410,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
               for (int d = 0; d < 4; ++d) w[d] &= keep;
             }
             const u32x4 o = {w[0], w[1], w[2], w[3]};
-            *reinterpret_cast<u32x4*>(dst + u * ldss) = o;
+            *reinterpret_cast<u32x4*>(dst + (lbase + (((swz >> (2 * u)) & 3u) << 4)) + u * (RS * RB)) = o;
           }
         };
         using yes = std::integral_constant<bool, true>;
@@ -459,49 +430,70 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
     constexpr int NR = TR / RSTEP;                          // image rows per thread
     constexpr int NPARTS = NR / EPP;
     static_assert(NR % EPP == 0, "whole parts");
-    const int vq = ltid % VPR, prow = ltid / VPR;
-    const unsigned img0 = (unsigned)((prow * OS + vq * EPL) * (int)sizeof(T));
+    const int vq = ltid % VPR;
+    int prow = ltid / VPR;                                  // (opaque once per item, like r0)
+    unsigned img0 = (unsigned)((prow * OS + vq * EPL) * (int)sizeof(T));
     const unsigned imgs = (unsigned)(RSTEP * OS * (int)sizeof(T));
-    const unsigned gof0 = (unsigned)((prow * P.Cout + vq * EPL) * (int)sizeof(T));     // inside the tile's rows
-    const unsigned gofs = (unsigned)(RSTEP * P.Cout * (int)sizeof(T));
+    const unsigned rowb = (unsigned)(P.Cout * (int)sizeof(T));                          // bytes of an output row
+    const unsigned colb = (unsigned)(vq * EPL * (int)sizeof(T));
     float s1[EPL], s2[EPL];
 #pragma unroll
     for (int jj = 0; jj < EPL; ++jj) { s1[jj] = 0.f; s2[jj] = 0.f; }
     float msc[EPL], msh[EPL];
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 2) {
       const int cg = cbase_blk + vq * EPL;
 #pragma unroll
-      for (int jj = 0; jj < EPL; ++jj) { msc[jj] = P.maux[cg + jj]; msh[jj] = P.maux[P.Cout + cg + jj]; }
+      for (int jj = 0; jj < EPL; ++jj) {
+        msc[jj] = P.maux ? P.maux[cg + jj] : 1.f;
+        msh[jj] = P.maux ? P.maux[P.Cout + cg + jj] : 0.f;
+      }
     }
     TileL pend = tile_of(0);
     int ppart = NPARTS;                                     // nothing pending
     T* outg = reinterpret_cast<T*>(P.out);
     const T* auxg = reinterpret_cast<const T*>(P.aux);
+    const bool has_aux = MODE == 1 || (MODE == 2 && auxg != nullptr);
+    // The tile's output rows in HBM: row p of the tile is output frame out_mul * (m0 + p / V) + out_off, joint p % V, i.e.
+    // (p + (out_mul - 1) * (p / V) * V) rows behind the tile's first one; the descriptor ends with the tile's last row, so
+    // image rows past a short tile land behind it and their stores are dropped (their loads read zeros).
     auto tile_elem0 = [&](const TileL& t) __attribute__((always_inline)) {
-      return ((size_t)(t.n * P.Tout + t.m0 + P.out_off) * V) * P.Cout + cbase_blk;
+      return ((size_t)(t.n * P.Tout + P.out_mul * t.m0 + P.out_off) * V) * P.Cout + cbase_blk;
     };
-    // mode 1: the part's `aux` rows, requested at the top of the iteration (a zero-size descriptor when nothing is pending:
-    // the same number of loads on every path keeps the compiler's vmcnt bookkeeping exact)
+    auto tile_bytes = [&](const TileL& t) __attribute__((always_inline)) {
+      return (unsigned)((t.rows + (P.out_mul - 1) * (t.nf - 1) * V) * (int)rowb) - (unsigned)(cbase_blk * (int)sizeof(T));
+    };
+    // (9 / 15 taps are forward convolutions or the data gradients of stride-1 ones: dense output rows, out_mul = 1, checked
+    //  by the launcher; 4 / 5 taps are the phases of a stride-2 convolution's data gradient: every out_mul-th frame)
+    constexpr bool DENSE = NTAPS >= 9;
+    auto row_off = [&](int p) __attribute__((always_inline)) {       // byte offset of image row p in the tile's HBM window
+      const int rr = DENSE ? p : p + (P.out_mul - 1) * frame_of(p) * V;
+      return (unsigned)rr * rowb + colb;
+    };
+    // modes 1 / 2: the part's `aux` rows, requested at the top of the iteration (a zero-size descriptor when nothing is
+    // pending: the same number of loads on every path keeps the compiler's vmcnt bookkeeping exact)
     auto aux_issue = [&](u32x4 (&AV)[EPP]) __attribute__((always_inline)) {
-      if constexpr (MODE == 1) {
-        const bool act = ppart < NPARTS;
-        const rsrc_t rs = make_rsrc(auxg + tile_elem0(pend), act ? (unsigned)(pend.rows * P.Cout * (int)sizeof(T)) : 0u);
-        const unsigned vo = gof0 + (unsigned)(ppart * EPP) * gofs;     // (all of the offset in the VGPR: that is what the range check sees)
+      if constexpr (MODE >= 1) {
+        const bool act = ppart < NPARTS && has_aux;
+        const rsrc_t rs = make_rsrc((auxg ? auxg : ing) + (act ? tile_elem0(pend) : 0), act ? tile_bytes(pend) : 0u);
 #pragma unroll
-        for (int e = 0; e < EPP; ++e)
-          AV[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + (unsigned)e * gofs, 0, 2 /* nt: read once */));
+        for (int e = 0; e < EPP; ++e)       // (all of the offset in the VGPR: that is what the range check sees)
+          AV[e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, row_off(prow + (ppart * EPP + e) * RSTEP), 0, 2 /* nt: read once */));
       }
     };
     auto epi_part = [&](u32x4 (&AV)[EPP]) __attribute__((always_inline)) {
       if (ppart >= NPARTS) return;
-#ifdef TL_X_NOEPI           /* experiment build: the output image is never streamed out (results wrong) */
-      ++ppart;
-      return;
-#endif
-      const rsrc_t ro = make_rsrc(outg + tile_elem0(pend), (unsigned)(pend.rows * P.Cout * (int)sizeof(T)));
+      const rsrc_t ro = make_rsrc(outg + tile_elem0(pend), tile_bytes(pend));
       const int i0 = ppart * EPP;
-      const unsigned vo = gof0 + (unsigned)i0 * gofs;
       const unsigned char* img = smem + P.off_o + img0 + (unsigned)i0 * imgs;
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int e4 = 0; e4 < EPL; e4 += 4) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(pre_l + vq * EPL + e4);
+          const f32x4 h4 = *reinterpret_cast<const f32x4*>(pre_l + P.Cin + vq * EPL + e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { msc[e4 + e] = s4[e]; msh[e4 + e] = h4[e]; }
+        }
+      }
       auto body = [&](auto masked) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < EPP; ++e) {
@@ -527,6 +519,17 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
               s2[2 * d + 1] = __builtin_fmaf(ohi, ghi, s2[2 * d + 1]);
               w[d] = pk2<T>(olo, ohi);
             }
+          } else if constexpr (MODE == 2) {                 // inference: relu(conv + scale * residual + shift)
+            const uint32_t g[4] = {AV[e][0], AV[e][1], AV[e][2], AV[e][3]};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              float glo, ghi, zlo, zhi;
+              unpack2<T>(g[d], glo, ghi);
+              unpack2<T>(w[d], zlo, zhi);
+              const float olo = has_aux ? zlo + __builtin_fmaf(glo, msc[2 * d], msh[2 * d]) : zlo;
+              const float ohi = has_aux ? zhi + __builtin_fmaf(ghi, msc[2 * d + 1], msh[2 * d + 1]) : zhi;
+              w[d] = relu_pk(pk2<T>(olo, ohi));
+            }
           } else {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
             }
           }
           const u32x4 o = {w[0], w[1], w[2], w[3]};
-          __builtin_amdgcn_raw_buffer_store_b128(o, ro, vo + (unsigned)e * gofs, 0, 0);        // rows >= pend.rows: dropped
+          __builtin_amdgcn_raw_buffer_store_b128(o, ro, row_off(prow + (i0 + e) * RSTEP), 0, 0);     // rows >= pend.rows: dropped
         }
       };
       using yes = std::integral_constant<bool, true>;
@@ -551,24 +554,25 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
 
     // ---- the item loop.  While the compute waves are on item `it`, item it+1 goes registers -> LDS (other half of the
     //      tile buffer) and item it+2 HBM -> registers; behind them one part of the previous tile's image goes LDS -> HBM. ----
-    u32x4 RA[UL], RB[UL];
+    u32x4 RA[ULV], RBf[ULV];
     issue(RA);
-    issue(RB);
+    issue(RBf);
     __builtin_amdgcn_sched_barrier(0);
     commit(RA, (unsigned)P.off_u0);
     lds_barrier();                                          // item 0 staged
     int ch = 0, kt = 0;
-    auto iteration = [&](int it, u32x4 (&Rn)[UL], u32x4 (&Rf)[UL]) __attribute__((always_inline)) {    // Rn: item it+1, Rf: free -> item it+2
+    auto iteration = [&](int it, u32x4 (&Rn)[ULV], u32x4 (&Rf)[ULV]) __attribute__((always_inline)) {   // Rn: item it+1, Rf: free -> item it+2
+      // (r0 opaque per item: everything derived from it -- the ULV row numbers of the edge masks, slot offsets -- is a loop
+      //  invariant the compiler would otherwise keep in a register each and spill: reloads with vmcnt(0) waits in the loop)
+      asm volatile("" : "+v"(r0));
+      asm volatile("" : "+v"(prow));
+      asm volatile("" : "+v"(img0));
       u32x4 AV[EPP];
       aux_issue(AV);
       __builtin_amdgcn_sched_barrier(0);
       issue(Rf);                                            // (past the last item: empty descriptor, same number of loads)
       __builtin_amdgcn_sched_barrier(0);
       TSTAMP(0)
-#ifdef ISTGCN_TCONV_STAMP    /* the wait for item it+1's loads, stamped apart from the transform (slot 4 = tile-end barrier is tiny) */
-      if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      TSTAMP(4)
-#endif
       commit(Rn, (unsigned)(((it + 1) & 1) ? P.off_u1 : P.off_u0));     // (past the last item: tc.valid is false)
       __builtin_amdgcn_sched_barrier(0);
       TSTAMP(1)
@@ -580,15 +584,15 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
         ch = 0;
         lds_barrier();                                      // image written by the compute waves
         TSTAMP(3)
-        // (NPARTS <= nch, checked by the launcher: the previous image has been streamed out completely)
+        // (NPARTS <= nch, checked by the geometry: the previous image has been streamed out completely)
         pend = tile_of(kt++);
         ppart = 0;
       }
     };
     TSTAMP(5)
     for (int it = 0; it < total_items; it += 2) {
-      iteration(it, RB, RA);
-      if (it + 1 < total_items) iteration(it + 1, RA, RB);
+      iteration(it, RBf, RA);
+      if (it + 1 < total_items) iteration(it + 1, RA, RBf);
     }
     while (ppart < NPARTS) {                                // the last tile's image
       u32x4 AV[EPP];
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
 #endif
 
     // ---- BatchNorm partial sums: registers -> lanes sharing a channel vector -> LDS ----
-    if (P.stats) {
+    if (MODE != 2 && P.stats) {
 #pragma unroll
       for (int jj = 0; jj < EPL; ++jj) {
         float a = s1[jj], b = s2[jj];
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
     }
   }
 
-  if (P.stats) {
+  if (MODE != 2 && P.stats) {
     lds_barrier();
     double* dst = P.stats + (size_t)(blockIdx.x % P.stats_rep) * 2 * P.Cout;
     for (int c = tid; c < MT * 32; c += NTH) {
@@ -630,9 +634,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
   bn_tail_run(P.tail, gridDim.x * gridDim.y, reinterpret_cast<unsigned*>(smem));
 }
 
-template <typename T, int MT, int MODE, int WM>
+template <typename T, int MT, int MODE, int NTAPS, int ULV>
 int launch_lean(const TlParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
-  auto kfn = tconv_lean_kernel<T, MT, MODE, WM>;
+  auto kfn = tconv_lean_kernel<T, MT, MODE, NTAPS, ULV>;
   static std::atomic<unsigned long long> optin{0};
   if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
   int gx = (grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, NTH, lds)) / gy;
@@ -642,62 +646,57 @@ int launch_lean(const TlParams& P, int grid_cap, int gy, size_t lds, hipStream_t
   return ISTGCN_OK;
 }
 
-}  // namespace
-
-// LDS layout of the lean kernel: the tables of tconv.hip, two staged-chunk buffers of UL * 64 rows each (a slot for every
-// vector a memory-wave thread handles: no predicated LDS store), the output image.
-struct LeanLds { int off_stat, off_u0, off_u1, off_o, lds; };
-static LeanLds lean_lds(const tconv_geo::TconvGeom& G, int Cin) {
-  LeanLds L;
-  size_t off = 0;
-  L.off_stat = (int)off;
-  off += (size_t)(3 * G.MT * 32 + 2 * Cin) * 4;
-  off = (off + 15) & ~(size_t)15;
-  const size_t ubytes = (size_t)UL * 64 * G.us_stride * 2;
-  L.off_u0 = (int)off; off += ubytes;
-  L.off_u1 = (int)off; off += ubytes;
-  L.off_o = (int)off; off += (size_t)256 * G.out_stride * 2;
-  L.lds = (int)off;
-  return L;
+template <typename T>
+int launch_lean_T(const TlParams& P, const LeanGeom& G, int mode, int ntaps, int grid_cap, hipStream_t stream) {
+  const size_t lds = (size_t)G.lds;
+#define CASE(MTv, MD, NTv, ULv) \
+  if (G.MT == MTv && mode == MD && ntaps == NTv && G.UL == ULv) return launch_lean<T, MTv, MD, NTv, ULv>(P, grid_cap, G.gy, lds, stream)
+#ifdef TL_X_ONE             /* ISA inspection builds: one instantiation */
+#define CASES(MTv) CASE(MTv, 1, 9, 8)
+#else
+#define CASES(MTv)                                                                                           \
+  CASE(MTv, 0, 9, 8); CASE(MTv, 0, 9, 11); CASE(MTv, 0, 15, 11);                                             \
+  CASE(MTv, 1, 9, 8); CASE(MTv, 1, 15, 11); CASE(MTv, 1, 5, 8); CASE(MTv, 1, 4, 8);                          \
+  CASE(MTv, 2, 9, 8); CASE(MTv, 2, 9, 11); CASE(MTv, 2, 15, 11)
+#endif
+  CASES(2);
+  CASES(4);
+#undef CASES
+#undef CASE
+  return ISTGCN_EINVAL;
 }
 
-// Does the lean kernel serve this launch?  (Called by istgcn_tconv with the geometry it has already decided.)
-bool tconv_lean_ok(const tconv_geo::TconvGeom& G, int mode, int Tin, int V, int Cin, int Cout, int ntaps, int out_mul, int dtype) {
-  static const bool off = [] { const char* e = getenv("ISTGCN_TCONV_LEAN"); return e && atoi(e) == 0; }();
-  if (off || dtype == 0 || mode > 1 || out_mul != 1) return false;
-  if (G.NT != 2 || (G.MT != 2 && G.MT != 4) || G.CC != 32 || G.NKG != 2 || G.us_stride != US || G.out_stride != OS) return false;
-  if (ntaps % 3 != 0 || Cin % 32 != 0 || Cout % (G.MT * 32) != 0) return false;
-  if (G.nch < G.MT) return false;                           // NPARTS = MT parts of the image, one per item of the next tile
-  if ((long long)Tin * V * Cin * 2 >= (1ll << 30)) return false;
-  if (G.Fin * V > UL * 64 || lean_lds(G, Cin).lds > 160 * 1024) return false;
-  return true;
+}  // namespace
+
+// Which (mode, taps, window) combinations have an instantiation above.
+bool tconv_lean_serves(int mode, int ntaps, int ul) {
+  if (mode == 1) return (ntaps == 9 && ul == 8) || (ntaps == 15 && ul == 11) || ((ntaps == 5 || ntaps == 4) && ul == 8);
+  return (ntaps == 9 && (ul == 8 || ul == 11)) || (ntaps == 15 && ul == 11);
 }
 
 int tconv_lean_launch(const void* in, const void* Wp, const float* bias, const float* pre, int pre_relu, const void* aux,
                       const float* maux, void* out, double* stats, int stats_rep, int mode, int NM, int Tin, int Tout,
-                      int Mlog, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int out_off, int dtype,
-                      int grid_cap, const tconv_geo::TconvGeom& G, const BnTail& tail, hipStream_t stream) {
+                      int Mlog, int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int out_mul, int out_off,
+                      int dtype, int grid_cap, const tconv_geo::LeanGeom& G, const BnTail& tail, hipStream_t stream) {
+  if (!tconv_lean_serves(mode, ntaps, G.UL)) return ISTGCN_EINVAL;
+  if (ntaps >= 9 && out_mul != 1) return ISTGCN_EINVAL;      // (the phases of an 18- / 30-tap stride-2 convolution: nobody's layer)
+  if (mode == 1 && pre) return ISTGCN_EINVAL;                // (a data gradient's input is a gradient: no BatchNorm + ReLU in front)
+  if ((long long)Tin * V * Cin * 2 >= (1ll << 30)) return ISTGCN_EINVAL;        // (a sequence behind one 32-bit descriptor, far offsets above it)
   TlParams P{};
   P.in = in; P.Wp = Wp; P.bias = bias; P.pre = pre; P.aux = aux; P.maux = maux; P.out = out; P.stats = stats;
-  P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Mlog = Mlog; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
-  P.in_mul = in_mul; P.out_off = out_off; P.pre_relu = pre_relu; P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
-  for (int j = 0; j < ntaps; ++j) P.tap_off[j] = tap_off[j];
+  P.NM = NM; P.Tin = Tin; P.Tout = Tout; P.Mlog = Mlog; P.V = V; P.Cin = Cin; P.Cout = Cout;
+  P.in_mul = in_mul; P.out_mul = out_mul; P.out_off = out_off; P.pre_relu = pre_relu; P.stats_rep = stats_rep < 1 ? 1 : stats_rep;
+  P.tap0 = tap_off[0]; P.tapd = ntaps > 1 ? tap_off[1] - tap_off[0] : 0;
   P.F = G.F; P.nch = G.nch; P.MTtot = G.MTtot; P.min_off = G.min_off; P.Fin = G.Fin;
-  const LeanLds L = lean_lds(G, Cin);
-  P.off_stat = L.off_stat; P.off_u0 = L.off_u0; P.off_u1 = L.off_u1; P.off_o = L.off_o;
+  P.off_stat = G.off_stat; P.off_u0 = G.off_u0; P.off_u1 = G.off_u1; P.off_o = G.off_o;
   P.tiles_per_seq = ceil_div(Mlog, G.F);
   P.total_tiles = NM * P.tiles_per_seq;
   P.tps_magic = (unsigned)(((1ull << 32) + P.tiles_per_seq - 1) / (unsigned long long)P.tiles_per_seq);
+  P.v_magic = V == 1 ? 0u : (unsigned)(((1ull << 32) + V - 1) / (unsigned long long)V);   // x / V == umulhi(x, magic) for x * V < 2^32, V > 1
   P.tail = tail;
 #ifdef ISTGCN_TCONV_STAMP
   { const char* e_dbg = getenv("ISTGCN_TCONV_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
 #endif
-#ifndef TL_WM4
-#define TL_WM4 2            /* compute-wave layout of the 128-channel tiles: 2 (two channel groups x two row groups) or 4 */
-#endif
-#define CASE(TT, MTv, MD) if (G.MT == MTv && mode == MD) return launch_lean<TT, MTv, MD, (MTv == 4 ? TL_WM4 : 2)>(P, grid_cap, G.gy, (size_t)L.lds, stream)
-  if (dtype == 2) { CASE(_Float16, 2, 0); CASE(_Float16, 2, 1); CASE(_Float16, 4, 0); CASE(_Float16, 4, 1); }
-  else { CASE(__bf16, 2, 0); CASE(__bf16, 2, 1); CASE(__bf16, 4, 0); CASE(__bf16, 4, 1); }
-#undef CASE
-  return ISTGCN_EINVAL;
+  if (dtype == 2) return launch_lean_T<_Float16>(P, G, mode, ntaps, grid_cap, stream);
+  return launch_lean_T<__bf16>(P, G, mode, ntaps, grid_cap, stream);
 }

@@ -348,6 +348,7 @@ class STGCNModel(nn.Module):
         self._nnz_cap = None
         self._fold_consts = {}               # device -> [J,K,V,V] constants of the fused importance fold
         self._patterns = {}                  # device -> [K,V,V] fp32 union pattern of those constants
+        self._pack_plans = {}                # (dtype, device, V) -> weight-pack plan; the dict is shared with DataParallel replicas
         self.register_load_state_dict_post_hook(_buffers_reloaded)
 
     # the sparsity pattern bounds the kernels' in-LDS adjacency lists; recomputed if buffers are reloaded
@@ -429,12 +430,23 @@ class STGCNModel(nn.Module):
         when a parameter's storage moved (an optimizer re-pointing `.data` into its flat buffer, `.to()`), the launch is
         repeated every forward because the optimizer has updated the weights in between."""
         ptrs = tuple((p.data_ptr(), p.stride()) for p in self.parameters())
-        key = (x.dtype, x.device, x.shape[2], ptrs)
-        ent = self.__dict__.get('_pack_plan')
-        if ent is None or ent[0] != key:
+        # One plan per (storage type, device, joints), kept in a dict that nn.DataParallel's replicas SHARE with the
+        # module they were made from (a replica's __dict__ is a shallow copy: same dict object): a replica -- a fresh set of
+        # parameter tensors on every forward -- finds its device's plan, re-points the job sources and reuses the
+        # destinations, instead of building a plan (geometry queries, ~46 allocations) per forward and device.
+        plans = self.__dict__.get('_pack_plans')
+        if plans is None:
+            plans = self.__dict__['_pack_plans'] = {}
+        key = (x.dtype, x.device, x.shape[2])
+        ent = plans.get(key)
+        if ent is None:
             plan = ops.PackPlan(x.dtype, x.device)
-            ent = (key, plan, [blk.pack_jobs(plan, x.shape[2]) for blk in self.st_gcn_networks])
-            self.__dict__['_pack_plan'] = ent
+            ent = plans[key] = [ptrs, plan, [blk.pack_jobs(plan, x.shape[2]) for blk in self.st_gcn_networks]]
+        elif ent[0] != ptrs:
+            ent[1].begin_rebind()
+            ent[2] = [blk.pack_jobs(ent[1], x.shape[2]) for blk in self.st_gcn_networks]
+            ent[1].end_rebind()
+            ent[0] = ptrs
         ent[1].run()
         return ent[2]
 

@@ -1040,15 +1040,40 @@ class PackPlan:
         self.dtype, self.device = dtype, device
         self.jobs = []                 # (kind, src view, dst, extra)
         self._table = None
+        self._rebind = None            # position in `jobs` while the sources are being re-pointed (begin_rebind)
+
+    def begin_rebind(self):
+        """The parameters moved (an nn.DataParallel replica is a fresh set of tensors on every forward; an optimizer
+        re-pointed `.data`): replay the SAME sequence of add_* calls -- each replaces the source of the job registered at
+        that position and returns its existing destination (no allocation, geometry unchanged) -- then end_rebind()."""
+        self._rebind = 0
+
+    def end_rebind(self):
+        if self._rebind != len(self.jobs):
+            raise RuntimeError('PackPlan.end_rebind: %d of %d jobs re-pointed' % (self._rebind, len(self.jobs)))
+        self._rebind = None
+        self._table = None             # the job table holds raw source pointers: rebuilt (and uploaded) by the next run()
+
+    def _add(self, kind, src, extra, nelems):
+        if self._rebind is not None:
+            k0, s0, dst, e0 = self.jobs[self._rebind]
+            if k0 != kind or tuple(s0.shape) != tuple(src.shape) or e0 != extra:
+                raise RuntimeError('PackPlan rebind: job %d differs from the one registered first' % self._rebind)
+            self.jobs[self._rebind] = (kind, src, dst, extra)
+            self._rebind += 1
+            return dst
+        n = nelems()
+        if n < 0:
+            raise RuntimeError('istgcn pack geometry: invalid')
+        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
+        self.jobs.append((kind, src, dst, extra))
+        return dst
 
     def add_gcn(self, wr):
         """wr [Cout][K][Cin] fp32 view -> dst as ops.pack_gcn_weight"""
         _src_ok(wr)
         cout, K, cin = wr.shape
-        n = _lib.load().istgcn_pack_gcn_elems(cin, cout, K, _DT[self.dtype])
-        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
-        self.jobs.append((0, wr, dst, None))
-        return dst
+        return self._add(0, wr, None, lambda: _lib.load().istgcn_pack_gcn_elems(cin, cout, K, _DT[self.dtype]))
 
     def add_tconv(self, wf, V, tap_off, in_mul, tap_sel=None):
         """wf [taps][Cout][Cin] fp32 view -> dst as ops.pack_tconv_weight"""
@@ -1056,21 +1081,14 @@ class PackPlan:
         if tap_sel is None:
             tap_sel = list(range(wf.shape[0]))
         _, cout, cin = wf.shape
-        n = _lib.load().istgcn_pack_tconv_elems(V, cin, cout, len(tap_off), _int_array(tap_off), in_mul, _DT[self.dtype])
-        if n < 0:
-            raise RuntimeError('istgcn_pack_tconv_elems: invalid geometry')
-        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
-        self.jobs.append((1, wf, dst, (V, list(tap_off), in_mul, list(tap_sel))))
-        return dst
+        return self._add(1, wf, (V, list(tap_off), in_mul, list(tap_sel)),
+                         lambda: _lib.load().istgcn_pack_tconv_elems(V, cin, cout, len(tap_off), _int_array(tap_off), in_mul, _DT[self.dtype]))
 
     def add_gcn_wb(self, w3):
         """w3 [K][Cout][Cin] fp32 view -> dst as ops.pack_gcn_wb"""
         _src_ok(w3)
         K, cout, cin = w3.shape
-        n = _lib.load().istgcn_pack_gcn_bwd_elems(cin, cout, K, _DT[self.dtype])
-        dst = torch.empty(int(n), dtype=self.dtype, device=self.device)
-        self.jobs.append((2, w3, dst, None))
-        return dst
+        return self._add(2, w3, None, lambda: _lib.load().istgcn_pack_gcn_bwd_elems(cin, cout, K, _DT[self.dtype]))
 
     def _build(self):
         lib = _lib.load()

@@ -808,6 +808,74 @@ def test_dataparallel_wrapper_runs_the_hip_path(ops):
 
 
 @pytest.mark.gpu
+def test_two_replicas_from_two_threads_on_two_streams(ops):
+    """what nn.DataParallel does per device (processor/my_io.py:86-87: a device LIST) on the one GPU a test
+    box has -- two replicas of one model driven from two host threads on two streams: per-thread scratch and BatchNorm-tail
+    arming, a StepArena per replica, the weight-pack plan shared through the source module.  Each replica must give what
+    the bare model gives on its half of the batch (train mode: BatchNorm statistics per replica, as under DataParallel), and
+    ONE backward over both losses must give the sum of the two halves' gradients.  Also: a replica whose parameters are
+    fresh tensors (another device's copy) re-points the shared plan instead of building one."""
+    import threading
+    from torch.nn.parallel import replicate
+    from istgcn_amd.net import st_gcn_msgcn as prod
+    d = torch.device('cuda:0')
+    gargs = dict(layout='ntu-rgb+d', strategy='spatial_3')
+    torch.manual_seed(4)
+    m = prod.Model(3, 60, gargs, True, dropout=0).to(d).train()
+    m.load_state_dict(det_fill_(m.state_dict()))
+    x = torch.randn(4, 3, 24, 25, 2, generator=torch.Generator().manual_seed(5)).to(d)
+    y = torch.randint(0, 60, (4,), generator=torch.Generator().manual_seed(6)).to(d)
+    halves = [(x[:2], y[:2]), (x[2:], y[2:])]
+    ref_out, ref_grad = [], None
+    for xh, yh in halves:                                   # the bare model on each half
+        m.zero_grad()
+        o = m(xh)
+        F.cross_entropy(o, yh).backward()
+        gvec = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone()
+        ref_out.append(o.detach().clone())
+        ref_grad = gvec if ref_grad is None else ref_grad + gvec
+    m.zero_grad()
+    assert len(m._pack_plans) == 1
+    plan_before = next(iter(m._pack_plans.values()))[1]
+    reps = [replicate(m, [0])[0] for _ in halves]
+    streams = [torch.cuda.Stream(device=d) for _ in halves]
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.device(d), torch.cuda.stream(streams[i]):
+                streams[i].wait_stream(torch.cuda.default_stream(d))
+                outs[i] = reps[i](halves[i][0])
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for s_ in streams:
+        torch.cuda.current_stream(d).wait_stream(s_)
+    loss = sum(F.cross_entropy(outs[i], halves[i][1]) for i in range(2))
+    loss.backward()
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert rel_err(outs[i], ref_out[i]) < 1e-5
+    g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert rel_err(g1, ref_grad) < 2e-3
+    assert len(m._pack_plans) == 1 and next(iter(m._pack_plans.values()))[1] is plan_before     # the replicas used the source's plan
+    # a replica with its own parameter tensors (what another device's replica is): same plan object, sources re-pointed
+    rep = replicate(m, [0])[0]
+    for blk in rep.st_gcn_networks:
+        for name, p in list(blk.gcn.the_conv()._parameters.items()):
+            blk.gcn.the_conv()._parameters[name] = p.detach().clone().requires_grad_(True)
+    o = rep(halves[0][0])
+    assert rel_err(o, ref_out[0]) < 1e-5
+    assert len(m._pack_plans) == 1 and next(iter(m._pack_plans.values()))[1] is plan_before
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('shape', [(6, 2, 75, 25, 256), (4, 1, 13, 18, 64), (2, 2, 5, 25, 20), (3, 1, 2, 3, 7)])
 def test_pooling_matches_avg_pool_and_person_mean(ops, shape, dt):
