@@ -10,6 +10,8 @@ sub-modules -- it hands their tensors to the HIP kernels through `functional.STG
 
 There is no CPU path: tensors must be on an MI355X, otherwise RuntimeError.
 """
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -299,6 +301,9 @@ def _buffers_reloaded(module, incompatible_keys):
     module._patterns.clear()
 
 
+_PLAN_LOCK = threading.Lock()
+
+
 class STGCNModel(nn.Module):
     KIND = None
     BLOCK = None
@@ -438,17 +443,19 @@ class STGCNModel(nn.Module):
         if plans is None:
             plans = self.__dict__['_pack_plans'] = {}
         key = (x.dtype, x.device, x.shape[2])
-        ent = plans.get(key)
-        if ent is None:
-            plan = ops.PackPlan(x.dtype, x.device)
-            ent = plans[key] = [ptrs, plan, [blk.pack_jobs(plan, x.shape[2]) for blk in self.st_gcn_networks]]
-        elif ent[0] != ptrs:
-            ent[1].begin_rebind()
-            ent[2] = [blk.pack_jobs(ent[1], x.shape[2]) for blk in self.st_gcn_networks]
-            ent[1].end_rebind()
-            ent[0] = ptrs
-        ent[1].run()
-        return ent[2]
+        with _PLAN_LOCK:                                    # (replicas run in one host thread each)
+            ent = plans.get(key)
+            if ent is None:
+                plan = ops.PackPlan(x.dtype, x.device)
+                ent = plans[key] = [ptrs, plan, [blk.pack_jobs(plan, x.shape[2]) for blk in self.st_gcn_networks], threading.Lock()]
+        with ent[3]:                                        # two replicas on ONE device share a plan: re-point + launch as one step
+            if ent[0] != ptrs:
+                ent[1].begin_rebind()
+                ent[2] = [blk.pack_jobs(ent[1], x.shape[2]) for blk in self.st_gcn_networks]
+                ent[1].end_rebind()
+                ent[0] = ptrs
+            ent[1].run()
+            return ent[2]
 
     def _folded_bias(self, i, blk):
         """(A_eff, bterm) with the bias term resolved (for the inference plan)."""

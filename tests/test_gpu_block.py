@@ -826,14 +826,15 @@ def test_two_replicas_from_two_threads_on_two_streams(ops):
     x = torch.randn(4, 3, 24, 25, 2, generator=torch.Generator().manual_seed(5)).to(d)
     y = torch.randint(0, 60, (4,), generator=torch.Generator().manual_seed(6)).to(d)
     halves = [(x[:2], y[:2]), (x[2:], y[2:])]
-    ref_out, ref_grad = [], None
+    ref_out, ref_grad = [], {}
     for xh, yh in halves:                                   # the bare model on each half
         m.zero_grad()
         o = m(xh)
         F.cross_entropy(o, yh).backward()
-        gvec = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone()
+        for n_, p in m.named_parameters():
+            if p.grad is not None:
+                ref_grad[n_] = ref_grad[n_] + p.grad if n_ in ref_grad else p.grad.clone()
         ref_out.append(o.detach().clone())
-        ref_grad = gvec if ref_grad is None else ref_grad + gvec
     m.zero_grad()
     assert len(m._pack_plans) == 1
     plan_before = next(iter(m._pack_plans.values()))[1]
@@ -846,15 +847,16 @@ def test_two_replicas_from_two_threads_on_two_streams(ops):
             with torch.cuda.device(d), torch.cuda.stream(streams[i]):
                 streams[i].wait_stream(torch.cuda.default_stream(d))
                 outs[i] = reps[i](halves[i][0])
-        except Exception as e:      # noqa: BLE001
-            errs.append(e)
+        except Exception:           # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     for t in th:
         t.start()
     for t in th:
         t.join()
-    assert not errs, errs
+    assert not errs, '\n'.join(errs)
     for s_ in streams:
         torch.cuda.current_stream(d).wait_stream(s_)
     loss = sum(F.cross_entropy(outs[i], halves[i][1]) for i in range(2))
@@ -862,15 +864,18 @@ def test_two_replicas_from_two_threads_on_two_streams(ops):
     torch.cuda.synchronize()
     for i in range(2):
         assert rel_err(outs[i], ref_out[i]) < 1e-5
-    g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
-    assert rel_err(g1, ref_grad) < 2e-3
+    got = {n_: p.grad for n_, p in m.named_parameters() if p.grad is not None}
+    assert set(ref_grad) <= set(got)
+    scale = max(float(v.abs().max()) for v in ref_grad.values())
+    for n_, v in got.items():
+        if n_ in ref_grad:
+            assert float((v - ref_grad[n_]).abs().max()) < 2e-3 * max(1.0, scale), n_
+        else:       # the reference's dead parameters (gcn.branch.bn.*): Broadcast's backward hands them zeros instead of None
+            assert float(v.abs().max()) == 0.0, n_
     assert len(m._pack_plans) == 1 and next(iter(m._pack_plans.values()))[1] is plan_before     # the replicas used the source's plan
-    # a replica with its own parameter tensors (what another device's replica is): same plan object, sources re-pointed
-    rep = replicate(m, [0])[0]
-    for blk in rep.st_gcn_networks:
-        for name, p in list(blk.gcn.the_conv()._parameters.items()):
-            blk.gcn.the_conv()._parameters[name] = p.detach().clone().requires_grad_(True)
-    o = rep(halves[0][0])
+    # (a replica's parameters are fresh tensors on every forward -- Broadcast copies them even onto the source's own device --
+    #  so each of the forwards above re-pointed the shared plan; once more, alone)
+    o = replicate(m, [0])[0](halves[0][0])
     assert rel_err(o, ref_out[0]) < 1e-5
     assert len(m._pack_plans) == 1 and next(iter(m._pack_plans.values()))[1] is plan_before
 

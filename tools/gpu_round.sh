@@ -1,22 +1,35 @@
 #!/bin/bash
-# One gpurun call: GPU parity suite, then (unless the suite was killed by its timeout) the bench lines.
-# usage: tools/gpu_round.sh <tag> [extra]   (extra = "full": also f16 config-5 bench, 2-rank gloo rehearsal, inference bench)
-tag=$1; extra=$2
+# One gpurun call at a milestone: GPU parity suite, then (unless the suite was killed by its timeout) the bench lines of all
+# five BASELINE configurations and the rocprofv3 summaries named so that bench.py finds them.
+# usage: tools/gpu_round.sh <tag> [profile configs, e.g. "2 4 5"]
+tag=$1; prof=${2:-}
 mkdir -p gpurun_out
-timeout -k 10 840 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
+rm -f gpurun_out/err16_measured.txt
+timeout -k 10 900 python -m pytest tests -m gpu -q --maxfail=40 -p no:cacheprovider > gpurun_out/${tag}_tests.log 2>&1
 rc=$?
 echo "pytest rc=$rc" | tee -a gpurun_out/${tag}_tests.log
-tail -5 gpurun_out/${tag}_tests.log
+tail -4 gpurun_out/${tag}_tests.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "suite killed: no further GPU step"; exit $rc; fi
-timeout -k 10 240 python bench.py --steps 10 --warmup 3 --breakdown > gpurun_out/${tag}_bench_bf16.json 2> gpurun_out/${tag}_bench_bf16.err || exit 1
-tail -c 1500 gpurun_out/${tag}_bench_bf16.json; grep "ms/step" gpurun_out/${tag}_bench_bf16.err
-if [ "$extra" = "full" ]; then
-  timeout -k 10 300 python bench.py --model st_gcn_mstcn_1x1_deep --dtype f16 --batch 128 --steps 5 --warmup 2 --breakdown --no-cpu-baseline > gpurun_out/${tag}_bench_cfg5_f16.json 2> gpurun_out/${tag}_bench_cfg5_f16.err || exit 1
-  tail -c 1200 gpurun_out/${tag}_bench_cfg5_f16.json; grep "ms/step" gpurun_out/${tag}_bench_cfg5_f16.err
-  ISTGCN_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --batch 32 --no-cpu-baseline > gpurun_out/${tag}_bench_2rank_gloo.json 2> gpurun_out/${tag}_bench_2rank_gloo.err || { tail -20 gpurun_out/${tag}_bench_2rank_gloo.err; exit 1; }
-  tail -c 800 gpurun_out/${tag}_bench_2rank_gloo.json
-  timeout -k 10 200 python tools/infer_bench.py st_gcn_msgcn 64 bf16 > gpurun_out/${tag}_infer.json 2> gpurun_out/${tag}_infer.err || { tail -20 gpurun_out/${tag}_infer.err; exit 1; }
-  timeout -k 10 200 python tools/infer_bench.py st_gcnold 64 f32 >> gpurun_out/${tag}_infer.json 2>> gpurun_out/${tag}_infer.err
-  cat gpurun_out/${tag}_infer.json
-fi
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err || { tail -5 gpurun_out/${tag}_bench_default.err; exit 1; }
+cut -c1-330 gpurun_out/${tag}_bench_default.json
+for c in 1 3 4 5; do
+  timeout -k 10 300 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --breakdown > gpurun_out/${tag}_bench_cfg$c.json 2> gpurun_out/${tag}_bench_cfg$c.err || { tail -5 gpurun_out/${tag}_bench_cfg$c.err; exit 1; }
+  python3 -c "import json,sys; d=json.load(open('gpurun_out/${tag}_bench_cfg$c.json')); print('cfg$c', d['ms_per_step'], d['value'], d['roofline']['kernel'][:30], d['roofline']['frac'])"
+done
+for dt in bf16; do for c in 3 4; do
+  timeout -k 10 300 python bench.py --config $c --dtype $dt --steps 5 --warmup 2 --no-cpu-baseline --breakdown > gpurun_out/${tag}_bench_cfg${c}_$dt.json 2> gpurun_out/${tag}_bench_cfg${c}_$dt.err || exit 1
+  python3 -c "import json,sys; d=json.load(open('gpurun_out/${tag}_bench_cfg${c}_$dt.json')); print('cfg$c $dt', d['ms_per_step'], d['value'], d['roofline']['kernel'][:30], d['roofline']['frac'])"
+done; done
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --breakdown > /dev/null 2> gpurun_out/${tag}_breakdown_cfg2.txt; grep "ms/step" gpurun_out/${tag}_breakdown_cfg2.txt
+for c in $prof; do
+  case $c in
+    2) n=st_gcn_msgcn_bf16_b64; a="";;
+    3) n=st_gcn_mstcn_1x1_f32_b256; a="--config 3";;
+    4) n=st_gcn_multi3_fix_3A_mstcn_bf16_b64; a="--config 4 --dtype bf16";;
+    5) n=st_gcn_mstcn_1x1_deep_f16_b128; a="--config 5";;
+  esac
+  tools/profile_bench.sh r04_$n $a > gpurun_out/${tag}_prof_$c.log 2>&1 || { tail -5 gpurun_out/${tag}_prof_$c.log; exit 1; }
+  tail -3 gpurun_out/${tag}_prof_$c.log
+  rm -rf gpurun_out/prof_r04_$n
+done
 exit $rc
