@@ -728,6 +728,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #else
 #define TWG_LD_DZ(p) (*reinterpret_cast<const u32x4*>(p))
 #endif
+// packed-pair helpers of the memory role's BatchNorm + ReLU transform (see tconv_lean.hip)
+template <typename T> __device__ static inline void twg_unpack2(uint32_t p, float& lo, float& hi);
+template <> __device__ inline void twg_unpack2<__bf16>(uint32_t p, float& lo, float& hi) {
+  lo = __builtin_bit_cast(float, p << 16);
+  hi = __builtin_bit_cast(float, p & 0xffff0000u);
+}
+template <> __device__ inline void twg_unpack2<_Float16>(uint32_t p, float& lo, float& hi) {
+  const f16x2 v = __builtin_bit_cast(f16x2, p);
+  lo = (float)v[0];
+  hi = (float)v[1];
+}
+template <typename T> __device__ static inline uint32_t twg_pk2(float a, float b);
+template <> __device__ inline uint32_t twg_pk2<__bf16>(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <> __device__ inline uint32_t twg_pk2<_Float16>(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ static inline uint32_t twg_relu_pk(uint32_t w) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
+}
 constexpr int WS_NROLE = 256;
 constexpr int WS_NTH = 2 * WS_NROLE;
 constexpr int WS_UZ = 4;              // dz vectors per memory thread and tile: 128 rows x 8 vectors / 256
@@ -922,6 +949,9 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       asm volatile("v_mov_b32 %0, %1" : "=v"(sel_hi) : "s"(one << 16));
     }
     auto bias_add = [&](const frag_t& v) __attribute__((always_inline)) {
+#ifdef TWG_X_NOBIAS         /* experiment build: no conv-bias column sums (dbias wrong) */
+      return;
+#endif
 #pragma unroll
       for (int e = 0; e < EPL; e += 2) {
         if constexpr (std::is_same<T, __bf16>::value) {
@@ -936,16 +966,23 @@ __global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
       }
     };
     auto transform = [&](frag_t& v) __attribute__((always_inline)) {
-      // pairs of elements on the packed-math pipe (v_pk_fma_f32 / v_pk_max_f32): half the vector instructions
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      // per dword: unpack two elements (shift / and), two plain fma, ONE conversion of the pair, ReLU as v_pk_max_i16 on the
+      // packed result (a negative float is a negative int16) -- the form of tconv_lean.hip; packed fp32 math (v_pk_fma_f32)
+      // costs 22 cycles per instruction next to the MFMA waves (tools/valu_beside_mfma.hip)
+      u32x4 w = __builtin_bit_cast(u32x4, v);
+      uint32_t d4[4] = {w[0], w[1], w[2], w[3]};
 #pragma unroll
-      for (int e = 0; e < EPL; e += 2) {
-        f32x2 fv = {E::to_f(v[e]), E::to_f(v[e + 1])};
-        const f32x2 sc2 = {scv[e], scv[e + 1]}, sh2 = {shv[e], shv[e + 1]};
-        fv = fv * sc2 + sh2;
-        if (P.pre_relu) fv = __builtin_elementwise_max(fv, f32x2{0.f, 0.f});
-        v[e] = E::from_f(fv[0]); v[e + 1] = E::from_f(fv[1]);
+      for (int d = 0; d < 4; ++d) {
+        float lo, hi;
+        twg_unpack2<T>(d4[d], lo, hi);
+        lo = __builtin_fmaf(lo, scv[2 * d], shv[2 * d]);
+        hi = __builtin_fmaf(hi, scv[2 * d + 1], shv[2 * d + 1]);
+        uint32_t p = twg_pk2<T>(lo, hi);
+        if (P.pre_relu) p = twg_relu_pk(p);
+        d4[d] = p;
       }
+      const u32x4 o = {d4[0], d4[1], d4[2], d4[3]};
+      v = __builtin_bit_cast(frag_t, o);
     };
     // pipelined part: dz tile + the window's last adv frames.  UNCONDITIONAL loads with clamped addresses.
     auto issue = [&](int k, const TPos& c, int w, u32x4 (&RZ)[WS_UZ], u32x4 (&RS)[WS_US]) __attribute__((always_inline)) {
