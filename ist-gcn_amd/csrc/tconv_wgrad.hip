@@ -13,6 +13,7 @@
 // position axis straight from the row-major image); fp32 operand registers are double buffered so LDS latency
 // hides behind the MFMAs of the previous k-step.
 #include "common.hpp"
+#include "tconv_wgrad_lean.hpp"
 // Diagnostic hooks (ablation masks whose results are WRONG, in-kernel cycle stamps with their debug buffer) exist only in
 // experiment builds (-DISTGCN_EXPERIMENT through tools/build_variant.sh); the shipped library reads no such switch.
 #ifdef ISTGCN_EXPERIMENT
@@ -1823,6 +1824,12 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
         (mode == 2 || (in_mul == 2 && ntaps <= 10)))
       return istgcn_tconv_wgrad_rc(dz, g, pre, pre_relu, dW, dbias, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype,
                                    grid_cap, ws, ws_floats, stream);
+  }
+  // lean form of twg_ws (tconv_wgrad_lean.hip) when no conv-bias gradient is asked for (the training step: functional.py)
+  if (!dbias && twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz)) {
+    const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, dtype, grid_cap, ws,
+                                   ws_floats, (hipStream_t)stream);
+    if (rc >= 0) return rc;
   }
   TwgParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;

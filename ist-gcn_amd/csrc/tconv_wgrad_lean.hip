@@ -1,0 +1,451 @@
+// Weight gradient of the temporal convolution, trunk layers in 16-bit storage: the lean form (round 4) of twg_ws
+// (tconv_wgrad.hip) -- the autograd of the (k,1) Conv2d of net/st_gcnold.py:165-175 with BatchNorm + ReLU in front of it:
+//
+//   dW[j][o][i] += sum_{n,m,v} dz[n, m, v, o] * pre(g[n, m + tap_off[j], v, i])          (stride 1, zero padding)
+//
+// Same contraction layout as twg_ws: one 8-wave workgroup per CU owns a 64 x 64 (o x i) channel block for ALL taps and
+// walks consecutive 128-position tiles; four compute waves hold one (o-tile, i-tile) pair x JT tap accumulators each and
+// read both operands transposed (ds_read_b64_tr_b16) from row-major LDS sub-tiles; four memory waves stage the dz tile
+// (double-buffered) and the NEW frames of a halo window that slides through an LDS region (a FRESH window is staged whole at
+// the front when the region is used up or a sequence starts).  One raw s_barrier per tile.
+//
+// What changed is the memory role, by the rules tconv_lean.hip measured (profiles/r04_valu_beside_mfma.txt): next to an
+// MFMA wave a vector wave gets one plain instruction per 8-13 cycles, so its instruction count IS its time.
+//   * twg_ws: ~400 vector + 150 scalar instructions per tile and memory wave, in ~45-instruction basic blocks separated by
+//     per-vector predicates (row exists? row inside the sequence? channel vector inside the block?).
+//   * here: no per-vector predicate at all.  dz is loaded through a buffer descriptor that ENDS with the tile's last row
+//     (rows 125..127 of a 5-frame tile and everything behind a short last tile read as zeros without traffic); the window's
+//     frames through a descriptor of the sequence, with unsigned row offsets, so frames in front of / behind the sequence
+//     are zeros as well; every thread stores every vector it loaded (the LDS buffers have a slot for each).  Rows that are
+//     padding of the conv must be zeros AFTER BatchNorm + ReLU: tiles that touch a sequence edge take a masked copy of the
+//     transform (uniform branch, 2 tiles of 60).  The transform itself: shift / and, two fma, one packed conversion, ReLU
+//     as v_pk_max_i16 per dword; this file is compiled without the SLP vectoriser (packed fp32 math costs 22 cycles per
+//     instruction here).
+//   * no conv-bias column sums: the launcher takes this kernel only when the caller does not ask for dbias (the training
+//     step does not: a bias in front of a batch-statistics BatchNorm has sum_p dz = 0 identically, functional.py).
+//
+// Shapes: 16-bit storage, stride 1, C_in % 64 == 0, C_out % 64 == 0, 4..9 taps, V such that a 5-frame... see twg_lean_ok().
+//
+// hipcc-flags: -fno-slp-vectorize
+#include "common.hpp"
+#include "gcn_rc.hpp"     // rsrc_t / make_rsrc
+#include "tconv_wgrad_lean.hpp"
+#include <cstdlib>
+
+extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, float* d0, int n0, float* d1, int n1, void* stream);
+
+namespace {
+
+constexpr int TR = 128;              // positions (rows) of a tile
+constexpr int CB = 32;               // channels of an LDS sub-tile
+constexpr int RB = CB * 2;           // bytes of a sub-tile row
+constexpr int NROLE = 256, NTH = 2 * NROLE;
+constexpr int UZ = 4;                // dz vectors per memory thread and tile: 128 rows x 8 vectors / 256
+constexpr int US = 4;                // vectors of a window's new frames: F * V <= 128 rows
+constexpr int UX = 7;                // vectors of the first Fin - F frames of a fresh window: <= 224 rows
+constexpr int SWEEP = NROLE / 8;     // rows one sweep of the 256 threads covers (8 vectors per 64-channel row)
+
+struct TwlParams {
+  const void* dz;        // [NM][Tz][V][Cout]
+  const void* g;         // [NM][Tin][V][Cin]
+  const float* pre;      // [2][Cin] scale, shift or null (identity)
+  float* dW;             // [ntaps][Cout][Cin] fp32, caller-zeroed
+  float* ws;             // partial-sum workspace (one slice per blockIdx.x) or null: flush with atomics
+  long long ws_slice;
+  int NM, Tin, Tz, V, Cin, Cout, ntaps, pre_relu;
+  int tap_off[16];
+  int F, Fin, min_off, tiles_per_seq, total_tiles, n_iblk;
+  int urows, capf;       // rows of a u sub-tile region; frames the halo window can slide through
+  int off_dz, off_dz1, off_u;
+  unsigned long long* dbg;   // experiment builds (-DISTGCN_TWG_STAMP): cycle stamps of workgroup 0
+};
+
+#ifdef ISTGCN_TWG_STAMP
+#define WSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
+#else
+#define WSTAMP(i)
+#endif
+
+__device__ static inline void lds_barrier() {
+  // LDS traffic of this wave retired, then the workgroup barrier; NOT __syncthreads() (its fence drains the prefetches)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename T> __device__ static inline void unpk2(uint32_t p, float& lo, float& hi);
+template <> __device__ inline void unpk2<__bf16>(uint32_t p, float& lo, float& hi) {
+  lo = __builtin_bit_cast(float, p << 16);
+  hi = __builtin_bit_cast(float, p & 0xffff0000u);
+}
+template <> __device__ inline void unpk2<_Float16>(uint32_t p, float& lo, float& hi) {
+  const f16x2 v = __builtin_bit_cast(f16x2, p);
+  lo = (float)v[0];
+  hi = (float)v[1];
+}
+template <typename T> __device__ static inline uint32_t pk2(float a, float b);
+template <> __device__ inline uint32_t pk2<__bf16>(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+template <> __device__ inline uint32_t pk2<_Float16>(float a, float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// max on two packed int16: with floor 0 it is ReLU on two packed 16-bit floats of either format (a negative float is a
+// negative int16), with floor -32768 it is the identity
+__device__ static inline uint32_t max_pk(uint32_t w, uint32_t floor2) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), __builtin_bit_cast(s16x2, floor2)));
+}
+
+struct TPos { int n, mq; };
+
+template <typename T, int JT>
+__global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
+  using E = Elem<T>;
+  typedef typename E::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_compute = wave8 < 4;
+  const int ltid = tid & (NROLE - 1);
+  const int V = P.V;
+  const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
+  const int o0 = oblk * 64, i0 = iblk * 64;
+  const int dz_sub = TR * RB, u_sub = P.urows * RB;        // bytes per 32-channel sub-tile
+
+  {
+    // both dz halves and the whole u region start as zeros: everything the contraction can reach is finite from the first
+    // tile on (pad positions behind a tile's frames meet zero dz rows and whatever finite u rows lie there)
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const int n0 = 2 * 2 * dz_sub / 16, n1 = 2 * u_sub / 16;
+    for (int i = tid; i < n0; i += NTH) *reinterpret_cast<u32x4*>(smem + P.off_dz + i * 16) = z;
+    for (int i = tid; i < n1; i += NTH) *reinterpret_cast<u32x4*>(smem + P.off_u + i * 16) = z;
+  }
+  __syncthreads();
+
+  const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
+  const int ntile = t_end > t_begin ? t_end - t_begin : 0;
+  const int adv = P.F, keep = P.Fin - adv;                 // frames a window advances by / shares with its predecessor
+  // window schedule, computed identically by both roles: tile k is FRESH (window at frame 0 of the region, staged whole) at
+  // the start of the walk, at a sequence start, or when sliding on would leave the region; otherwise its window is adv
+  // frames further on.  Tiles of a workgroup are consecutive: (sequence, tile in sequence) advance by increments.
+  auto tpos_first = [&]() __attribute__((always_inline)) { TPos c; c.n = t_begin / P.tiles_per_seq; c.mq = t_begin - c.n * P.tiles_per_seq; return c; };
+  auto tpos_next = [&](TPos c) __attribute__((always_inline)) { if (++c.mq == P.tiles_per_seq) { c.mq = 0; ++c.n; } return c; };
+  auto next_window = [&](int k, const TPos& c, int w_prev, bool& fresh) __attribute__((always_inline)) {
+    fresh = k == 0 || c.mq == 0 || w_prev + adv + P.Fin > P.capf;
+    return fresh ? 0 : w_prev + adv;
+  };
+
+  f32x16 acc[JT];
+#ifdef ISTGCN_TWG_STAMP
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
+#endif
+  if (is_compute) {
+    // =========================================== compute waves ===========================================
+    const int ot = wave8 & 1, it = wave8 >> 1;
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    int toff[JT];                                           // byte offset of a tap's rows in a u sub-tile
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int jv = j < P.ntaps ? j : 0;                   // padding taps alias tap 0 (computed, never flushed)
+      toff[j] = (P.tap_off[jv] - P.min_off) * V * RB;
+    }
+    const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int coff = (cblk + 4 * pp) * 2;                   // bytes
+    const int lrow = 8 * h + q;                             // this lane addresses rows 16*ks + lrow and + 4 of every k-step
+    lds_barrier();                                          // tile 0 staged (the memory waves' prologue)
+#ifdef ISTGCN_TWG_STAMP
+    tlast = __builtin_amdgcn_s_memtime();
+#endif
+    int w = 0;
+    bool fresh = true;
+    TPos cpos = tpos_first();
+    for (int k = 0; k < ntile; ++k) {
+      w = next_window(k, cpos, w, fresh);
+      cpos = tpos_next(cpos);
+      // byte offsets in LDS, never pointers selected at run time (those decay to flat loads)
+      const int dzb = ((k & 1) ? P.off_dz1 : P.off_dz) + ot * dz_sub + coff;
+      const int ub = P.off_u + it * u_sub + coff + w * V * RB;
+      constexpr int NK = TR / 16;
+      const unsigned char* ap = smem + dzb + lrow * RB;
+      const unsigned char* up[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) up[j] = smem + ub + lrow * RB + toff[j];
+      frag_t a0, a1, b0[JT], b1[JT];
+      auto load_k = [&](int ks, frag_t& a, frag_t (&b)[JT]) __attribute__((always_inline)) {
+        a = tr_pair<T>(reinterpret_cast<const T*>(ap + ks * 16 * RB), reinterpret_cast<const T*>(ap + ks * 16 * RB + 4 * RB));
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+          b[j] = tr_pair<T>(reinterpret_cast<const T*>(up[j] + ks * 16 * RB), reinterpret_cast<const T*>(up[j] + ks * 16 * RB + 4 * RB));
+      };
+      auto mma_k = [&](const frag_t& a, const frag_t (&b)[JT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j) mma_kgroup(acc[j], a, b[j]);
+      };
+      load_k(0, a0, b0);
+#pragma unroll
+      for (int ks = 0; ks < NK; ks += 2) {
+        load_k(ks + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < NK) load_k(ks + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      WSTAMP(0)
+      lds_barrier();                                        // tile k contracted, tile k+1 staged (unless it is a late fresh one)
+      if (k + 1 < ntile) {
+        bool f1;
+        next_window(k + 1, cpos, w, f1);                    // (cpos is tile k+1 by now)
+        if (f1 && w < P.Fin) lds_barrier();                 // fresh tile whose front window overlaps window k: staged now
+      }
+      WSTAMP(1)
+    }
+#ifdef ISTGCN_TWG_STAMP
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[0] = tacc[0]; P.dbg[1] = tacc[1]; P.dbg[7] = (unsigned long long)ntile; }
+#endif
+  } else {
+    // =========================================== memory waves ============================================
+    const int q = ltid & 7;                                 // this thread's channel vector of a 64-channel row (both tensors)
+    const int sub = q >> 2, ql = q & 3;
+    int r0 = ltid >> 3;                                     // row of slot 0; slot u is row r0 + 32 u
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = P.pre ? P.pre[i0 + q * 8 + e] : 1.f;
+      sh[e] = P.pre ? P.pre[P.Cin + i0 + q * 8 + e] : 0.f;
+    }
+    const uint32_t floor2 = P.pre_relu ? 0u : 0x80008000u;
+    const T* dzg = reinterpret_cast<const T*>(P.dz);
+    const T* gg = reinterpret_cast<const T*>(P.g);
+    const unsigned zrow = (unsigned)(P.Cout * 2), urow = (unsigned)(P.Cin * 2);          // bytes per tensor row
+    const unsigned zvo0 = (unsigned)r0 * zrow + (unsigned)(q * 16);                     // slot 0 inside the tile / the slab
+    const unsigned uvo0 = (unsigned)r0 * urow + (unsigned)(q * 16);
+    const unsigned zstep = SWEEP * zrow, ustep = SWEEP * urow;
+    const unsigned seq_z = (unsigned)(P.Tz * V) * zrow, seq_u = (unsigned)(P.Tin * V) * urow;   // bytes per sequence
+    const unsigned useq_rec = (unsigned)(P.Tin * V - 1) * urow + 128u;                  // the i-block's last byte in a sequence
+    // LDS: vector q of row r of a sub-tile at sub-tile + r * 64 + (q & 3) * 16
+    const unsigned zl0 = (unsigned)(sub * dz_sub + r0 * RB + ql * 16);
+    const unsigned ul0 = (unsigned)(P.off_u + sub * u_sub + r0 * RB + ql * 16);
+    const int Tv = P.Tin * V;
+
+    // ---- issue: dz tile + the window's last adv frames of tile k -> registers.  No predicates: the descriptors end where
+    //      the data ends (invalid tile: zero records). ----
+    auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RS)[US]) __attribute__((always_inline)) {
+      const bool valid = k < ntile;
+      const int n = valid ? c.n : 0, m0 = (valid ? c.mq : 0) * P.F;
+      const int nf = min(P.F, P.Tz - m0);
+      const rsrc_t rz = make_rsrc(reinterpret_cast<const unsigned char*>(dzg) + (size_t)n * seq_z + o0 * 2,
+                                  valid ? (unsigned)((m0 + nf) * V - 1) * zrow + 128u : 0u);
+      const rsrc_t ru = make_rsrc(reinterpret_cast<const unsigned char*>(gg) + (size_t)n * seq_u + i0 * 2, valid ? useq_rec : 0u);
+      unsigned zo = zvo0 + (unsigned)(m0 * V) * zrow;
+      unsigned uo = uvo0 + (unsigned)((m0 + P.min_off + keep) * V) * urow;              // (>= 0: the launcher checks keep >= -min_off)
+#pragma unroll
+      for (int u = 0; u < UZ; ++u) { RZ[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 0, 0)); zo += zstep; }
+#pragma unroll
+      for (int u = 0; u < US; ++u) { RS[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uo, 0, 0)); uo += ustep; }
+    };
+    // BatchNorm affine + ReLU of one vector; EDGE: rows outside the sequence (conv padding) are zeros AFTER it
+    auto transform = [&](u32x4 v, bool inside, auto edge) __attribute__((always_inline)) {
+      uint32_t d4[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float lo, hi;
+        unpk2<T>(d4[d], lo, hi);
+        lo = __builtin_fmaf(lo, sc[2 * d], sh[2 * d]);
+        hi = __builtin_fmaf(hi, sc[2 * d + 1], sh[2 * d + 1]);
+        uint32_t p = max_pk(pk2<T>(lo, hi), floor2);
+        if constexpr (decltype(edge)::value) p = inside ? p : 0u;
+        d4[d] = p;
+      }
+      const u32x4 o = {d4[0], d4[1], d4[2], d4[3]};
+      return o;
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    // ---- commit: registers of tile k -> LDS (dz half k & 1; the new frames behind the window's kept ones); a FRESH window's
+    //      first keep frames are loaded and staged here as well (once per region pass: the pipeline drains) ----
+    auto commit = [&](int k, const TPos& c, int w, bool fresh, u32x4 (&RZ)[UZ], u32x4 (&RS)[US]) __attribute__((always_inline)) {
+      asm volatile("" : "+v"(r0));          // (opaque per tile: or every slot's row test / address is kept in its own register)
+      unsigned char* dzs = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + zl0;
+#pragma unroll
+      for (int u = 0; u < UZ; ++u) *reinterpret_cast<u32x4*>(dzs + u * (SWEEP * RB)) = RZ[u];
+      const int m0 = c.mq * P.F;
+      const int fin0 = m0 + P.min_off;                      // first input frame of the window (stride 1); may be < 0
+      const int row_s = (fin0 + keep) * V;                  // sequence row of the slab's first row (>= 0)
+      unsigned char* us = smem + ul0 + (unsigned)((w + keep) * V * RB);
+      if (row_s + TR <= Tv) {
+#pragma unroll
+        for (int u = 0; u < US; ++u) *reinterpret_cast<u32x4*>(us + u * (SWEEP * RB)) = transform(RS[u], true, no{});
+      } else {
+#pragma unroll
+        for (int u = 0; u < US; ++u) *reinterpret_cast<u32x4*>(us + u * (SWEEP * RB)) = transform(RS[u], row_s + r0 + u * SWEEP < Tv, yes{});
+      }
+      if (fresh) {
+        const rsrc_t ru = make_rsrc(reinterpret_cast<const unsigned char*>(gg) + (size_t)c.n * seq_u + i0 * 2, useq_rec);
+        const int row_x = fin0 * V;                         // sequence row of the window's first row; negative at a sequence start
+        unsigned uo = uvo0 + (unsigned)row_x * urow;        // (unsigned: rows in front of the sequence are far out of range)
+        u32x4 RX[UX];
+#pragma unroll
+        for (int u = 0; u < UX; ++u) { RX[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uo, 0, 0)); uo += ustep; }
+        unsigned char* ux = smem + ul0 + (unsigned)(w * V * RB);
+        // (rows keep*V .. 223 of these slots are the slab's first rows once more: the same values to the same places)
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+          const int rs = row_x + r0 + u * SWEEP;
+          *reinterpret_cast<u32x4*>(ux + u * (SWEEP * RB)) = transform(RX[u], rs >= 0 && rs < Tv, yes{});
+        }
+      }
+    };
+    // tiles in flight: k (being contracted), k+1 (being committed), k+2 (being issued)
+    u32x4 ZA[UZ], SA[US], ZB[UZ], SB[US];
+    int w1 = 0, w2 = 0;
+    bool f1 = true, f2 = true;
+    const TPos c0 = tpos_first();
+    TPos c1 = tpos_next(c0), c2 = c1;                       // positions of tiles k+1 and k+2
+    issue(0, c0, ZA, SA);
+    w1 = next_window(1, c1, 0, f1);
+    issue(1, c1, ZB, SB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ntile > 0) commit(0, c0, 0, true, ZA, SA);
+    lds_barrier();                                          // tile 0 staged
+#ifdef ISTGCN_TWG_STAMP
+    tlast = __builtin_amdgcn_s_memtime();
+#endif
+    int w_k = 0;                                            // window of the tile the compute waves are on
+    auto iteration = [&](int k, u32x4 (&Zn)[UZ], u32x4 (&Sn)[US], u32x4 (&Zf)[UZ], u32x4 (&Sf)[US]) __attribute__((always_inline)) {
+      // (Zn, Sn): tile k+1, loaded;  (Zf, Sf): free -> tile k+2
+      c2 = tpos_next(c1);
+      w2 = next_window(k + 2, c2, w1, f2);
+      issue(k + 2, c2, Zf, Sf);                             // (past the last tile: zero-record descriptors, same number of loads)
+      __builtin_amdgcn_sched_barrier(0);
+      WSTAMP(1)
+      const bool have = k + 1 < ntile;
+      const bool late = have && f1 && w_k < P.Fin;         // fresh window at the front would overlap window k: after the barrier
+      if (have && !late) commit(k + 1, c1, w1, f1, Zn, Sn);
+      WSTAMP(0)
+      lds_barrier();                                        // tile k contracted
+      if (late) {
+        commit(k + 1, c1, w1, f1, Zn, Sn);
+        lds_barrier();
+      }
+      w_k = w1; w1 = w2; f1 = f2; c1 = c2;
+      WSTAMP(2)
+    };
+    for (int k = 0; k < ntile; k += 2) {
+      iteration(k, ZB, SB, ZA, SA);
+      if (k + 1 < ntile) iteration(k + 1, ZA, SA, ZB, SB);
+    }
+#ifdef ISTGCN_TWG_STAMP
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) { P.dbg[8] = tacc[0]; P.dbg[9] = tacc[1]; P.dbg[10] = tacc[2]; }
+#endif
+  }
+  __syncthreads();
+
+  // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per instruction.  Every element of a
+  //      workspace slice is written by exactly one workgroup of that blockIdx.x (workgroups without tiles write zeros). ----
+  if (is_compute) {
+    const int ot = wave8 & 1, it = wave8 >> 1;
+    float* dst = P.ws ? P.ws + (size_t)blockIdx.x * P.ws_slice : P.dW;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      if (j < P.ntaps) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
+          float* p = dst + ((size_t)j * P.Cout + o) * P.Cin + i;
+          if (P.ws) *p = acc[j][r];
+          else atomicAdd(p, acc[j][r]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int JT>
+int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
+  P.n_iblk = P.Cin / 64;
+  const int n_oblk = P.Cout / 64;
+  size_t base = 0;
+  const size_t dzb = (size_t)2 * TR * RB;
+  P.off_dz = (int)base; base += dzb;
+  P.off_dz1 = (int)base; base += dzb;
+  P.off_u = (int)base;
+  // region: as many slides as fit, at least until an overflow re-stage can run beside the window it replaces (n*F >= Fin)
+  const int span_rows = (P.Fin - P.F) * P.V;                // tap span in rows; pad positions of a tile read TR + span rows
+  int n_adv = 0;
+  for (int n = 8; n >= 1; --n) {
+    const size_t rows = (size_t)(n * P.F) * P.V + TR + span_rows;
+    if (base + 2 * rows * RB <= 158 * 1024) { n_adv = n; break; }
+  }
+  if (n_adv * P.F < P.Fin) return -1;
+  P.capf = P.Fin + n_adv * P.F;
+  P.urows = n_adv * P.F * P.V + TR + span_rows;
+  // a fresh window's first Fin - F frames go through UX slots whose last rows spill into the slab: inside the region
+  if ((P.Fin - P.F) * P.V > UX * SWEEP || UX * SWEEP > P.urows) return -1;
+  const size_t lds = base + (size_t)2 * P.urows * RB;
+  const int blocks = n_oblk * P.n_iblk;
+  auto kfn = twg_lean_kernel<T, JT>;
+  static std::atomic<unsigned long long> optin{0};
+  if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
+  if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, NTH, lds);
+  int gx = grid_cap / blocks;
+  if (gx < 1) gx = 1;
+  if (gx > P.total_tiles) gx = P.total_tiles;
+  const int n0 = P.ntaps * P.Cout * P.Cin;
+  if (P.ws && ((long long)gx * n0 > P.ws_slice || gx < 128)) P.ws = nullptr;   // too small / atomics are as fast
+  P.ws_slice = n0;
+#ifdef ISTGCN_TWG_STAMP
+  { const char* e_dbg = getenv("ISTGCN_TWG_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
+#endif
+  ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(NTH), lds, stream, P);
+  ISTGCN_CHECK_LAUNCH();
+  if (P.ws) return istgcn_wgrad_reduce(P.ws, P.ws_slice, gx, P.dW, n0, nullptr, 0, stream);
+  return ISTGCN_OK;
+}
+
+}  // namespace
+
+bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz) {
+  static const bool off = [] { const char* e = getenv("ISTGCN_TWG_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
+  if (off || dtype == 0 || in_mul != 1 || ntaps < 4 || ntaps > 9) return false;
+  if (Cin % 64 || Cout % 64 || V < 2 || V > TR) return false;
+  int mn = tap_off[0], mx = tap_off[0];
+  for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
+  const int F = TR / V, Fin = F - 1 + (mx - mn) + 1, keep = Fin - F;
+  if (F < 1 || Fin <= F || keep + mn < 0) return false;      // the new frames of a slide start inside the sequence
+  if (F * V > US * SWEEP || keep * V > UX * SWEEP) return false;
+  // byte offsets inside a sequence are 32-bit, "in front of the sequence" must stay out of range after wrapping
+  if ((long long)Tin * V * Cin * 2 >= (1ll << 30) || (long long)Tz * V * Cout * 2 >= (1ll << 30)) return false;
+  return true;
+}
+
+int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
+                    int Cin, int Cout, int ntaps, const int* tap_off, int dtype, int grid_cap, float* ws, long long ws_floats,
+                    hipStream_t stream) {
+  TwlParams P{};
+  P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.pre_relu = pre ? pre_relu : 0;
+  P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
+  P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;
+  int mn = tap_off[0], mx = tap_off[0];
+  for (int j = 0; j < 16; ++j) {
+    P.tap_off[j] = tap_off[j < ntaps ? j : 0];
+    mn = P.tap_off[j] < mn ? P.tap_off[j] : mn; mx = P.tap_off[j] > mx ? P.tap_off[j] : mx;
+  }
+  P.min_off = mn;
+  P.F = TR / V;
+  P.Fin = P.F - 1 + (mx - mn) + 1;
+  P.tiles_per_seq = ceil_div(Tz, P.F);
+  P.total_tiles = NM * P.tiles_per_seq;
+  if (ntaps <= 5) return dtype == 2 ? launch_twl<_Float16, 5>(P, grid_cap, stream) : launch_twl<__bf16, 5>(P, grid_cap, stream);
+  return dtype == 2 ? launch_twl<_Float16, 9>(P, grid_cap, stream) : launch_twl<__bf16, 9>(P, grid_cap, stream);
+}

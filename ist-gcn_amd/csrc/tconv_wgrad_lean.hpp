@@ -1,0 +1,10 @@
+// Entry of the lean temporal-conv weight gradient (tconv_wgrad_lean.hip) for the dispatcher in tconv_wgrad.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// shapes the kernel serves (16-bit storage, stride 1, 64-channel blocks, 4..9 taps, no conv-bias gradient asked for)
+bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz);
+// returns an ISTGCN_* code, or -1 when the LDS plan does not fit (the caller falls back to twg_ws)
+int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
+                    int Cin, int Cout, int ntaps, const int* tap_off, int dtype, int grid_cap, float* ws, long long ws_floats,
+                    hipStream_t stream);

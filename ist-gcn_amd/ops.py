@@ -481,7 +481,8 @@ def tconv_wgrad(dz, g, tap_off, in_mul=1, pre=None, pre_relu=False, want_bias=Tr
         dW = torch.zeros((len(tap_off), Cout, Cin), dtype=torch.float32, device=dz.device)
         db = torch.zeros((Cout,), dtype=torch.float32, device=dz.device) if want_bias else None
     dv = _check_dev(dz, g, pre, dW, db)
-    _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db), NM, Tin, Tz,
+    # want_bias=False with a caller-provided buffer: the column sums are skipped, `db` stays as the caller zero-filled it
+    _call('istgcn_tconv_wgrad', _ptr(dz), _ptr(g), _ptr(pre), int(bool(pre_relu)), _ptr(dW), _ptr(db if want_bias else None), NM, Tin, Tz,
           V, Cin, Cout, len(tap_off), _int_array(tap_off), in_mul, dtype_code(dz), _gcap('istgcn_tconv_wgrad', grid_cap),
           _ptr(_wgrad_ws(dz.device)), ctypes.c_longlong(WGRAD_WS_FLOATS), _stream(dz),
           work=(2.0 * NM * Tz * V * Cout * Cin * len(tap_off), float(NM * V) * (Tz * Cout + Tin * Cin) * _esz(dz)), dev=dv)

@@ -136,6 +136,47 @@ def test_tconv_weight_gradient(ops, case, dt):
     assert diag(name + '_db', db, bp.grad, tol) < tol
 
 
+# the lean weight-gradient kernel (tconv_wgrad_lean.hip; taken when no bias gradient is asked for): NM, Cin, Cout, T, V, k and
+# the grid cap (0 = resident size; a small one gives each workgroup a long walk: sliding windows, a region pass ending in
+# a fresh window, sequence starts in the middle of a walk, the "late" fresh window right after a sequence start)
+LEAN_WG_CASES = [
+    ((2, 64, 64, 23, 25, 9), 0), ((1, 64, 64, 300, 25, 9), 2), ((3, 128, 64, 41, 25, 9), 4), ((5, 64, 128, 7, 25, 9), 2),
+    ((2, 256, 256, 12, 18, 9), 0), ((2, 256, 256, 40, 18, 9), 16), ((2, 64, 128, 37, 25, 5), 2), ((1, 64, 64, 50, 20, 7), 1),
+    ((2, 64, 64, 3, 25, 9), 0), ((4, 64, 64, 5, 25, 9), 1), ((1, 128, 128, 151, 25, 9), 4),
+]
+
+
+@pytest.mark.parametrize('with_pre', [True, False])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case,cap', LEAN_WG_CASES)
+def test_tconv_weight_gradient_without_bias(ops, case, cap, dt, with_pre):
+    """dW alone (the training step's call: the bias feeds a batch-statistics BatchNorm) against autograd of
+    relu(bn(x)) -> conv2d, at shapes the lean kernel serves; the bias buffer handed in must come back untouched."""
+    NM, cin, cout, T, V, k = case
+    x, W, b, sc, sh = _mk(case + (1,), dt, seed=3)
+    g = torch.Generator().manual_seed(79)
+    u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if with_pre else x
+    if dt != torch.float32:
+        u = u.to(dt).float()
+    Wp = W.clone().requires_grad_(True)
+    z = F.conv2d(u, Wp, None, padding=((k - 1) // 2, 0))
+    dz = torch.randn(z.shape, generator=g)
+    dz = dz.to(dt).float()
+    z.backward(dz)
+    d = dev()
+    taps, in_mul = ops.conv_taps_fwd(k, 1)
+    blocks = (cin // 64) * (cout // 64)
+    out = (torch.zeros(k, cout, cin, device=d), torch.full((cout,), 7.0, device=d))
+    dW, db = ops.tconv_wgrad(to_ntvc(dz).to(d, dt), to_ntvc(x).to(d, dt), taps, in_mul=in_mul,
+                             pre=torch.stack([sc, sh]).to(d) if with_pre else None, pre_relu=with_pre, want_bias=False,
+                             grid_cap=cap * blocks, out=out)
+    torch.cuda.synchronize()
+    ref = Wp.grad[:, :, :, 0].permute(2, 0, 1)
+    name = 'tconv_wgrad_nobias_%s_cap%d_%s_%s' % ('x'.join(map(str, case)), cap, str(dt)[6:], 'pre' if with_pre else 'raw')
+    assert diag(name, dW, ref, 5e-3) < 5e-3
+    assert bool((db == 7.0).all())
+
+
 @pytest.mark.parametrize('k,s', [(1, 2), (3, 4), (1, 1)])
 def test_conv_data_gradient_with_empty_phases(ops, k, s):
     """k < stride: some output phases of the data gradient receive no tap.  Those frames must be zero and the OTHER

@@ -50,7 +50,7 @@ def test_shipped_library_has_no_experiment_hooks_and_knows_its_sources(lib):
     bad = [n for n in names if n.endswith('_ABL') or '_DBG' in n or n in ('ISTGCN_RC_NCT', 'ISTGCN_GWG_OT', 'ISTGCN_RC_SPLIT', 'ISTGCN_DEBUG')]
     assert not bad, bad
     assert names <= {'ISTGCN_GCN_RC', 'ISTGCN_GCN_V1', 'ISTGCN_GCNBWD_WS', 'ISTGCN_WGRAD_WS', 'ISTGCN_TWG_RC', 'ISTGCN_TCONV_SK',
-                     'ISTGCN_TCONV_V1', 'ISTGCN_TCONV_LEAN'}, names
+                     'ISTGCN_TCONV_V1', 'ISTGCN_TCONV_LEAN', 'ISTGCN_TWG_LEAN'}, names
     assert _lib.build_id() == _lib.csrc_hash() and len(_lib.csrc_hash()) == 16
 
 
