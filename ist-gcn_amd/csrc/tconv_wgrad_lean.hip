@@ -24,7 +24,9 @@
 //   * no conv-bias column sums: the launcher takes this kernel only when the caller does not ask for dbias (the training
 //     step does not: a bias in front of a batch-statistics BatchNorm has sum_p dz = 0 identically, functional.py).
 //
-// Shapes: 16-bit storage, stride 1, C_in % 64 == 0, C_out % 64 == 0, 4..9 taps, V such that a 5-frame... see twg_lean_ok().
+// Shapes: 16-bit storage, stride 1, C_in % 64 == 0, C_out % 64 == 0, 4..9 taps per launch (10..15 taps -- the 15-tap fold of
+// the Inception-TCN -- as two launches over the first 8 and the remaining taps), the first Fin - F frames of a window within
+// 224 rows: twg_lean_ok().  Everything else: tconv_wgrad.hip.
 //
 // hipcc-flags: -fno-slp-vectorize
 #include "common.hpp"
@@ -167,47 +169,68 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     int w = 0;
     bool fresh = true;
     TPos cpos = tpos_first();
-    for (int k = 0; k < ntile; ++k) {
+    constexpr int NK = TR / 16;
+    // LDS byte offsets of this lane's first rows in the dz half and at every tap of the window (never pointers selected at
+    // run time: those decay to flat loads)
+    unsigned ap = 0, up[JT];
+    auto setup = [&](int k) __attribute__((always_inline)) {
       w = next_window(k, cpos, w, fresh);
       cpos = tpos_next(cpos);
-      // byte offsets in LDS, never pointers selected at run time (those decay to flat loads)
-      const int dzb = ((k & 1) ? P.off_dz1 : P.off_dz) + ot * dz_sub + coff;
-      const int ub = P.off_u + it * u_sub + coff + w * V * RB;
-      constexpr int NK = TR / 16;
-      const unsigned char* ap = smem + dzb + lrow * RB;
-      const unsigned char* up[JT];
+      ap = (unsigned)(((k & 1) ? P.off_dz1 : P.off_dz) + ot * dz_sub + coff + lrow * RB);
+      const unsigned ub = (unsigned)(P.off_u + it * u_sub + coff + w * V * RB + lrow * RB);
 #pragma unroll
-      for (int j = 0; j < JT; ++j) up[j] = smem + ub + lrow * RB + toff[j];
-      frag_t a0, a1, b0[JT], b1[JT];
-      auto load_k = [&](int ks, frag_t& a, frag_t (&b)[JT]) __attribute__((always_inline)) {
-        a = tr_pair<T>(reinterpret_cast<const T*>(ap + ks * 16 * RB), reinterpret_cast<const T*>(ap + ks * 16 * RB + 4 * RB));
+      for (int j = 0; j < JT; ++j) up[j] = ub + (unsigned)toff[j];
+    };
+    frag_t a0, a1, b0[JT], b1[JT];
+    auto load_k = [&](int ks, frag_t& a, frag_t (&b)[JT]) __attribute__((always_inline)) {
+      a = tr_pair<T>(reinterpret_cast<const T*>(smem + ap + ks * 16 * RB), reinterpret_cast<const T*>(smem + ap + ks * 16 * RB + 4 * RB));
 #pragma unroll
-        for (int j = 0; j < JT; ++j)
-          b[j] = tr_pair<T>(reinterpret_cast<const T*>(up[j] + ks * 16 * RB), reinterpret_cast<const T*>(up[j] + ks * 16 * RB + 4 * RB));
-      };
-      auto mma_k = [&](const frag_t& a, const frag_t (&b)[JT]) __attribute__((always_inline)) {
+      for (int j = 0; j < JT; ++j)
+        b[j] = tr_pair<T>(reinterpret_cast<const T*>(smem + up[j] + ks * 16 * RB), reinterpret_cast<const T*>(smem + up[j] + ks * 16 * RB + 4 * RB));
+    };
+    auto mma_k = [&](const frag_t& a, const frag_t (&b)[JT]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < JT; ++j) mma_kgroup(acc[j], a, b[j]);
-      };
-      load_k(0, a0, b0);
+      for (int j = 0; j < JT; ++j) mma_kgroup(acc[j], a, b[j]);
+    };
+    // the transposed reads of a k-step (2 per fragment) are issued BETWEEN the MFMAs of the k-step before it: one MFMA, then
+    // a fragment's two reads (twg_ws: all reads of a k-step in one burst, with the MFMA pipe idle meanwhile)
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int j = 1; j < JT; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    };
+    if (ntile > 0) { setup(0); load_k(0, a0, b0); }
+    for (int k = 0; k < ntile; ++k) {
+      // (the fragments of this tile's first k-step are in flight)
 #pragma unroll
       for (int ks = 0; ks < NK; ks += 2) {
         load_k(ks + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
         mma_k(a0, b0);
+        interleave();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < NK) load_k(ks + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < NK) {
+          load_k(ks + 2, a0, b0);
+          mma_k(a1, b1);
+          interleave();
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       WSTAMP(0)
-      lds_barrier();                                        // tile k contracted, tile k+1 staged (unless it is a late fresh one)
+      lds_barrier();                                        // tile k read (its last MFMAs are still to come), tile k+1 staged (unless it is a late fresh one)
       if (k + 1 < ntile) {
         bool f1;
         next_window(k + 1, cpos, w, f1);                    // (cpos is tile k+1 by now)
         if (f1 && w < P.Fin) lds_barrier();                 // fresh tile whose front window overlaps window k: staged now
+        setup(k + 1);
+        load_k(0, a0, b0);                                  // the next tile's first fragments ...
       }
+      __builtin_amdgcn_sched_barrier(0);
+      mma_k(a1, b1);                                        // ... and, in their shadow, this tile's last k-step (registers only)
+      __builtin_amdgcn_sched_barrier(0);
       WSTAMP(1)
     }
 #ifdef ISTGCN_TWG_STAMP
@@ -356,17 +379,20 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
   if (is_compute) {
     const int ot = wave8 & 1, it = wave8 >> 1;
     float* dst = P.ws ? P.ws + (size_t)blockIdx.x * P.ws_slice : P.dW;
+    float* p0 = dst + (size_t)(o0 + ot * CB + 4 * (lane >> 5)) * P.Cin + i0 + it * CB + (lane & 31);
+    const size_t tap_stride = (size_t)P.Cout * P.Cin;
+    if (P.ws) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      if (j < P.ntaps) {
+      for (int j = 0; j < JT; ++j)
+        if (j < P.ntaps)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-          float* p = dst + ((size_t)j * P.Cout + o) * P.Cin + i;
-          if (P.ws) *p = acc[j][r];
-          else atomicAdd(p, acc[j][r]);
-        }
-      }
+          for (int r = 0; r < 16; ++r) p0[j * tap_stride + (size_t)((r & 3) + 8 * (r >> 2)) * P.Cin] = acc[j][r];
+    } else {
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+        if (j < P.ntaps)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) atomicAdd(p0 + j * tap_stride + (size_t)((r & 3) + 8 * (r >> 2)) * P.Cin, acc[j][r]);
     }
   }
 }
@@ -415,10 +441,7 @@ int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
 
 }  // namespace
 
-bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz) {
-  static const bool off = [] { const char* e = getenv("ISTGCN_TWG_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
-  if (off || dtype == 0 || in_mul != 1 || ntaps < 4 || ntaps > 9) return false;
-  if (Cin % 64 || Cout % 64 || V < 2 || V > TR) return false;
+static bool twl_subset_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int Tin, int Tz) {
   int mn = tap_off[0], mx = tap_off[0];
   for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
   const int F = TR / V, Fin = F - 1 + (mx - mn) + 1, keep = Fin - F;
@@ -429,9 +452,27 @@ bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in
   return true;
 }
 
+// 10..15 taps (the 15-tap fold of the Inception-TCN, net/st_gcn_multi3_fix_3A_mstcn.py:160-180): two launches over the first
+// ceil(n / 2) and the remaining taps, each with the window of its own taps
+bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz) {
+  static const bool off = [] { const char* e = getenv("ISTGCN_TWG_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
+  if (off || dtype == 0 || in_mul != 1 || ntaps < 4 || ntaps > 15) return false;
+  if (Cin % 64 || Cout % 64 || V < 2 || V > TR) return false;
+  if (ntaps <= 9) return twl_subset_ok(V, Cin, Cout, ntaps, tap_off, Tin, Tz);
+  const int n1 = (ntaps + 1) / 2;
+  return twl_subset_ok(V, Cin, Cout, n1, tap_off, Tin, Tz) && twl_subset_ok(V, Cin, Cout, ntaps - n1, tap_off + n1, Tin, Tz);
+}
+
 int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
                     int Cin, int Cout, int ntaps, const int* tap_off, int dtype, int grid_cap, float* ws, long long ws_floats,
                     hipStream_t stream) {
+  if (ntaps > 9) {
+    const int n1 = (ntaps + 1) / 2;
+    const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, n1, tap_off, dtype, grid_cap, ws, ws_floats, stream);
+    if (rc != ISTGCN_OK) return rc;
+    return twg_lean_launch(dz, g, pre, pre_relu, dW + (size_t)n1 * Cout * Cin, NM, Tin, Tz, V, Cin, Cout, ntaps - n1, tap_off + n1,
+                           dtype, grid_cap, ws, ws_floats, stream);
+  }
   TwlParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.pre_relu = pre ? pre_relu : 0;
   P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
@@ -446,6 +487,10 @@ int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_rel
   P.Fin = P.F - 1 + (mx - mn) + 1;
   P.tiles_per_seq = ceil_div(Tz, P.F);
   P.total_tiles = NM * P.tiles_per_seq;
-  if (ntaps <= 5) return dtype == 2 ? launch_twl<_Float16, 5>(P, grid_cap, stream) : launch_twl<__bf16, 5>(P, grid_cap, stream);
-  return dtype == 2 ? launch_twl<_Float16, 9>(P, grid_cap, stream) : launch_twl<__bf16, 9>(P, grid_cap, stream);
+#define TWL_CASE(J) return dtype == 2 ? launch_twl<_Float16, J>(P, grid_cap, stream) : launch_twl<__bf16, J>(P, grid_cap, stream)
+  if (ntaps <= 5) TWL_CASE(5);
+  if (ntaps <= 7) TWL_CASE(7);
+  if (ntaps == 8) TWL_CASE(8);
+  TWL_CASE(9);
+#undef TWL_CASE
 }

@@ -143,6 +143,8 @@ LEAN_WG_CASES = [
     ((2, 64, 64, 23, 25, 9), 0), ((1, 64, 64, 300, 25, 9), 2), ((3, 128, 64, 41, 25, 9), 4), ((5, 64, 128, 7, 25, 9), 2),
     ((2, 256, 256, 12, 18, 9), 0), ((2, 256, 256, 40, 18, 9), 16), ((2, 64, 128, 37, 25, 5), 2), ((1, 64, 64, 50, 20, 7), 1),
     ((2, 64, 64, 3, 25, 9), 0), ((4, 64, 64, 5, 25, 9), 1), ((1, 128, 128, 151, 25, 9), 4),
+    # 10..15 taps: two launches (8 + the rest), each with its own window
+    ((1, 128, 128, 31, 25, 15), 0), ((2, 64, 64, 40, 25, 15), 2), ((2, 64, 128, 20, 25, 11), 1), ((2, 128, 64, 33, 18, 15), 2),
 ]
 
 
