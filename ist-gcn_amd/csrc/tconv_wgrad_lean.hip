@@ -46,6 +46,8 @@ constexpr int UZ = 4;                // dz vectors per memory thread and tile: 1
 constexpr int US = 4;                // vectors of a window's new frames: F * V <= 128 rows
 constexpr int UX = 7;                // vectors of the first Fin - F frames of a fresh window: <= 224 rows
 constexpr int SWEEP = NROLE / 8;     // rows one sweep of the 256 threads covers (8 vectors per 64-channel row)
+// LDS plan (bytes): the two halves of the double-buffered dz tile (2 sub-tiles each), then the u region (2 sub-tiles of urows rows)
+constexpr int OFF_DZ = 0, OFF_DZ1 = 2 * TR * RB, OFF_U = 4 * TR * RB;
 
 struct TwlParams {
   const void* dz;        // [NM][Tz][V][Cout]
@@ -58,10 +60,14 @@ struct TwlParams {
   int tap_off[16];
   int F, Fin, min_off, tiles_per_seq, total_tiles, n_iblk;
   int urows, capf;       // rows of a u sub-tile region; frames the halo window can slide through
-  int off_dz, off_dz1, off_u;
   unsigned long long* dbg;   // experiment builds (-DISTGCN_TWG_STAMP): cycle stamps of workgroup 0
 };
 
+#ifdef TWL_X_NOMFMA         /* experiment build: the compute waves issue everything but the MFMAs (results wrong) */
+#define TWL_MMA(acc, a, b) { asm volatile("" :: "v"(a), "v"(b)); }
+#else
+#define TWL_MMA(acc, a, b) mma_kgroup(acc, a, b)
+#endif
 #ifdef ISTGCN_TWG_STAMP
 #define WSTAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
 #else
@@ -103,6 +109,21 @@ __device__ static inline uint32_t max_pk(uint32_t w, uint32_t floor2) {
 
 struct TPos { int n, mq; };
 
+template <int I, int N, typename F> __device__ static inline void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// scheduling pattern of one step: M MFMAs with R LDS reads spread between them
+// (+ E scalar / vector ALU instructions behind each MFMA: address arithmetic that would otherwise sit in one lump)
+template <int M, int R, int E = 0> __device__ static inline void interleave_mr() {
+  if constexpr (M > 0) {
+    constexpr int r = (R + M - 1) / M;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);
+    if constexpr (E > 0) __builtin_amdgcn_sched_group_barrier(0x006, E, 0);
+    interleave_mr<M - 1, R - r, E>();
+  }
+}
+
 template <typename T, int JT>
 __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
   using E = Elem<T>;
@@ -122,8 +143,8 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     // tile on (pad positions behind a tile's frames meet zero dz rows and whatever finite u rows lie there)
     const u32x4 z = {0u, 0u, 0u, 0u};
     const int n0 = 2 * 2 * dz_sub / 16, n1 = 2 * u_sub / 16;
-    for (int i = tid; i < n0; i += NTH) *reinterpret_cast<u32x4*>(smem + P.off_dz + i * 16) = z;
-    for (int i = tid; i < n1; i += NTH) *reinterpret_cast<u32x4*>(smem + P.off_u + i * 16) = z;
+    for (int i = tid; i < n0; i += NTH) *reinterpret_cast<u32x4*>(smem + OFF_DZ + i * 16) = z;
+    for (int i = tid; i < n1; i += NTH) *reinterpret_cast<u32x4*>(smem + OFF_U + i * 16) = z;
   }
   __syncthreads();
 
@@ -141,100 +162,126 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     return fresh ? 0 : w_prev + adv;
   };
 
-  f32x16 acc[JT];
+  // A compute wave: BOTH o-tiles x one i-tile x half of the taps (wave8 & 1 = i-tile, wave8 >> 1 = tap group): per k-step
+  // 2 dz fragments + JW u fragments feed 2 * JW MFMAs (one pair per wave x all taps: 1 + JT fragments for JT MFMAs -- that
+  // form is bound by the transposed LDS reads: 640 ds_read_b64_tr_b16 = 2560 LDS cycles per tile against 2304 of MFMA).
+  // An odd tap count leaves a middle tap: group 0 contracts it over the first half of a tile's k-steps, group 1 over the
+  // second half -- with group 1 walking the k-steps rotated by half a tile, so both groups run the same instruction stream
+  // (the shared slot is live in the first NK / 2 steps of the walk); the two partial sums meet in the flush.
+  constexpr int JW = (JT + 1) / 2;                          // tap slots of a wave
+  constexpr bool SHARED = (JT & 1) != 0;
+  constexpr int NK = TR / 16;
+  f32x16 acc[2][JW];
 #ifdef ISTGCN_TWG_STAMP
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
 #endif
+  const int it_w = wave8 & 1, grp_w = (wave8 >> 1) & 1;
   if (is_compute) {
     // =========================================== compute waves ===========================================
-    const int ot = wave8 & 1, it = wave8 >> 1;
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    int toff[JT];                                           // byte offset of a tap's rows in a u sub-tile
+      for (int j = 0; j < JW; ++j)
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int jv = j < P.ntaps ? j : 0;                   // padding taps alias tap 0 (computed, never flushed)
+        for (int r = 0; r < 16; ++r) acc[o][j][r] = 0.f;
+    int toff[JW];                                           // byte offset of a slot's tap rows in a u sub-tile
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int tap = grp_w ? JT - 1 - j : j;               // slot JW - 1 of an odd JT is the middle tap in both groups
+      const int jv = tap < P.ntaps ? tap : 0;               // padding taps alias tap 0 (computed, never flushed)
       toff[j] = (P.tap_off[jv] - P.min_off) * V * RB;
     }
     const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
     const int q = (lane & 15) >> 2, pp = lane & 3;
     const int coff = (cblk + 4 * pp) * 2;                   // bytes
     const int lrow = 8 * h + q;                             // this lane addresses rows 16*ks + lrow and + 4 of every k-step
+    const int rot = (SHARED && grp_w) ? (NK / 2) * 16 * RB : 0;   // bytes the k-step walk of group 1 is rotated by
     lds_barrier();                                          // tile 0 staged (the memory waves' prologue)
 #ifdef ISTGCN_TWG_STAMP
     tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long clk0 = tlast, real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     int w = 0;
     bool fresh = true;
     TPos cpos = tpos_first();
-    constexpr int NK = TR / 16;
-    // LDS byte offsets of this lane's first rows in the dz half and at every tap of the window (never pointers selected at
-    // run time: those decay to flat loads)
-    unsigned ap = 0, up[JT];
+    // LDS byte offsets of this lane's first rows in the dz half and at every slot's tap of the window, for the first and the
+    // second half of the walk (step x reads k-step (x + rot) mod NK: x * 1024 on top of the `lo` bases for x < NK / 2, of the
+    // `hi` bases behind).  Offsets, never pointers selected at run time: those decay to flat loads.
+    unsigned ap_lo = 0, ap_hi = 0, up_lo[JW], up_hi[JW];
+    bool late = false;                                      // the tile set up last is a fresh one whose front window overlaps its predecessor's
     auto setup = [&](int k) __attribute__((always_inline)) {
+      const int w_prev = w;
       w = next_window(k, cpos, w, fresh);
+      late = k > 0 && k < ntile && fresh && w_prev < P.Fin;
       cpos = tpos_next(cpos);
-      ap = (unsigned)(((k & 1) ? P.off_dz1 : P.off_dz) + ot * dz_sub + coff + lrow * RB);
-      const unsigned ub = (unsigned)(P.off_u + it * u_sub + coff + w * V * RB + lrow * RB);
+      const unsigned ab = (unsigned)(((k & 1) ? OFF_DZ1 : OFF_DZ) + coff + lrow * RB);
+      const unsigned ub = (unsigned)(OFF_U + it_w * u_sub + coff + w * V * RB + lrow * RB);
+      ap_lo = ab + (unsigned)rot; ap_hi = ab - (unsigned)rot;
 #pragma unroll
-      for (int j = 0; j < JT; ++j) up[j] = ub + (unsigned)toff[j];
+      for (int j = 0; j < JW; ++j) { up_lo[j] = ub + (unsigned)(toff[j] + rot); up_hi[j] = ub + (unsigned)(toff[j] - rot); }
     };
-    frag_t a0, a1, b0[JT], b1[JT];
-    auto load_k = [&](int ks, frag_t& a, frag_t (&b)[JT]) __attribute__((always_inline)) {
-      a = tr_pair<T>(reinterpret_cast<const T*>(smem + ap + ks * 16 * RB), reinterpret_cast<const T*>(smem + ap + ks * 16 * RB + 4 * RB));
+    frag_t a0[2], a1[2], b0[JW], b1[JW];
+    auto nslots = [](int x) constexpr { return (SHARED && x >= NK / 2) ? JW - 1 : JW; };
+    auto load_x = [&](auto xc, frag_t (&a)[2], frag_t (&b)[JW]) __attribute__((always_inline)) {
+      constexpr int X = decltype(xc)::value;
+      const unsigned ab = X < NK / 2 ? ap_lo : ap_hi;
 #pragma unroll
-      for (int j = 0; j < JT; ++j)
-        b[j] = tr_pair<T>(reinterpret_cast<const T*>(smem + up[j] + ks * 16 * RB), reinterpret_cast<const T*>(smem + up[j] + ks * 16 * RB + 4 * RB));
-    };
-    auto mma_k = [&](const frag_t& a, const frag_t (&b)[JT]) __attribute__((always_inline)) {
+      for (int o = 0; o < 2; ++o)
+        a[o] = tr_pair<T>(reinterpret_cast<const T*>(smem + ab + o * dz_sub + X * 16 * RB), reinterpret_cast<const T*>(smem + ab + o * dz_sub + X * 16 * RB + 4 * RB));
 #pragma unroll
-      for (int j = 0; j < JT; ++j) mma_kgroup(acc[j], a, b[j]);
-    };
-    // the transposed reads of a k-step (2 per fragment) are issued BETWEEN the MFMAs of the k-step before it: one MFMA, then
-    // a fragment's two reads (twg_ws: all reads of a k-step in one burst, with the MFMA pipe idle meanwhile)
-    auto interleave = [&]() __attribute__((always_inline)) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int j = 1; j < JT; ++j) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      for (int j = 0; j < nslots(X); ++j) {
+        const unsigned ubj = X < NK / 2 ? up_lo[j] : up_hi[j];
+        b[j] = tr_pair<T>(reinterpret_cast<const T*>(smem + ubj + X * 16 * RB), reinterpret_cast<const T*>(smem + ubj + X * 16 * RB + 4 * RB));
       }
     };
-    if (ntile > 0) { setup(0); load_k(0, a0, b0); }
+    auto mma_x = [&](auto xc, const frag_t (&a)[2], const frag_t (&b)[JW]) __attribute__((always_inline)) {
+      constexpr int X = decltype(xc)::value;
+#pragma unroll
+      for (int j = 0; j < nslots(X); ++j)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) TWL_MMA(acc[o][j], a[o], b[j]);
+    };
+    using x0 = std::integral_constant<int, 0>;
+    using xl = std::integral_constant<int, NK - 1>;
+    if (ntile > 0) { setup(0); load_x(x0{}, a0, b0); }
     for (int k = 0; k < ntile; ++k) {
-      // (the fragments of this tile's first k-step are in flight)
-#pragma unroll
-      for (int ks = 0; ks < NK; ks += 2) {
-        load_k(ks + 1, a1, b1);
-        mma_k(a0, b0);
-        interleave();
+      // (the fragments of this tile's first step are in flight.)  The transposed reads of a step are issued BETWEEN the
+      // MFMAs of the step before it, spread evenly (twg_ws: one burst per k-step with the MFMA pipe idle meanwhile).
+      static_for<0, NK - 1>([&](auto xc) __attribute__((always_inline)) {
+        constexpr int X = decltype(xc)::value;
+        using xn = std::integral_constant<int, X + 1>;
+        if constexpr (X % 2 == 0) { load_x(xn{}, a1, b1); mma_x(xc, a0, b0); }
+        else { load_x(xn{}, a0, b0); mma_x(xc, a1, b1); }
+        // the last reads of this tile are in this step: the addresses of the next tile are computed here as well, a few
+        // instructions behind each MFMA (behind the barrier they were 250 cycles of scalar work with the MFMA pipe idle;
+        // past the last tile the values are unused)
+        if constexpr (X == NK - 2) { setup(k + 1); interleave_mr<2 * nslots(X), 2 * (2 + nslots(X + 1)), 8>(); }
+        else interleave_mr<2 * nslots(X), 2 * (2 + nslots(X + 1))>();
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < NK) {
-          load_k(ks + 2, a0, b0);
-          mma_k(a1, b1);
-          interleave();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      });
+      // (Measured and dropped: a commit count of the memory waves in LDS that lets a compute wave fetch the next tile's first
+      //  fragments BEFORE its barrier when that tile is already staged -- the steps got slower by what the tail got faster.)
       WSTAMP(0)
+#ifdef ISTGCN_TWG_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WSTAMP(2)
+      asm volatile("s_barrier" ::: "memory");
+      WSTAMP(3)
+#else
       lds_barrier();                                        // tile k read (its last MFMAs are still to come), tile k+1 staged (unless it is a late fresh one)
+#endif
       if (k + 1 < ntile) {
-        bool f1;
-        next_window(k + 1, cpos, w, f1);                    // (cpos is tile k+1 by now)
-        if (f1 && w < P.Fin) lds_barrier();                 // fresh tile whose front window overlaps window k: staged now
-        setup(k + 1);
-        load_k(0, a0, b0);                                  // the next tile's first fragments ...
+        if (late) lds_barrier();                            // fresh tile whose front window overlaps window k: staged now
+        load_x(x0{}, a0, b0);                               // the next tile's first fragments ...
       }
       __builtin_amdgcn_sched_barrier(0);
-      mma_k(a1, b1);                                        // ... and, in their shadow, this tile's last k-step (registers only)
+      mma_x(xl{}, a1, b1);                                  // ... and, in their shadow, this tile's last step (registers only)
       __builtin_amdgcn_sched_barrier(0);
       WSTAMP(1)
     }
 #ifdef ISTGCN_TWG_STAMP
-    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[0] = tacc[0]; P.dbg[1] = tacc[1]; P.dbg[7] = (unsigned long long)ntile; }
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { P.dbg[4] = __builtin_amdgcn_s_memtime() - clk0; P.dbg[5] = __builtin_amdgcn_s_memrealtime() - real0; P.dbg[0] = tacc[0]; P.dbg[1] = tacc[1]; P.dbg[2] = tacc[2]; P.dbg[3] = tacc[3]; P.dbg[7] = (unsigned long long)ntile; }
+    if (P.dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 192) { P.dbg[11] = tacc[0]; P.dbg[12] = tacc[1]; P.dbg[13] = tacc[2]; P.dbg[14] = tacc[3]; }
 #endif
   } else {
     // =========================================== memory waves ============================================
@@ -258,12 +305,15 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     const unsigned useq_rec = (unsigned)(P.Tin * V - 1) * urow + 128u;                  // the i-block's last byte in a sequence
     // LDS: vector q of row r of a sub-tile at sub-tile + r * 64 + (q & 3) * 16
     const unsigned zl0 = (unsigned)(sub * dz_sub + r0 * RB + ql * 16);
-    const unsigned ul0 = (unsigned)(P.off_u + sub * u_sub + r0 * RB + ql * 16);
+    const unsigned ul0 = (unsigned)(OFF_U + sub * u_sub + r0 * RB + ql * 16);
     const int Tv = P.Tin * V;
 
     // ---- issue: dz tile + the window's last adv frames of tile k -> registers.  No predicates: the descriptors end where
     //      the data ends (invalid tile: zero records). ----
     auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RS)[US]) __attribute__((always_inline)) {
+#ifdef TWL_X_NOMEM          /* experiment build: the memory waves only keep the barriers (results wrong) */
+      return;
+#endif
       const bool valid = k < ntile;
       const int n = valid ? c.n : 0, m0 = (valid ? c.mq : 0) * P.F;
       const int nf = min(P.F, P.Tz - m0);
@@ -298,8 +348,11 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     // ---- commit: registers of tile k -> LDS (dz half k & 1; the new frames behind the window's kept ones); a FRESH window's
     //      first keep frames are loaded and staged here as well (once per region pass: the pipeline drains) ----
     auto commit = [&](int k, const TPos& c, int w, bool fresh, u32x4 (&RZ)[UZ], u32x4 (&RS)[US]) __attribute__((always_inline)) {
+#ifdef TWL_X_NOMEM
+      return;
+#endif
       asm volatile("" : "+v"(r0));          // (opaque per tile: or every slot's row test / address is kept in its own register)
-      unsigned char* dzs = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + zl0;
+      unsigned char* dzs = smem + ((k & 1) ? OFF_DZ1 : OFF_DZ) + zl0;
 #pragma unroll
       for (int u = 0; u < UZ; ++u) *reinterpret_cast<u32x4*>(dzs + u * (SWEEP * RB)) = RZ[u];
       const int m0 = c.mq * P.F;
@@ -375,24 +428,41 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
   __syncthreads();
 
   // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per instruction.  Every element of a
-  //      workspace slice is written by exactly one workgroup of that blockIdx.x (workgroups without tiles write zeros). ----
+  //      workspace slice is written by exactly one wave of the workgroups with that blockIdx.x (workgroups without tiles
+  //      write zeros).  The shared middle tap: group 1 hands its partial sums to group 0 through LDS (the dz halves are free). ----
+  if constexpr (SHARED) {
+    f32x16* xch = reinterpret_cast<f32x16*>(smem + OFF_DZ);               // [i-tile][o-tile][lane]
+    if (is_compute && grp_w == 1) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) xch[(it_w * 2 + o) * 64 + lane] = acc[o][JW - 1];
+    }
+    __syncthreads();
+    if (is_compute && grp_w == 0) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f32x16 v = xch[(it_w * 2 + o) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[o][JW - 1][r] += v[r];
+      }
+    }
+  }
   if (is_compute) {
-    const int ot = wave8 & 1, it = wave8 >> 1;
     float* dst = P.ws ? P.ws + (size_t)blockIdx.x * P.ws_slice : P.dW;
-    float* p0 = dst + (size_t)(o0 + ot * CB + 4 * (lane >> 5)) * P.Cin + i0 + it * CB + (lane & 31);
+    float* p0 = dst + (size_t)(o0 + 4 * (lane >> 5)) * P.Cin + i0 + it_w * CB + (lane & 31);
     const size_t tap_stride = (size_t)P.Cout * P.Cin;
-    if (P.ws) {
 #pragma unroll
-      for (int j = 0; j < JT; ++j)
-        if (j < P.ntaps)
+    for (int j = 0; j < JW; ++j) {
+      const int tap = grp_w ? JT - 1 - j : j;
+      if (tap < P.ntaps && !(SHARED && j == JW - 1 && grp_w == 1)) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) p0[j * tap_stride + (size_t)((r & 3) + 8 * (r >> 2)) * P.Cin] = acc[j][r];
-    } else {
+        for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int j = 0; j < JT; ++j)
-        if (j < P.ntaps)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) atomicAdd(p0 + j * tap_stride + (size_t)((r & 3) + 8 * (r >> 2)) * P.Cin, acc[j][r]);
+          for (int r = 0; r < 16; ++r) {
+            float* p = p0 + tap * tap_stride + (size_t)(o * CB + (r & 3) + 8 * (r >> 2)) * P.Cin;
+            if (P.ws) *p = acc[o][j][r];
+            else atomicAdd(p, acc[o][j][r]);
+          }
+      }
     }
   }
 }
@@ -401,11 +471,7 @@ template <typename T, int JT>
 int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
   P.n_iblk = P.Cin / 64;
   const int n_oblk = P.Cout / 64;
-  size_t base = 0;
-  const size_t dzb = (size_t)2 * TR * RB;
-  P.off_dz = (int)base; base += dzb;
-  P.off_dz1 = (int)base; base += dzb;
-  P.off_u = (int)base;
+  const size_t base = OFF_U;
   // region: as many slides as fit, at least until an overflow re-stage can run beside the window it replaces (n*F >= Fin)
   const int span_rows = (P.Fin - P.F) * P.V;                // tap span in rows; pad positions of a tile read TR + span rows
   int n_adv = 0;

@@ -25,5 +25,8 @@ for c, T in ((64, 300), (128, 150), (256, 75)):
     torch.cuda.synchronize()
     v = dbg.cpu().tolist()
     nt = max(1, v[7])
-    print('%3dch  %.0f us, %d tiles per workgroup; cycles per tile: compute wave: MFMA loop %.0f, wait at barrier %.0f | memory wave: issue %.0f, commit %.0f, wait at barrier %.0f' % (
-        c, e0.elapsed_time(e1) * 1e3, v[7], v[0] / nt, v[1] / nt, v[9] / nt, v[8] / nt, v[10] / nt), flush=True)
+    print('%3dch  %.0f us, %d tiles per workgroup; cycles per tile: compute wave 0: steps %.0f, own LDS reads %.0f, barrier %.0f, next tile\'s first reads + last step %.0f | '
+          'compute wave 3: %.0f, %.0f, %.0f, %.0f | memory wave: issue %.0f, commit %.0f, barrier %.0f' % (
+              c, e0.elapsed_time(e1) * 1e3, v[7], v[0] / nt, v[2] / nt, v[3] / nt, v[1] / nt, v[11] / nt, v[13] / nt, v[14] / nt, v[12] / nt,
+              v[9] / nt, v[8] / nt, v[10] / nt), flush=True)
+    print('        s_memtime %d ticks over %d ticks of the 100 MHz s_memrealtime: %.0f MHz' % (v[4], v[5], v[4] / max(1, v[5]) * 100.0), flush=True)
