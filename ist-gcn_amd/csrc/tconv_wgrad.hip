@@ -1812,6 +1812,12 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
     return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || Tz == 0) return ISTGCN_OK;
+  // lean form of twg_ws (tconv_wgrad_lean.hip) when no conv-bias gradient is asked for (the training step: functional.py)
+  if (!dbias && twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz)) {
+    const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype, grid_cap, ws,
+                                   ws_floats, (hipStream_t)stream);
+    if (rc >= 0) return rc;      // (-1: the LDS plan does not fit -- decided before anything was launched)
+  }
   {
     // frame-tiled kernel (tconv_rc_wgrad.hip): consecutive taps, stride 1 or 2, 64-channel blocks, 16-bit storage.  Measured
     // (tools/twg_exp.py, bf16, NM = 128): it wins where the round-2 kernels have no wave-specialised form for the 9-tap
@@ -1824,12 +1830,6 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
         (mode == 2 || (in_mul == 2 && ntaps <= 10)))
       return istgcn_tconv_wgrad_rc(dz, g, pre, pre_relu, dW, dbias, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype,
                                    grid_cap, ws, ws_floats, stream);
-  }
-  // lean form of twg_ws (tconv_wgrad_lean.hip) when no conv-bias gradient is asked for (the training step: functional.py)
-  if (!dbias && twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz)) {
-    const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, dtype, grid_cap, ws,
-                                   ws_floats, (hipStream_t)stream);
-    if (rc >= 0) return rc;
   }
   TwgParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;

@@ -60,6 +60,9 @@ struct TwlParams {
   int tap_off[16];
   int F, Fin, min_off, tiles_per_seq, total_tiles, n_iblk;
   int urows, capf;       // rows of a u sub-tile region; frames the halo window can slide through
+  int fs, fbase;         // the input frames the kernel walks are a VIEW of g: view frame f is frame fs * f + fbase of the sequence
+                         // (stride-2 convs: one launch per tap parity, each a unit-stride problem on every second frame)
+  int tap_dst0, tap_dstep;   // tap j of this launch is tap tap_dst0 + j * tap_dstep of dW
   unsigned long long* dbg;   // experiment builds (-DISTGCN_TWG_STAMP): cycle stamps of workgroup 0
 };
 
@@ -299,14 +302,22 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     const T* gg = reinterpret_cast<const T*>(P.g);
     const unsigned zrow = (unsigned)(P.Cout * 2), urow = (unsigned)(P.Cin * 2);          // bytes per tensor row
     const unsigned zvo0 = (unsigned)r0 * zrow + (unsigned)(q * 16);                     // slot 0 inside the tile / the slab
-    const unsigned uvo0 = (unsigned)r0 * urow + (unsigned)(q * 16);
-    const unsigned zstep = SWEEP * zrow, ustep = SWEEP * urow;
+    const unsigned zstep = SWEEP * zrow;
+    // slot u of a slab / of a fresh window's first frames is row r0 + 32 u of it: view frame r / V, joint r % V -- its byte
+    // offset from the slab's first row in the sequence, and its frame index (8 bits per slot) for the edge test
+    unsigned uoff[UX], frs_lo = 0, frs_hi = 0;
+#pragma unroll
+    for (int u = 0; u < UX; ++u) {
+      const int r = r0 + u * SWEEP, f = r / V;
+      uoff[u] = (unsigned)(P.fs * f * V + (r - f * V)) * urow + (unsigned)(q * 16);
+      if (u < 4) frs_lo |= (unsigned)f << (8 * u); else frs_hi |= (unsigned)f << (8 * (u - 4));
+    }
+    auto slot_frame = [&](int u) __attribute__((always_inline)) { return (int)(((u < 4 ? frs_lo : frs_hi) >> (8 * (u & 3))) & 255u); };
     const unsigned seq_z = (unsigned)(P.Tz * V) * zrow, seq_u = (unsigned)(P.Tin * V) * urow;   // bytes per sequence
     const unsigned useq_rec = (unsigned)(P.Tin * V - 1) * urow + 128u;                  // the i-block's last byte in a sequence
     // LDS: vector q of row r of a sub-tile at sub-tile + r * 64 + (q & 3) * 16
     const unsigned zl0 = (unsigned)(sub * dz_sub + r0 * RB + ql * 16);
     const unsigned ul0 = (unsigned)(OFF_U + sub * u_sub + r0 * RB + ql * 16);
-    const int Tv = P.Tin * V;
 
     // ---- issue: dz tile + the window's last adv frames of tile k -> registers.  No predicates: the descriptors end where
     //      the data ends (invalid tile: zero records). ----
@@ -321,11 +332,11 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
                                   valid ? (unsigned)((m0 + nf) * V - 1) * zrow + 128u : 0u);
       const rsrc_t ru = make_rsrc(reinterpret_cast<const unsigned char*>(gg) + (size_t)n * seq_u + i0 * 2, valid ? useq_rec : 0u);
       unsigned zo = zvo0 + (unsigned)(m0 * V) * zrow;
-      unsigned uo = uvo0 + (unsigned)((m0 + P.min_off + keep) * V) * urow;              // (>= 0: the launcher checks keep >= -min_off)
+      const unsigned ub = (unsigned)((P.fs * (m0 + P.min_off + keep) + P.fbase) * V) * urow;   // (frames in front of the sequence: wraps far out of range)
 #pragma unroll
       for (int u = 0; u < UZ; ++u) { RZ[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, zo, 0, 0)); zo += zstep; }
 #pragma unroll
-      for (int u = 0; u < US; ++u) { RS[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uo, 0, 0)); uo += ustep; }
+      for (int u = 0; u < US; ++u) RS[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, ub + uoff[u], 0, 0));
     };
     // BatchNorm affine + ReLU of one vector; EDGE: rows outside the sequence (conv padding) are zeros AFTER it
     auto transform = [&](u32x4 v, bool inside, auto edge) __attribute__((always_inline)) {
@@ -356,30 +367,29 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
 #pragma unroll
       for (int u = 0; u < UZ; ++u) *reinterpret_cast<u32x4*>(dzs + u * (SWEEP * RB)) = RZ[u];
       const int m0 = c.mq * P.F;
-      const int fin0 = m0 + P.min_off;                      // first input frame of the window (stride 1); may be < 0
-      const int row_s = (fin0 + keep) * V;                  // sequence row of the slab's first row (>= 0)
+      const int fin0 = m0 + P.min_off;                      // first view frame of the window
+      const int gf_s = P.fs * (fin0 + keep) + P.fbase;      // frame of the sequence the slab starts at
       unsigned char* us = smem + ul0 + (unsigned)((w + keep) * V * RB);
-      if (row_s + TR <= Tv) {
+      if (gf_s >= 0 && gf_s + P.fs * ((TR - 1) / V) < P.Tin) {
 #pragma unroll
         for (int u = 0; u < US; ++u) *reinterpret_cast<u32x4*>(us + u * (SWEEP * RB)) = transform(RS[u], true, no{});
       } else {
 #pragma unroll
-        for (int u = 0; u < US; ++u) *reinterpret_cast<u32x4*>(us + u * (SWEEP * RB)) = transform(RS[u], row_s + r0 + u * SWEEP < Tv, yes{});
+        for (int u = 0; u < US; ++u)
+          *reinterpret_cast<u32x4*>(us + u * (SWEEP * RB)) = transform(RS[u], (unsigned)(gf_s + P.fs * slot_frame(u)) < (unsigned)P.Tin, yes{});
       }
       if (fresh) {
         const rsrc_t ru = make_rsrc(reinterpret_cast<const unsigned char*>(gg) + (size_t)c.n * seq_u + i0 * 2, useq_rec);
-        const int row_x = fin0 * V;                         // sequence row of the window's first row; negative at a sequence start
-        unsigned uo = uvo0 + (unsigned)row_x * urow;        // (unsigned: rows in front of the sequence are far out of range)
+        const int gf_x = P.fs * fin0 + P.fbase;             // frame of the sequence the window starts at; negative at a sequence start
+        const unsigned ub = (unsigned)(gf_x * V) * urow;    // (unsigned: rows in front of the sequence are far out of range)
         u32x4 RX[UX];
 #pragma unroll
-        for (int u = 0; u < UX; ++u) { RX[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, uo, 0, 0)); uo += ustep; }
+        for (int u = 0; u < UX; ++u) RX[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, ub + uoff[u], 0, 0));
         unsigned char* ux = smem + ul0 + (unsigned)(w * V * RB);
         // (rows keep*V .. 223 of these slots are the slab's first rows once more: the same values to the same places)
 #pragma unroll
-        for (int u = 0; u < UX; ++u) {
-          const int rs = row_x + r0 + u * SWEEP;
-          *reinterpret_cast<u32x4*>(ux + u * (SWEEP * RB)) = transform(RX[u], rs >= 0 && rs < Tv, yes{});
-        }
+        for (int u = 0; u < UX; ++u)
+          *reinterpret_cast<u32x4*>(ux + u * (SWEEP * RB)) = transform(RX[u], (unsigned)(gf_x + P.fs * slot_frame(u)) < (unsigned)P.Tin, yes{});
       }
     };
     // tiles in flight: k (being contracted), k+1 (being committed), k+2 (being issued)
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
         for (int o = 0; o < 2; ++o)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float* p = p0 + tap * tap_stride + (size_t)(o * CB + (r & 3) + 8 * (r >> 2)) * P.Cin;
+            float* p = p0 + (P.tap_dst0 + tap * P.tap_dstep) * tap_stride + (size_t)(o * CB + (r & 3) + 8 * (r >> 2)) * P.Cin;
             if (P.ws) *p = acc[o][j][r];
             else atomicAdd(p, acc[o][j][r]);
           }
@@ -494,14 +504,14 @@ int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   const int n0 = P.ntaps * P.Cout * P.Cin;
-  if (P.ws && ((long long)gx * n0 > P.ws_slice || gx < 128)) P.ws = nullptr;   // too small / atomics are as fast
+  if (P.ws && ((long long)gx * n0 > P.ws_slice || gx < 128 || P.tap_dstep != 1)) P.ws = nullptr;   // too small / atomics are as fast / taps interleaved in dW
   P.ws_slice = n0;
 #ifdef ISTGCN_TWG_STAMP
   { const char* e_dbg = getenv("ISTGCN_TWG_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
 #endif
   ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(NTH), lds, stream, P);
   ISTGCN_CHECK_LAUNCH();
-  if (P.ws) return istgcn_wgrad_reduce(P.ws, P.ws_slice, gx, P.dW, n0, nullptr, 0, stream);
+  if (P.ws) return istgcn_wgrad_reduce(P.ws, P.ws_slice, gx, P.dW + (size_t)P.tap_dst0 * P.Cout * P.Cin, n0, nullptr, 0, stream);
   return ISTGCN_OK;
 }
 
@@ -511,10 +521,25 @@ static bool twl_subset_ok(int V, int Cin, int Cout, int ntaps, const int* tap_of
   int mn = tap_off[0], mx = tap_off[0];
   for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
   const int F = TR / V, Fin = F - 1 + (mx - mn) + 1, keep = Fin - F;
-  if (F < 1 || Fin <= F || keep + mn < 0) return false;      // the new frames of a slide start inside the sequence
+  if (F < 1 || Fin <= F || (TR - 1) / V > 255) return false;
   if (F * V > US * SWEEP || keep * V > UX * SWEEP) return false;
+  {
+    // the LDS plan of launch_twl must come out (so that a multi-launch dispatch never fails half way)
+    const int span_rows = keep * V;
+    int n_adv = 0;
+    for (int n = 8; n >= 1; --n)
+      if ((size_t)OFF_U + 2 * ((size_t)(n * F) * V + TR + span_rows) * RB <= 158 * 1024) { n_adv = n; break; }
+    if (n_adv * F < Fin || UX * SWEEP > n_adv * F * V + TR + span_rows) return false;
+  }
   // byte offsets inside a sequence are 32-bit, "in front of the sequence" must stay out of range after wrapping
   if ((long long)Tin * V * Cin * 2 >= (1ll << 30) || (long long)Tz * V * Cout * 2 >= (1ll << 30)) return false;
+  return true;
+}
+
+// stride 2: consecutive tap offsets t0, t0 + 1, ...: the taps of one parity read every second frame -- two unit-stride
+// problems on the views "frame 2 f + t0" and "frame 2 f + t0 + 1", with taps 0, 1, 2, ... each
+static bool twl_consecutive(int ntaps, const int* tap_off) {
+  for (int j = 1; j < ntaps; ++j) if (tap_off[j] != tap_off[0] + j) return false;
   return true;
 }
 
@@ -522,26 +547,26 @@ static bool twl_subset_ok(int V, int Cin, int Cout, int ntaps, const int* tap_of
 // ceil(n / 2) and the remaining taps, each with the window of its own taps
 bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz) {
   static const bool off = [] { const char* e = getenv("ISTGCN_TWG_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
-  if (off || dtype == 0 || in_mul != 1 || ntaps < 4 || ntaps > 15) return false;
+  if (off || dtype == 0 || in_mul < 1 || in_mul > 2 || ntaps < 4 || ntaps > 15) return false;
   if (Cin % 64 || Cout % 64 || V < 2 || V > TR) return false;
+  if (in_mul == 2) {
+    if (ntaps < 8 || ntaps > 10 || !twl_consecutive(ntaps, tap_off)) return false;
+    const int view[5] = {0, 1, 2, 3, 4};
+    return twl_subset_ok(V, Cin, Cout, (ntaps + 1) / 2, view, Tin, Tz);
+  }
   if (ntaps <= 9) return twl_subset_ok(V, Cin, Cout, ntaps, tap_off, Tin, Tz);
   const int n1 = (ntaps + 1) / 2;
   return twl_subset_ok(V, Cin, Cout, n1, tap_off, Tin, Tz) && twl_subset_ok(V, Cin, Cout, ntaps - n1, tap_off + n1, Tin, Tz);
 }
 
-int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
-                    int Cin, int Cout, int ntaps, const int* tap_off, int dtype, int grid_cap, float* ws, long long ws_floats,
-                    hipStream_t stream) {
-  if (ntaps > 9) {
-    const int n1 = (ntaps + 1) / 2;
-    const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, n1, tap_off, dtype, grid_cap, ws, ws_floats, stream);
-    if (rc != ISTGCN_OK) return rc;
-    return twg_lean_launch(dz, g, pre, pre_relu, dW + (size_t)n1 * Cout * Cin, NM, Tin, Tz, V, Cin, Cout, ntaps - n1, tap_off + n1,
-                           dtype, grid_cap, ws, ws_floats, stream);
-  }
+// one launch: the taps `tap_off` (view frames) of a view (fs, fbase) of g, written to taps tap_dst0 + j * tap_dstep of dW
+static int twl_launch_one(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
+                          int Cin, int Cout, int ntaps, const int* tap_off, int fs, int fbase, int tap_dst0, int tap_dstep, int dtype,
+                          int grid_cap, float* ws, long long ws_floats, hipStream_t stream) {
   TwlParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.pre_relu = pre ? pre_relu : 0;
   P.NM = NM; P.Tin = Tin; P.Tz = Tz; P.V = V; P.Cin = Cin; P.Cout = Cout; P.ntaps = ntaps;
+  P.fs = fs; P.fbase = fbase; P.tap_dst0 = tap_dst0; P.tap_dstep = tap_dstep;
   P.ws = ws_floats > 0 ? ws : nullptr; P.ws_slice = ws_floats;
   int mn = tap_off[0], mx = tap_off[0];
   for (int j = 0; j < 16; ++j) {
@@ -554,9 +579,32 @@ int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_rel
   P.tiles_per_seq = ceil_div(Tz, P.F);
   P.total_tiles = NM * P.tiles_per_seq;
 #define TWL_CASE(J) return dtype == 2 ? launch_twl<_Float16, J>(P, grid_cap, stream) : launch_twl<__bf16, J>(P, grid_cap, stream)
-  if (ntaps <= 5) TWL_CASE(5);
+  if (ntaps <= 4) TWL_CASE(4);
+  if (ntaps == 5) TWL_CASE(5);
   if (ntaps <= 7) TWL_CASE(7);
   if (ntaps == 8) TWL_CASE(8);
   TWL_CASE(9);
 #undef TWL_CASE
+}
+
+int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
+                    int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats,
+                    hipStream_t stream) {
+  if (in_mul == 2) {
+    const int view[5] = {0, 1, 2, 3, 4};
+    const int ne = (ntaps + 1) / 2, no = ntaps / 2;
+    const int rc = twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ne, view, 2, tap_off[0], 0, 2, dtype, grid_cap, ws,
+                                  ws_floats, stream);
+    if (rc != ISTGCN_OK) return rc;
+    return twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, no, view, 2, tap_off[0] + 1, 1, 2, dtype, grid_cap, ws,
+                          ws_floats, stream);
+  }
+  if (ntaps > 9) {
+    const int n1 = (ntaps + 1) / 2;
+    const int rc = twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, n1, tap_off, 1, 0, 0, 1, dtype, grid_cap, ws, ws_floats, stream);
+    if (rc != ISTGCN_OK) return rc;
+    return twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps - n1, tap_off + n1, 1, 0, n1, 1, dtype, grid_cap, ws,
+                          ws_floats, stream);
+  }
+  return twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, 1, 0, 0, 1, dtype, grid_cap, ws, ws_floats, stream);
 }

@@ -145,6 +145,9 @@ LEAN_WG_CASES = [
     ((2, 64, 64, 3, 25, 9), 0), ((4, 64, 64, 5, 25, 9), 1), ((1, 128, 128, 151, 25, 9), 4),
     # 10..15 taps: two launches (8 + the rest), each with its own window
     ((1, 128, 128, 31, 25, 15), 0), ((2, 64, 64, 40, 25, 15), 2), ((2, 64, 128, 20, 25, 11), 1), ((2, 128, 64, 33, 18, 15), 2),
+    # stride 2 (a 7th entry): one unit-stride launch per tap parity on every second frame; odd and even input lengths
+    ((2, 64, 128, 20, 25, 9, 2), 0), ((3, 64, 128, 61, 25, 9, 2), 2), ((2, 128, 256, 50, 25, 9, 2), 4), ((1, 128, 128, 300, 25, 9, 2), 2),
+    ((2, 64, 64, 33, 18, 9, 2), 1), ((4, 64, 64, 7, 25, 9, 2), 1),
 ]
 
 
@@ -154,19 +157,20 @@ LEAN_WG_CASES = [
 def test_tconv_weight_gradient_without_bias(ops, case, cap, dt, with_pre):
     """dW alone (the training step's call: the bias feeds a batch-statistics BatchNorm) against autograd of
     relu(bn(x)) -> conv2d, at shapes the lean kernel serves; the bias buffer handed in must come back untouched."""
-    NM, cin, cout, T, V, k = case
-    x, W, b, sc, sh = _mk(case + (1,), dt, seed=3)
+    stride = case[6] if len(case) > 6 else 1
+    NM, cin, cout, T, V, k = case[:6]
+    x, W, b, sc, sh = _mk(tuple(case[:6]) + (stride,), dt, seed=3)
     g = torch.Generator().manual_seed(79)
     u = F.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if with_pre else x
     if dt != torch.float32:
         u = u.to(dt).float()
     Wp = W.clone().requires_grad_(True)
-    z = F.conv2d(u, Wp, None, padding=((k - 1) // 2, 0))
+    z = F.conv2d(u, Wp, None, stride=(stride, 1), padding=((k - 1) // 2, 0))
     dz = torch.randn(z.shape, generator=g)
     dz = dz.to(dt).float()
     z.backward(dz)
     d = dev()
-    taps, in_mul = ops.conv_taps_fwd(k, 1)
+    taps, in_mul = ops.conv_taps_fwd(k, stride)
     blocks = (cin // 64) * (cout // 64)
     out = (torch.zeros(k, cout, cin, device=d), torch.full((cout,), 7.0, device=d))
     dW, db = ops.tconv_wgrad(to_ntvc(dz).to(d, dt), to_ntvc(x).to(d, dt), taps, in_mul=in_mul,

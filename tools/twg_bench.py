@@ -11,10 +11,10 @@ dt = {'bf16': torch.bfloat16, 'f16': torch.float16}[sys.argv[1] if len(sys.argv)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 d = torch.device('cuda:0')
 NM, V = 128, 25
-for c, T in ((64, 300), (128, 150), (256, 75)):
-    dz = (torch.randn(NM, T, V, c, device=d) * 0.1).to(dt)
+for c, T, s in ((64, 300, 1), (128, 150, 1), (256, 75, 1), (128, 300, 2), (256, 150, 2)):
+    dz = (torch.randn(NM, (T + s - 1) // s, V, c, device=d) * 0.1).to(dt)
     g = torch.randn(NM, T, V, c, device=d).to(dt)
-    taps, im = ops.conv_taps_fwd(k, 1)
+    taps, im = ops.conv_taps_fwd(k, s)
     pre = torch.stack([0.5 + torch.rand(c), 0.3 * torch.randn(c)]).to(d)
     res = {}
     outs = {}
@@ -38,6 +38,6 @@ for c, T in ((64, 300), (128, 150), (256, 75)):
         torch.cuda.synchronize()
         res[wb] = e0.elapsed_time(e1) * 100
     err = float((outs[True][0] - outs[False][0]).abs().max() / outs[True][0].abs().max())
-    fl = 2.0 * NM * T * V * c * c * k
-    print('tconv_wgrad %d taps %3d ch T=%3d: with dbias %.1f us (%.0f TFLOP/s)  without %.1f us (%.0f TFLOP/s)   dW diff %.2e' % (
-        k, c, T, res[True], fl / res[True] * 1e-6, res[False], fl / res[False] * 1e-6, err), flush=True)
+    fl = 2.0 * NM * ((T + s - 1) // s) * V * c * c * k
+    print('tconv_wgrad %d taps %3d ch T=%3d stride %d: with dbias %.1f us (%.0f TFLOP/s)  without %.1f us (%.0f TFLOP/s)   dW diff %.2e' % (
+        k, c, T, s, res[True], fl / res[True] * 1e-6, res[False], fl / res[False] * 1e-6, err), flush=True)
