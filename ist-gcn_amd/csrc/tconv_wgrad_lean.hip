@@ -504,7 +504,10 @@ int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > P.total_tiles) gx = P.total_tiles;
   const int n0 = P.ntaps * P.Cout * P.Cin;
-  if (P.ws && ((long long)gx * n0 > P.ws_slice || gx < 128 || P.tap_dstep != 1)) P.ws = nullptr;   // too small / atomics are as fast / taps interleaved in dW
+#ifndef TWL_WS_MIN
+#define TWL_WS_MIN 128
+#endif
+  if (P.ws && ((long long)gx * n0 > P.ws_slice || gx < TWL_WS_MIN || P.tap_dstep != 1)) P.ws = nullptr;   // too small / atomics are as fast / taps interleaved in dW
   P.ws_slice = n0;
 #ifdef ISTGCN_TWG_STAMP
   { const char* e_dbg = getenv("ISTGCN_TWG_DBG_PTR"); P.dbg = e_dbg ? reinterpret_cast<unsigned long long*>(strtoull(e_dbg, nullptr, 0)) : nullptr; }
