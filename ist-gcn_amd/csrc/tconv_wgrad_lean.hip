@@ -155,6 +155,9 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
   const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
   const int ntile = t_end > t_begin ? t_end - t_begin : 0;
   const int adv = P.F, keep = P.Fin - adv;                 // frames a window advances by / shares with its predecessor
+  // rows at the front of the region a FRESH window's staging writes: its Fin frames, and at least the UX sweeps of the first
+  // keep frames (which run on into the slab: the same values to the same places, but rows a live window must not own)
+  const int front_rows = max(P.Fin * V, UX * SWEEP);
   // window schedule, computed identically by both roles: tile k is FRESH (window at frame 0 of the region, staged whole) at
   // the start of the walk, at a sequence start, or when sliding on would leave the region; otherwise its window is adv
   // frames further on.  Tiles of a workgroup are consecutive: (sequence, tile in sequence) advance by increments.
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
     auto setup = [&](int k) __attribute__((always_inline)) {
       const int w_prev = w;
       w = next_window(k, cpos, w, fresh);
-      late = k > 0 && k < ntile && fresh && w_prev < P.Fin;
+      late = k > 0 && k < ntile && fresh && w_prev * V < front_rows;
       cpos = tpos_next(cpos);
       const unsigned ab = (unsigned)(((k & 1) ? OFF_DZ1 : OFF_DZ) + coff + lrow * RB);
       const unsigned ub = (unsigned)(OFF_U + it_w * u_sub + coff + w * V * RB + lrow * RB);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
       __builtin_amdgcn_sched_barrier(0);
       WSTAMP(1)
       const bool have = k + 1 < ntile;
-      const bool late = have && f1 && w_k < P.Fin;         // fresh window at the front would overlap window k: after the barrier
+      const bool late = have && f1 && w_k * V < front_rows;   // fresh window at the front would overlap window k: after the barrier
       if (have && !late) commit(k + 1, c1, w1, f1, Zn, Sn);
       WSTAMP(0)
       lds_barrier();                                        // tile k contracted
@@ -489,7 +492,7 @@ int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
     const size_t rows = (size_t)(n * P.F) * P.V + TR + span_rows;
     if (base + 2 * rows * RB <= 158 * 1024) { n_adv = n; break; }
   }
-  if (n_adv * P.F < P.Fin) return -1;
+  if (n_adv * P.F * P.V < (P.Fin * P.V > UX * SWEEP ? P.Fin * P.V : UX * SWEEP)) return -1;   // an overflow re-stage must fit beside the window it replaces
   P.capf = P.Fin + n_adv * P.F;
   P.urows = n_adv * P.F * P.V + TR + span_rows;
   // a fresh window's first Fin - F frames go through UX slots whose last rows spill into the slab: inside the region
@@ -524,7 +527,7 @@ static bool twl_subset_ok(int V, int Cin, int Cout, int ntaps, const int* tap_of
   int mn = tap_off[0], mx = tap_off[0];
   for (int j = 1; j < ntaps; ++j) { mn = tap_off[j] < mn ? tap_off[j] : mn; mx = tap_off[j] > mx ? tap_off[j] : mx; }
   const int F = TR / V, Fin = F - 1 + (mx - mn) + 1, keep = Fin - F;
-  if (F < 1 || Fin <= F || (TR - 1) / V > 255) return false;
+  if (F < 1 || Fin < F || (TR - 1) / V > 255) return false;
   if (F * V > US * SWEEP || keep * V > UX * SWEEP) return false;
   {
     // the LDS plan of launch_twl must come out (so that a multi-launch dispatch never fails half way)
@@ -532,7 +535,7 @@ static bool twl_subset_ok(int V, int Cin, int Cout, int ntaps, const int* tap_of
     int n_adv = 0;
     for (int n = 8; n >= 1; --n)
       if ((size_t)OFF_U + 2 * ((size_t)(n * F) * V + TR + span_rows) * RB <= 158 * 1024) { n_adv = n; break; }
-    if (n_adv * F < Fin || UX * SWEEP > n_adv * F * V + TR + span_rows) return false;
+    if (n_adv * F * V < (Fin * V > UX * SWEEP ? Fin * V : UX * SWEEP) || UX * SWEEP > n_adv * F * V + TR + span_rows) return false;
   }
   // byte offsets inside a sequence are 32-bit, "in front of the sequence" must stay out of range after wrapping
   if ((long long)Tin * V * Cin * 2 >= (1ll << 30) || (long long)Tz * V * Cout * 2 >= (1ll << 30)) return false;
@@ -550,11 +553,13 @@ static bool twl_consecutive(int ntaps, const int* tap_off) {
 // ceil(n / 2) and the remaining taps, each with the window of its own taps
 bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz) {
   static const bool off = [] { const char* e = getenv("ISTGCN_TWG_LEAN"); return e && atoi(e) == 0; }();   // dispatch override, read once
-  if (off || dtype == 0 || in_mul < 1 || in_mul > 2 || ntaps < 4 || ntaps > 15) return false;
+  if (off || dtype == 0 || in_mul < 1 || in_mul > 2 || ntaps < 1 || ntaps > 15) return false;
   if (Cin % 64 || Cout % 64 || V < 2 || V > TR) return false;
   if (in_mul == 2) {
-    if (ntaps < 8 || ntaps > 10 || !twl_consecutive(ntaps, tap_off)) return false;
-    const int view[5] = {0, 1, 2, 3, 4};
+    const int one[1] = {0};
+    if (ntaps == 1) return twl_subset_ok(V, Cin, Cout, 1, one, Tin, Tz);    // the 1 x 1 stride-2 residual conv: every second frame
+    if (ntaps < 8 || !twl_consecutive(ntaps, tap_off)) return false;     // (8..15 taps: 4..8 per parity)
+    const int view[8] = {0, 1, 2, 3, 4, 5, 6, 7};
     return twl_subset_ok(V, Cin, Cout, (ntaps + 1) / 2, view, Tin, Tz);
   }
   if (ntaps <= 9) return twl_subset_ok(V, Cin, Cout, ntaps, tap_off, Tin, Tz);
@@ -593,8 +598,12 @@ static int twl_launch_one(const void* dz, const void* g, const float* pre, int p
 int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
                     int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats,
                     hipStream_t stream) {
+  if (in_mul == 2 && ntaps == 1) {
+    const int one[1] = {0};
+    return twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, 1, one, 2, tap_off[0], 0, 1, dtype, grid_cap, ws, ws_floats, stream);
+  }
   if (in_mul == 2) {
-    const int view[5] = {0, 1, 2, 3, 4};
+    const int view[8] = {0, 1, 2, 3, 4, 5, 6, 7};
     const int ne = (ntaps + 1) / 2, no = ntaps / 2;
     const int rc = twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ne, view, 2, tap_off[0], 0, 2, dtype, grid_cap, ws,
                                   ws_floats, stream);

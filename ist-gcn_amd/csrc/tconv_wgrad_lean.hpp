@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 // shapes the kernel serves (16-bit storage, 64-channel blocks, no conv-bias gradient asked for; stride 1 with 4..15 taps,
-// stride 2 with 8..10 consecutive taps as one unit-stride launch per tap parity)
+// stride 2 with 8..15 consecutive taps as one unit-stride launch per tap parity)
 bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int Tin, int Tz);
 // returns an ISTGCN_* code, or -1 when the LDS plan does not fit (the caller falls back to twg_ws)
 int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,

@@ -1025,7 +1025,10 @@ def test_bn_tails_equal_standalone_launches(tag, dt):
         f.write('%s %s: tails taken %d stand-alone %d | tail vs alone: running %.3g logits %.3g grads %.3g | alone vs alone: running %.3g '
                 'logits %.3g grads %.3g\n' % (tag, str(dt)[6:], st1['taken'], st1['standalone'], rel(r1, r0), rel(l1, l0), rel(g1, g0),
                                               rel(r2, r0), rel(l2, l0), rel(g2, g0)))
-    assert rel(r1, r0) < 3 * rel(r2, r0) + 1e-5, (rel(r1, r0), rel(r2, r0))
+    # (16-bit storage: two stand-alone runs differ by 1e-6 .. 2e-5 in the running statistics themselves -- gpurun_out/
+    #  bn_tails_measured.txt: 1.4e-5 for st_gcn_msgcn, 1.3e-6 for the same test of st_gcn_multi3 on another day -- so the
+    #  yardstick alone is not a bound; the floor is the larger of those)
+    assert rel(r1, r0) < 3 * rel(r2, r0) + (1e-5 if dt == torch.float32 else 5e-5), (rel(r1, r0), rel(r2, r0))
     assert rel(l1, l0) < 3 * rel(l2, l0) + (1e-5 if dt == torch.float32 else 5e-3), (rel(l1, l0), rel(l2, l0))
     # (float32: logits agree to 3e-7, but one ReLU mask flip at a pre-activation within round-off of zero moves the whole
     #  gradient by 1e-3 .. 4e-3 -- discrete events, so two runs of the SAME path differ by 0.0006 .. 0.002 as well; cf. smoke())

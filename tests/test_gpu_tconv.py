@@ -148,6 +148,10 @@ LEAN_WG_CASES = [
     # stride 2 (a 7th entry): one unit-stride launch per tap parity on every second frame; odd and even input lengths
     ((2, 64, 128, 20, 25, 9, 2), 0), ((3, 64, 128, 61, 25, 9, 2), 2), ((2, 128, 256, 50, 25, 9, 2), 4), ((1, 128, 128, 300, 25, 9, 2), 2),
     ((2, 64, 64, 33, 18, 9, 2), 1), ((4, 64, 64, 7, 25, 9, 2), 1),
+    ((2, 64, 128, 41, 25, 15, 2), 2), ((1, 128, 128, 60, 25, 15, 2), 0),
+    # 1 and 3 taps (the 1 x 1 residual conv at stride 2; windows without / with two shared frames)
+    ((2, 64, 128, 61, 25, 1, 2), 2), ((3, 128, 256, 20, 25, 1, 2), 4), ((2, 64, 64, 37, 25, 1, 1), 1), ((2, 64, 128, 44, 25, 3, 1), 2),
+    ((6, 64, 64, 9, 25, 4, 1), 1), ((5, 64, 64, 11, 18, 4, 1), 1),
 ]
 
 
