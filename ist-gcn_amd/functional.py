@@ -338,8 +338,15 @@ class STGCNBlockFn(torch.autograd.Function):
             res, cr = x, None
         elif cfg.residual == 'conv':
             strs = ops.stats_scratch(2, cout, dev) if training else None
-            wr = pk['wr'] if 'wr' in pk else ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
-            r = ops.tconv(x, wr, cout, [0], bias=br, stats=strs, Tout=Tz, Mlog=Tz, in_mul=s)
+            if ops.gcn_rc_serves(cin, cout, 1, V, dt):
+                # 16-bit storage: the strided 1 x 1 conv as the register-chained graph-conv kernel with K = 1, A = I (the form its
+                # data gradient has had since round 3): 57 us against 83 on `tconv`, whose item structure is built for 9 taps
+                wrg = pk['wrg'] if 'wrg' in pk else ops.pack_gcn_weight(Wr.unsqueeze(1), dt)
+                bt_r = None if br is None else br.view(1, cout).expand(V, cout).contiguous()
+                r = ops.gcn_forward(x, _eye(V, dev), wrg, cout, bterm=bt_r, stats=strs, Tout=Tz, in_t_stride=s, nnz_cap=V)
+            else:
+                wr = pk['wr'] if 'wr' in pk else ops.pack_tconv_weight(Wr.view(1, cout, cin), V, [0], s, dt)
+                r = ops.tconv(x, wr, cout, [0], bias=br, stats=strs, Tout=Tz, Mlog=Tz, in_mul=s)
             coefr = ops.bn_finalize(strs, NM * Tz * V, gr, betar, bufs['bnr'][0], bufs['bnr'][1], cfg.momentum,
                                     cfg.eps, training, clear=True)
             res, cr = r, coefr[:2].contiguous()

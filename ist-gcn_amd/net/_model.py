@@ -222,6 +222,7 @@ class STGCNBlock(nn.Module):
             Wr = self.residual[0].weight.view(c, cin)
             d['wr'] = plan.add_tconv(Wr.view(1, c, cin), V, [0], s)
             d['wrt'] = plan.add_gcn(Wr.t().unsqueeze(1))
+            d['wrg'] = plan.add_gcn(Wr.unsqueeze(1))          # forward form of the same kernel (16-bit storage)
         return d
 
     def _gather(self, x, A_eff, mst, nnz_cap, bterm, pattern):

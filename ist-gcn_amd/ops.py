@@ -159,6 +159,11 @@ def weights_epoch():
 CHECK_NNZ = False        # debug / test switch: verify (with a host sync) that a reduced nnz_cap really covers nnz(A)
 
 
+def gcn_rc_serves(cin, cout, K, V, dtype):
+    """True when istgcn_gcn_fwd takes its register-chained kernel for this shape in 16-bit storage (csrc/gcn_fwd.hip)."""
+    return dtype != torch.float32 and V <= 32 and bool(_lib.load().istgcn_gcn_rc_layout(cin, cout, K, _DT[dtype]))
+
+
 def gcn_forward(x, A, wp, cout, bterm=None, addend=None, out=None, stats=None, Tout=None, Tlog=None,
                 in_t_stride=1, out_t_stride=1, nnz_cap=None, grid_cap=0):
     """istgcn_gcn_fwd.  x: [NM,Tin,V,Cin]; A: [K,V,V] fp32; wp from pack_gcn_weight; returns y [NM,Tout,V,cout].
