@@ -471,7 +471,8 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
         for (int o = 0; o < 2; ++o)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float* p = p0 + (P.tap_dst0 + tap * P.tap_dstep) * tap_stride + (size_t)(o * CB + (r & 3) + 8 * (r >> 2)) * P.Cin;
+            // (a workspace slice holds THIS launch's taps, 0 .. ntaps - 1; dW the layer's: tap_dst0 + j * tap_dstep)
+            float* p = p0 + (P.ws ? tap : P.tap_dst0 + tap * P.tap_dstep) * tap_stride + (size_t)(o * CB + (r & 3) + 8 * (r >> 2)) * P.Cin;
             if (P.ws) *p = acc[o][j][r];
             else atomicAdd(p, acc[o][j][r]);
           }

@@ -114,6 +114,20 @@ def test_weight_gradients_are_additive_over_batch_shards(ops, graph_A, NM, T, C,
     dWb, dbb = ops.tconv_wgrad(dz[h:].contiguous(), g[h:].contiguous(), taps, in_mul=in_mul, pre=pre, pre_relu=True)
     assert ((dW - (dWa + dWb)).abs().max() / dW.abs().max()) < tol
     assert ((db - (dba + dbb)).abs().max() / db.abs().max()) < tol
+    # the training step's call (no bias gradient: tconv_wgrad_lean.hip for 16-bit storage) against the call above (the
+    # round-2 / frame-tiled kernels, which still serve `dbias`): two independent kernels, one answer -- at 9 taps, at the 15
+    # taps of the Inception-TCN fold (two launches, the second one's taps offset in dW) and at stride 2 (one launch per tap
+    # parity, taps interleaved in dW); and additive over batch halves like the others
+    for kk, ss in ((9, 1), (15, 1), (9, 2), (15, 2)):
+        tp, im = ops.conv_taps_fwd(kk, ss)
+        dzs = dz if ss == 1 else dz[:, ::ss].contiguous()
+        full, _ = ops.tconv_wgrad(dzs, g, tp, in_mul=im, pre=pre, pre_relu=True)
+        lean, none = ops.tconv_wgrad(dzs, g, tp, in_mul=im, pre=pre, pre_relu=True, want_bias=False)
+        assert none is None
+        assert ((lean - full).abs().max() / full.abs().max()) < tol, (kk, ss)
+        la, _ = ops.tconv_wgrad(dzs[:h].contiguous(), g[:h].contiguous(), tp, in_mul=im, pre=pre, pre_relu=True, want_bias=False)
+        lb, _ = ops.tconv_wgrad(dzs[h:].contiguous(), g[h:].contiguous(), tp, in_mul=im, pre=pre, pre_relu=True, want_bias=False)
+        assert ((lean - (la + lb)).abs().max() / lean.abs().max()) < tol, (kk, ss)
     gW, S = ops.gcn_wgrad(dz, g, A, nnz_cap=cap)
     gWa, Sa = ops.gcn_wgrad(dz[:h].contiguous(), g[:h].contiguous(), A, nnz_cap=cap)
     gWb, Sb = ops.gcn_wgrad(dz[h:].contiguous(), g[h:].contiguous(), A, nnz_cap=cap)

@@ -152,6 +152,9 @@ LEAN_WG_CASES = [
     # 1 and 3 taps (the 1 x 1 residual conv at stride 2; windows without / with two shared frames)
     ((2, 64, 128, 61, 25, 1, 2), 2), ((3, 128, 256, 20, 25, 1, 2), 4), ((2, 64, 64, 37, 25, 1, 1), 1), ((2, 64, 128, 44, 25, 3, 1), 2),
     ((6, 64, 64, 9, 25, 4, 1), 1), ((5, 64, 64, 11, 18, 4, 1), 1),
+    # the second launch of a 15-tap layer through the WORKSPACE (>= 128 slices: its taps are local there, 8 .. 14 in dW), and a
+    # long walk over several sequences at stride 2 with 8 + 7 taps per parity
+    ((40, 64, 64, 20, 25, 15), 0), ((4, 256, 256, 150, 25, 15, 2), 1), ((3, 128, 128, 150, 25, 15, 2), 1),
     # one tile per sequence (every window fresh and "late"), more workgroups than tile chunks (a workgroup without tiles)
     ((5, 64, 64, 5, 25, 9), 4), ((7, 128, 64, 4, 25, 9, 2), 4),
 ]
