@@ -219,6 +219,9 @@ __global__ __launch_bounds__(NTH, 2) void tconv_lean_kernel(const TlParams P) {
       const int p = wr * (32 * NTW) + tt * 32 + (lane & 31);
       const int f = frame_of(p), v = p - f * V;
       brow[tt] = (unsigned)(((P.in_mul * f) * V + v) * RB + 16 * (h ^ ((v >> 2) & 3)));
+#ifdef TL_X_NOCONF          /* experiment build: fragment reads at conflict-free synthetic addresses (results wrong): what the bank conflicts cost */
+      brow[tt] = (unsigned)((tt * 32 + (lane & 31)) * RB + 16 * (h ^ (((lane & 31) >> 2) & 3)));
+#endif
     }
     unsigned ubase = (unsigned)P.off_u0;
     // (tapd may be negative -- the data gradient's taps are listed flipped --: unsigned arithmetic, the sums are in range)
