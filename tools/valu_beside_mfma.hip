@@ -101,7 +101,64 @@ void run(const char* tag, int mi, int vi) {
   hipFree(out);
 }
 
+// 12 waves per workgroup: one matrix wave and TWO vector waves per SIMD (does a second vector wave add issue slots?)
+__global__ __launch_bounds__(768, 3) void k12(unsigned long long* out, int mfma_iters, int valu_iters, float seed) {
+  const int wave = threadIdx.x >> 6;
+  const bool matrix = wave < 4;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (matrix) {
+    if (mfma_iters <= 0) return;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + threadIdx.x * 1e-3f); b[i] = (__bf16)(seed * 0.5f); }
+    f32x16 acc[4];
+    for (int n = 0; n < 4; ++n) for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+    for (int it = 0; it < mfma_iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[n]) : "v"(a), "v"(b));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int n = 0; n < 4; ++n) for (int i = 0; i < 16; ++i) s += acc[n][i];
+    if (s == 12345.678f) out[15] = 1;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && wave == 0) { out[0] = t1 - t0; out[1] = (unsigned long long)mfma_iters * 16; }
+  } else {
+    if (valu_iters <= 0) return;
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = seed + i + threadIdx.x;
+    const float c0 = seed * 0.999f, c1 = seed * 0.001f;
+    for (int it = 0; it < valu_iters; ++it)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c0), "v"(c1));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 8; ++i) s += v[i];
+    if (s == 12345.678f) out[15] = 2;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && wave == 4) { out[2] = t1 - t0; out[3] = (unsigned long long)valu_iters * 64; }
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && wave == 8) { out[4] = t1 - t0; }
+  }
+}
+
+void run12(const char* tag, int mi, int vi) {
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  unsigned long long* out; hipMalloc(&out, 16 * 8); hipMemset(out, 0, 16 * 8);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k12, dim3(p.multiProcessorCount), dim3(768), 0, 0, out, mi, vi, 1.0f);
+  hipDeviceSynchronize();
+  unsigned long long h[16]; hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+  printf("%-44s", tag);
+  if (mi) printf(" matrix wave: %7.1f cycles/MFMA", (double)h[0] / h[1]); else printf(" %34s", "");
+  if (vi) printf("   vector wave 4: %6.2f, wave 8: %6.2f cycles/VALU", (double)h[2] / h[3], (double)h[4] / h[3]);
+  printf("\n");
+  hipFree(out);
+}
+
 int main() {
+  run12("12 waves: two vector waves per SIMD, alone", 0, 4000);
+  run12("12 waves: matrix + two vector waves per SIMD", 4000, 4000);
+
   const int MI = 4000, VI = 4000;     // 64000 MFMAs = 2.05 M cycles alone; 256000 VALU = 1.0 M cycles alone at 4 cycles each
   run<0, 0, false, 0>("matrix waves alone", MI, 0);
   run<0, 0, false, 0>("vector waves alone", 0, VI);
