@@ -18,3 +18,6 @@ if [ -f tools/bin/lib_twgstamp.so ]; then
   ISTGCN_LIB_PATH=tools/bin/lib_twgstamp.so timeout -k 10 200 python tools/twg_stamp_exp.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_twg_stamps.txt
   cat gpurun_out/${tag}_twg_stamps.txt
 fi
+# two ranks sharing the one card over gloo: the data-parallel path end to end (layout agreement, early bucket, per-rank report)
+ISTGCN_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --batch 32 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_2rank_gloo.json 2> gpurun_out/${tag}_bench_2rank_gloo.err || { tail -5 gpurun_out/${tag}_bench_2rank_gloo.err; exit 1; }
+cut -c1-200 gpurun_out/${tag}_bench_2rank_gloo.json
