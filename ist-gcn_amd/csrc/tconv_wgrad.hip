@@ -1812,10 +1812,12 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
     return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || Tz == 0) return ISTGCN_OK;
-  // lean form of twg_ws (tconv_wgrad_lean.hip) when no conv-bias gradient is asked for (the training step: functional.py)
-  if (!dbias && twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz)) {
+  // lean form of twg_ws (tconv_wgrad_lean.hip) for the 16-bit trunk shapes; a conv-bias gradient, when asked for (the training
+  // step does not: functional.py), is a column-sum kernel of its own next to it
+  if (twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz) && (!dbias || (Cout <= 256 && 256 % (Cout / 8) == 0))) {
     const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype, grid_cap, ws,
                                    ws_floats, (hipStream_t)stream);
+    if (rc == ISTGCN_OK && dbias) return twg_lean_dbias(dz, dbias, NM, Tz, V, Cout, dtype, (hipStream_t)stream);
     if (rc >= 0) return rc;      // (-1: the LDS plan does not fit -- decided before anything was launched)
   }
   {

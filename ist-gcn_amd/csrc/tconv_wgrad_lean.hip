@@ -481,6 +481,45 @@ __global__ __launch_bounds__(NTH, 2) void twg_lean_kernel(const TwlParams P) {
   }
 }
 
+// Conv-bias gradient for callers that ask for it (eval-mode backward, the unit tests; the training step does not):
+// dbias[o] += sum over all rows of dz[row][o].  One 16-byte vector per thread and row, fp32 partial sums, a block reduction
+// through LDS, one float atomic per channel and workgroup.  HBM-bound: dz is read once more.
+template <typename T>
+__global__ __launch_bounds__(256) void dz_colsum_kernel(const T* __restrict__ dz, float* __restrict__ dbias, long long rows, int Cout) {
+  __shared__ float red[256][9];
+  const int QC = Cout / 8;                                  // vectors per row (8, 16 or 32: divides 256)
+  const int q = threadIdx.x % QC, rl = threadIdx.x / QC, rpb = 256 / QC;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // (four rows in flight per thread: the loop is latency-bound otherwise)
+  const long long step = (long long)gridDim.x * rpb;
+  for (long long row = (long long)blockIdx.x * rpb + rl; row < rows; row += 4 * step) {
+    u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long r = row + u * step;
+      v[u] = r < rows ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dz + r * Cout + q * 8)) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        float lo, hi;
+        unpk2<T>(v[u][d], lo, hi);
+        acc[2 * d] += lo;
+        acc[2 * d + 1] += hi;
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < Cout) {
+    const int c = threadIdx.x, cq = c / 8, ce = c % 8;
+    float sum = 0.f;
+    for (int r = 0; r < rpb; ++r) sum += red[r * QC + cq][ce];
+    atomicAdd(dbias + c, sum);
+  }
+}
+
 template <typename T, int JT>
 int launch_twl(TwlParams& P, int grid_cap, hipStream_t stream) {
   P.n_iblk = P.Cin / 64;
@@ -620,4 +659,16 @@ int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_rel
                           ws_floats, stream);
   }
   return twl_launch_one(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, 1, 0, 0, 1, dtype, grid_cap, ws, ws_floats, stream);
+}
+
+int twg_lean_dbias(const void* dz, float* dbias, int NM, int Tz, int V, int Cout, int dtype, hipStream_t stream) {
+  const long long rows = (long long)NM * Tz * V;
+  if (Cout % 8 || 256 % (Cout / 8) || Cout > 256) return ISTGCN_EINVAL;
+  const int rpb = 256 / (Cout / 8);
+  long long g = (rows + rpb - 1) / rpb;
+  if (g > 2048) g = 2048;
+  if (dtype == 2) ISTGCN_LAUNCH(dz_colsum_kernel<_Float16>, dim3((int)g), dim3(256), 0, stream, (const _Float16*)dz, dbias, rows, Cout);
+  else ISTGCN_LAUNCH(dz_colsum_kernel<__bf16>, dim3((int)g), dim3(256), 0, stream, (const __bf16*)dz, dbias, rows, Cout);
+  ISTGCN_CHECK_LAUNCH();
+  return ISTGCN_OK;
 }

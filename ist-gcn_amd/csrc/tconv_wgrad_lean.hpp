@@ -9,3 +9,5 @@ bool twg_lean_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in
 int twg_lean_launch(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, int NM, int Tin, int Tz, int V,
                     int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats,
                     hipStream_t stream);
+// dbias[o] += column sums of dz (16-bit storage, Cout in {64, 128, 256}): the bias gradient next to a lean launch
+int twg_lean_dbias(const void* dz, float* dbias, int NM, int Tz, int V, int Cout, int dtype, hipStream_t stream);

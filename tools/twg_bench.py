@@ -1,6 +1,6 @@
 """Per-call time (hipGraph replay of 10 calls) of tconv_wgrad at the trunk's stride-1 layer shapes (NM = 128, V = 25), with and
-without the conv-bias gradient (without: the lean kernel, tconv_wgrad_lean.hip; ISTGCN_TWG_LEAN=0 in the environment keeps
-twg_ws for both).  usage: twg_bench.py [bf16|f16] [taps]"""
+without the conv-bias gradient (both on the lean kernel, tconv_wgrad_lean.hip -- with: plus its column-sum kernel;
+ISTGCN_TWG_LEAN=0 in the environment: the round-1/2/3 kernels for both; one process per setting).  usage: twg_bench.py [bf16|f16] [taps]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
