@@ -472,11 +472,34 @@ __global__ __launch_bounds__(64 * OT * IT * PS * TS, (AGG && sizeof(T) == 2) ? 4
         else {
           wslot += adv;
           if (wslot + P.Fin > P.capf) {                   // window at the end of the region: overlap back to the front
-            for (int idx = tid; idx < keep_items; idx += NTH) {
-              const int q = idx % (IT * QV), r = idx / (IT * QV);
-              const int sub = q / QV, ql = q - sub * QV;
-              T* rowp = us + sub * u_sub + r * CB + ql * EPL;
-              *reinterpret_cast<frag_t*>(rowp) = *reinterpret_cast<const frag_t*>(rowp + wslot * V * CB);
+            // The kept frames move DOWN by wslot frames; source and destination ranges overlap whenever more frames are kept
+            // than the window advanced by, and the rows behind the kept ones are where this tile's new frames go.  All reads
+            // first, a barrier, then the writes: without it a wave that arrived early overwrote rows a late wave had not read
+            // yet (round 4: tap 0 of the 15-tap stride-2 layers wrong by < 1 % of max |dW| in a third of the runs at 256
+            // channels, tools/twg_flaky.py; the waves do not enter this loop together).
+            constexpr int KC = 8;                           // vectors per thread held across the barrier, per pass
+            for (int base = 0; base < keep_items; base += KC * NTH) {
+              frag_t tmp[KC];
+#pragma unroll
+              for (int u = 0; u < KC; ++u) {
+                const int idx = base + tid + u * NTH;
+                if (idx < keep_items) {
+                  const int q = idx % (IT * QV), r = idx / (IT * QV);
+                  const int sub = q / QV, ql = q - sub * QV;
+                  tmp[u] = *reinterpret_cast<const frag_t*>(us + sub * u_sub + r * CB + ql * EPL + wslot * V * CB);
+                }
+              }
+              __syncthreads();
+#pragma unroll
+              for (int u = 0; u < KC; ++u) {
+                const int idx = base + tid + u * NTH;
+                if (idx < keep_items) {
+                  const int q = idx % (IT * QV), r = idx / (IT * QV);
+                  const int sub = q / QV, ql = q - sub * QV;
+                  *reinterpret_cast<frag_t*>(us + sub * u_sub + r * CB + ql * EPL) = tmp[u];
+                }
+              }
+              if (base + KC * NTH < keep_items) __syncthreads();     // (another pass: its reads come after these writes)
             }
             wslot = 0;
           }

@@ -274,9 +274,10 @@ def test_bottleneck_trio_config5_full_size(ops):
 def test_stride2_15tap_weight_gradient_is_stable_at_full_size(ops):
     """Regression for a race of the ROUND-1 weight-gradient kernel that tools/twg_flaky.py found in round 4: at 256 channels,
     15 taps, stride 2, bf16 (the stride-2 Inception-TCN layer of st_gcn_multi3_fix_3A_mstcn at bench size) it returned tap 0
-    wrong by 0.2-0.8 % of max |dW| in 5-10 of 16 runs (gpurun_out/twg_flaky.txt).  The 16-bit trunk
-    shapes no longer reach it (tconv_wgrad_lean.hip serves them with and without dbias): eight repeats agree with each other
-    to the order of the atomics and with torch's conv2d weight gradient."""
+    wrong by 0.2-0.8 % of max |dW| in 5-10 of 16 runs (profiles/r04_twg_flaky_round1_kernel.txt): an
+    unsynchronised overlapping copy of the kept window frames in LDS, fixed with a barrier between its reads and writes.  The
+    16-bit trunk shapes run tconv_wgrad_lean.hip with and without dbias (ISTGCN_TWG_LEAN=0: the fixed round-1 kernel): eight
+    repeats agree with each other to the order of the atomics and with torch's conv2d weight gradient."""
     import torch.nn.functional as F
     d, dt = dev(), torch.bfloat16
     NM, T, C, k, s_ = 128, 150, 256, 15, 2
