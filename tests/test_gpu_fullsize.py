@@ -305,3 +305,16 @@ def test_stride2_15tap_weight_gradient_is_stable_at_full_size(ops):
         assert rel(dW, first) < 1e-5, (i, rel(dW, first))
         if db is not None:
             assert rel(db, dz.float().sum((0, 1, 2))) < 1e-4
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f32'])
+def test_repeated_launches_agree_at_bench_size(dtn):
+    """tools/stability_sweep.py in a child process: every hot-path op launched six times on the same bench-size inputs --
+    outputs without atomics in their path bit-identical, sums through atomics equal to 1e-5 (a race shows up as a run that
+    differs: the check that would have caught the round-1 weight-gradient kernel's race three rounds earlier)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'stability_sweep.py'), dtn, '6'], capture_output=True, text=True,
+                       timeout=600)
+    bad = [ln for ln in r.stdout.splitlines() if ' BAD ' in ln]
+    assert r.returncode == 0 and not bad, (bad, r.stdout[-600:], r.stderr[-600:])
