@@ -898,7 +898,8 @@ extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, con
   if (Tlog > 0 && ((Tlog - 1) * in_t_stride >= Tin || (Tlog - 1) * out_t_stride >= Tout)) return ISTGCN_EINVAL;
   if (stats && stats_rep < 1) return ISTGCN_EINVAL;
   if (NM == 0 || Tlog == 0) return ISTGCN_OK;
-  if (gcn_use_rc() && V <= 32 && !(stats && addend) && istgcn_gcn_rc_layout(Cin, Cout, K, dtype)) {
+  // (the 3-channel first-layer form of the register-chained kernel has no addend path: the round-2 kernels serve that call)
+  if (gcn_use_rc() && V <= 32 && !(stats && addend) && !(Cin == 3 && addend) && istgcn_gcn_rc_layout(Cin, Cout, K, dtype)) {
     const long long off = istgcn_gcn_rc_offset(Cin, Cout, K, dtype);
     if (off >= 0 && dtype != 0)
       return istgcn_gcn_fwd_rc(x, A, reinterpret_cast<const char*>(Wp) + (size_t)off * 2, bterm, addend, y, stats, stats_rep, NM, Tin,

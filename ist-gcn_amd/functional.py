@@ -156,10 +156,14 @@ def _pad_bneck(Ws, bs, Wt, bt, We, w, wp):
             None if bt is None else F.pad(bt, (0, p)), F.pad(We, (0, p)))
 
 
-def _bneck_rc(cfg, V, dt):
-    """Do the register-chained bottleneck kernels (csrc/bneck_rc.hip) serve this block?  16-bit storage, <= 15 taps, stride
-    1 or 2, V <= 32, 64 / 128 / 256 wide; `ops.BNECK_RC = False` (ISTGCN_BNECK_RC=0) keeps the generic temporal-conv kernels."""
-    return (ops.BNECK_RC and cfg.ksize <= 15 and cfg.stride in (1, 2) and
+def _bneck_rc(cfg, V, dt, rows=None):
+    """Do the register-chained bottleneck kernels (csrc/bneck_rc.hip) serve this block?  16-bit storage, stride <= taps <= 15
+    (every stride phase of the data gradient has a tap), stride 1 or 2, V <= 32, 64 / 128 / 256 wide, the wide tensor behind
+    one 4 GiB buffer descriptor (`rows` = N*M*T*V of the block's input); `ops.BNECK_RC = False` (ISTGCN_BNECK_RC=0) keeps the
+    generic temporal-conv kernels, which is also where every other shape goes."""
+    if rows is not None and rows * max(cfg.cout, cfg.cin) * 2 >= (1 << 32):
+        return False
+    return (ops.BNECK_RC and cfg.stride <= cfg.ksize <= 15 and cfg.stride in (1, 2) and
             ops.bneck_ok(V, cfg.cout, cfg.width, _pad_width(cfg.width, dt), dt))
 
 
@@ -313,7 +317,7 @@ class STGCNBlockFn(torch.autograd.Function):
             # 8- and 16-wide ones).  The narrow tensors are therefore stored with the width padded to whole vectors; the
             # padding channels carry zero weights and biases, so they ARE zeros and change nothing downstream.
             w, wp = cfg.width, _pad_width(cfg.width, dt)
-            if _bneck_rc(cfg, V, dt):
+            if _bneck_rc(cfg, V, dt, NM * T * V):
                 # 16-bit storage: two register-chained stream kernels (csrc/bneck_rc.hip) -- wide -> narrow, then
                 # narrow -> 15 taps -> narrow (saved) -> wide with the BatchNorm sums; weights read in place, no packs
                 q = ops.bneck_in(g, Ws, wp, bias=bs, pre=coef1[:2].contiguous(), pre_relu=True)
@@ -380,7 +384,7 @@ class STGCNBlockFn(torch.autograd.Function):
                                                                tail=(NM * Tz * V, g2, training))
         # (bottleneck blocks at 64 / 128 channels in 16-bit storage: dz is never written -- the stream kernel that consumes it
         #  forms it in registers from dres and z, dropout mask included; ops.BNECK_FUSE_BN = False keeps the separate pass)
-        fuse_in = (cfg.tcn == 'bneck' and ops.BNECK_FUSE_BN and _bneck_rc(cfg, V, dt) and
+        fuse_in = (cfg.tcn == 'bneck' and ops.BNECK_FUSE_BN and _bneck_rc(cfg, V, dt, NM * T * V) and
                    ops.bneck_bwd_in_ok(cout, cfg.width, _pad_width(cfg.width, dt), dt))
         dz = None if fuse_in else ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
@@ -417,7 +421,7 @@ class STGCNBlockFn(torch.autograd.Function):
                                 before_last=arm1)
         else:
             w, wp = cfg.width, _pad_width(cfg.width, dt)
-            rc = _bneck_rc(cfg, V, dt)
+            rc = _bneck_rc(cfg, V, dt, NM * T * V)
             if not rc:
                 Ws_, _, Wt_, _, We_ = _pad_bneck(Ws, None, Wt, None, We, w, wp)
             if fuse_in:
