@@ -170,8 +170,10 @@ def _bneck_rc(cfg, V, dt, rows=None):
 
 
 _EYE = {}
-# ISTGCN_WGRAD_SIDE=0: the temporal conv's weight gradient on the stream of the rest of the backward pass (A/B switch)
-WGRAD_SIDE_STREAM = os.environ.get('ISTGCN_WGRAD_SIDE', '1') != '0'
+# ISTGCN_WGRAD_SIDE=1: the temporal conv's weight gradient on a side stream next to the data gradient (off by default: 0.1-0.7 %
+# of a step on one GPU, and a data-gradient launch that shares the CUs with it no longer has a duration of its own -- the
+# per-kernel roofline of bench.py reads 0.27 instead of 0.38 for the same work)
+WGRAD_SIDE_STREAM = os.environ.get('ISTGCN_WGRAD_SIDE', '0') == '1'
 _SIDE = {}
 
 
