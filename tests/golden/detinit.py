@@ -99,10 +99,19 @@ def wide_unit_names(ci):
     return names + (['multi3', 'multi3fix', 'only3'] if ci == 0 else [])
 
 
-def wide_block_inputs(si, n=2):
+# Input seeds (salt of `x`) per (block kind, case), default 0.  A ReLU whose pre-activation is within fp32 round-off of zero
+# turns a strict fp32 gradient gate into a coin flip: which side it lands on depends on the summation order of the BatchNorm
+# batch sums (atomics on the GPU), and one flipped mask bit moves dx by 1e-2.  The reference output of (st_gcn_msgcn, w0) at
+# salt 0 had such an element -- |BN2(z) + res| = 5.3e-8 at scale 6.6 -- and tests/test_gpu_block.py::test_blocks_wide_golden
+# failed in 1 of 10 fresh processes (round 4).  tests/test_oracle_golden.py::test_wide_block_fixtures_have_no_knife_edge keeps
+# every fixture's smallest |pre-activation| above 2e-6.
+WIDE_X_SALT = {('st_gcn_msgcn', 0): 6}
+
+
+def wide_block_inputs(si, n=2, kind=None):
     cin, cout, stride, V = WIDE_BLOCKS[si]
     base = 'w%d.' % si
-    x = det_tensor('g3w.x' + base, (n, cin, WIDE_T, V))
+    x = det_tensor('g3w.x' + base, (n, cin, WIDE_T, V), salt=WIDE_X_SALT.get((kind, si), 0))
     r = det_tensor('g3w.r' + base, (n, cout, WIDE_T // stride, V))
     return x, r
 

@@ -273,9 +273,11 @@ def g2w_units():
     save('units_g2w.npz', **out)
 
 
-def g3w_blocks():
+def g3w_blocks(only=None):
     import importlib
     for kind, modname in BLOCK_KINDS.items():
+        if only and kind not in only:
+            continue                                       # (`g3w=kind[,kind]`: regenerate those files only)
         mod = importlib.import_module(modname)
         out = {}
         for si, (cin, cout, stride, V) in enumerate(WIDE_BLOCKS):
@@ -289,7 +291,7 @@ def g3w_blocks():
             sd = blk.state_dict()
             det_fill_(sd, salt=100 + si)
             blk.load_state_dict(sd)
-            x, r = wide_block_inputs(si)
+            x, r = wide_block_inputs(si, kind=kind)
             imps = [(0.5 + torch.rand((K, V, V), generator=torch.Generator().manual_seed(17 + j))).requires_grad_(True)
                     for j in range(3)]
             mst = (0.5 + torch.rand(3, generator=torch.Generator().manual_seed(21))).requires_grad_(True)
@@ -500,3 +502,6 @@ if __name__ == '__main__':
         g2w_units()
     if 'g3w' in what:
         g3w_blocks()
+    for w in what:
+        if w.startswith('g3w='):
+            g3w_blocks(w[4:].split(','))

@@ -190,7 +190,7 @@ def test_blocks_wide_golden(golden, kind, dt):
         gr = Graph('ntu-rgb+d' if V == 25 else 'openpose', 'spatial_3')
         A, A2, A3 = (torch.tensor(a, dtype=torch.float32, device=d) for a in (gr.A, gr.A2, gr.A3))
         K = A.shape[0]
-        x, r = wide_block_inputs(si)
+        x, r = wide_block_inputs(si, kind=kind)
         blk = mod.st_gcn(cin, cout, (9, K), stride, dropout=0, residual=True)
         blk.load_state_dict(det_fill_(blk.state_dict(), salt=100 + si), strict=True)
         blk.to(d)
