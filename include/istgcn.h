@@ -351,6 +351,12 @@ int istgcn_bn_tail_disarm(void);
 int istgcn_probe_mfma(const void* A, const void* Bt, float* D, int dtype, void* stream);
 int istgcn_probe_tr16(const void* src, int nelem, const int* lane_byte_off, void* out, void* stream);
 
+/* Dispatch trace (csrc/trace.hip; test instrumentation, own design -- the reference has no counterpart).  Off by default.
+ * op 1: switch the trace on and clear it; op 0: off and clear; op 2: write "count<TAB>kernel symbol\n" for every distinct
+ * kernel the library launched since the last clear into buf (NUL-terminated, at most cap bytes) and return the size of the
+ * full dump.  The parity tests use it to assert WHICH kernel variant served a shape (tests/gpu_util.py: launched()). */
+int istgcn_trace(int op, char* buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

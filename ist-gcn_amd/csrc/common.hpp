@@ -321,10 +321,16 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // hipGetLastError() is per-thread and sticky across *any* HIP call of the host process (PyTorch's allocator polls
 // events and leaves hipErrorNotReady behind): clear it before our launch so the check below sees only our own.
-#define ISTGCN_LAUNCH(...)            \
-  do {                                \
-    (void)hipGetLastError();          \
-    hipLaunchKernelGGL(__VA_ARGS__);  \
+// Dispatch trace (trace.hip; test instrumentation, off unless istgcn_trace(1) switched it on): every launch of the library
+// goes through this macro, so with the trace on the set of kernel symbols a call really launched can be read back --
+// tests assert which variant served a shape instead of trusting the dispatch predicates.
+extern "C" int istgcn_trace_on();
+extern "C" void istgcn_trace_note(const void* kfn, const char* launcher);
+#define ISTGCN_LAUNCH(k, ...)                                                        \
+  do {                                                                               \
+    (void)hipGetLastError();                                                         \
+    if (istgcn_trace_on()) istgcn_trace_note((const void*)(k), __PRETTY_FUNCTION__); \
+    hipLaunchKernelGGL(k, __VA_ARGS__);                                              \
   } while (0)
 
 // Workgroups of `kfn` resident on the whole device at once (occupancy x CUs).  The persistent kernels launch exactly

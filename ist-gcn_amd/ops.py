@@ -88,6 +88,44 @@ def _call(fn_name, *args, work=None, dev=None, family=None):
         raise RuntimeError('%s failed with code %d (%s)' % (fn_name, rc, why))
 
 
+def _trace_dump():
+    lib = _lib.load()
+    n = lib.istgcn_trace(2, None, 0)
+    buf = ctypes.create_string_buffer(n + 1)
+    lib.istgcn_trace(2, buf, n + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        cnt, name = line.split('\t', 1)
+        out[name] = int(cnt)
+    return out
+
+
+class trace:
+    """`with ops.trace() as tr: ...; tr.kernels` -> {kernel symbol: launches} of every kernel the library launched inside
+    the block (istgcn_trace, csrc/trace.hip: process-wide, test instrumentation; nests -- tests/conftest.py records every
+    GPU test's kernels around the test's own blocks).  `tr.ran('gcn_bwd_ws_kernel')`: a launched symbol contains that text."""
+    _depth = 0
+
+    def __enter__(self):
+        if trace._depth == 0:
+            _lib.load().istgcn_trace(1, None, 0)
+        trace._depth += 1
+        self._base = _trace_dump()
+        self.kernels = {}
+        return self
+
+    def __exit__(self, *exc):
+        now = _trace_dump()
+        self.kernels = {k: v - self._base.get(k, 0) for k, v in now.items() if v > self._base.get(k, 0)}
+        trace._depth -= 1
+        if trace._depth == 0:
+            _lib.load().istgcn_trace(0, None, 0)
+        return False
+
+    def ran(self, text):
+        return any(text in k for k in self.kernels)
+
+
 def _esz(t):
     return t.element_size()
 

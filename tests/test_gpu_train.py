@@ -1,0 +1,117 @@
+"""GPU: the training LOOP of processor/recognition.py:249-296 over many steps -- does 16-bit storage train?
+
+Every other parity test is one forward / backward.  Here `net/st_gcn_msgcn.py` (BASELINE config 2's model) is trained for a
+few hundred SGD-nesterov steps on a small synthetic task that can be learnt (class prototypes + noise), once per storage type
+on the HIP path -- float32, bfloat16, float16 with the static loss scale and the whole-step overflow skip -- from identical
+weights, batches and dropout seeds, and for its first steps on the CPU oracle.  Asserted: the fp32 HIP loss follows the
+oracle's step by step; every storage type learns the task (final loss far below ln(classes), accuracy on the training clips);
+the 16-bit runs end where the fp32 run ends; float16 skips no step after its warm-up."""
+import importlib
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import dev, OUT
+
+pytestmark = pytest.mark.gpu
+
+NC, N, T, V, BATCHES = 10, 8, 48, 25, 4
+GARGS = dict(layout='ntu-rgb+d', strategy='spatial_3')
+
+
+def make_task(seed=0):
+    """BATCHES batches of N clips (N,3,T,V,2): a class prototype (3,V) modulated over time + unit noise; labels."""
+    g = torch.Generator().manual_seed(seed)
+    proto = torch.randn(NC, 3, 1, V, 1, generator=g)
+    tmod = 1.0 + 0.5 * torch.sin(torch.linspace(0, 6.28, T)).view(1, 1, T, 1, 1)
+    xs, ys = [], []
+    for _ in range(BATCHES):
+        y = torch.randint(0, NC, (N,), generator=g)
+        x = proto[y] * tmod + torch.randn(N, 3, T, V, 2, generator=g)
+        xs.append(x)
+        ys.append(y)
+    return xs, ys
+
+
+def init_state(seed=0):
+    """one set of initial weights (recognition.py:31-44 through the oracle's restatement) shared by every run"""
+    from oracle import stgcn_ref as R
+    ref = R.RefModel('st_gcn_msgcn', 3, NC, GARGS, True, dropout=0.5)
+    R.weights_init_(ref, seed=seed)
+    return {k: v.clone() for k, v in ref.state_dict().items()}
+
+
+def run_hip(dt, steps, sd, xs, ys, dropout, lr=0.05):
+    from istgcn_amd import harness
+    d = dev()
+    m = importlib.import_module('istgcn_amd.net.st_gcn_msgcn').Model(3, NC, GARGS, True, dropout=dropout, compute_dtype=dt)
+    m.load_state_dict(sd)
+    m.to(d).train()
+    opt = harness.make_optimizer(m, base_lr=lr, loss_scale=65536.0 if dt == torch.float16 else 1.0)
+    xd, yd = [x.to(d) for x in xs], [y.to(d) for y in ys]
+    torch.manual_seed(1234)                                   # the per-forward dropout seeds are drawn from torch's generator
+    losses, scales = [], []
+    for i in range(steps):
+        losses.append(harness.train_step(m, opt, xd[i % BATCHES], yd[i % BATCHES]))
+        scales.append(opt.loss_scale)
+    losses = [float(l) for l in torch.stack(losses).cpu()]
+    m.eval()
+    with torch.no_grad():
+        acc = sum(int((m(x).argmax(1) == y).sum()) for x, y in zip(xd, yd)) / float(N * BATCHES)
+    skipped = opt.check_overflow()
+    return losses, acc, scales, skipped
+
+
+def test_training_loop_16bit_follows_fp32_and_the_oracle():
+    from oracle import stgcn_ref as R
+    xs, ys = make_task()
+    sd = init_state()
+    log = []
+    # ---- (a) fp32 HIP against the CPU oracle, dropout off, first steps of the loop
+    n_or = 10
+    ref = R.RefModel('st_gcn_msgcn', 3, NC, GARGS, True, dropout=0)
+    ref.load_state_dict(sd)
+    ropt = R.make_optimizer(ref, base_lr=0.05)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    l_or = [float(R.train_step(ref, ropt, xs[i % BATCHES], ys[i % BATCHES])[0]) for i in range(n_or)]
+    l_h0, _, _, _ = run_hip(torch.float32, n_or, sd, xs, ys, dropout=0)
+    dmax = max(abs(a - b) for a, b in zip(l_or, l_h0))
+    log.append('oracle   ' + ' '.join('%.5f' % v for v in l_or))
+    log.append('hip fp32 ' + ' '.join('%.5f' % v for v in l_h0) + '   max |diff| %.2e' % dmax)
+    # ---- (b) the loop itself in the three storage types, dropout 0.5 (same masks: same seeds), 240 steps
+    steps = 240
+    res = {}
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        res[dt] = run_hip(dt, steps, sd, xs, ys, dropout=0.5)
+        ls = res[dt][0]
+        log.append('%-8s first %.4f  mean[20:40] %.4f  mean[100:120] %.4f  mean[-20:] %.4f  acc %.3f  loss scale %g -> %g' % (
+            str(dt)[6:], ls[0], sum(ls[20:40]) / 20, sum(ls[100:120]) / 20, sum(ls[-20:]) / 20, res[dt][1], res[dt][2][0], res[dt][2][-1]))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, 'train_trajectory.txt'), 'w') as f:
+        f.write('\n'.join(log) + '\n')
+    # the same arithmetic, step by step: 10 steps of SGD amplify the fp32 summation-order differences only slightly
+    assert dmax < 2e-3, log[:2]
+    l32 = res[torch.float32][0]
+    end32 = sum(l32[-20:]) / 20
+    assert math.isfinite(end32) and end32 < 0.25 * math.log(NC) and res[torch.float32][1] > 0.9, log
+    for dt in (torch.bfloat16, torch.float16):
+        ls, acc, scales, skipped = res[dt]
+        end = sum(ls[-20:]) / 20
+        assert all(math.isfinite(v) for v in ls), dt
+        # ends where the fp32 run ends: within 5 % of it (+ 0.02 absolute: at the end the loss is a few hundredths and two
+        # runs of the SAME precision with other dropout seeds differ by that much)
+        assert abs(end - end32) <= 0.05 * end32 + 0.02, (dt, end, end32, log)
+        assert acc > 0.9, (dt, acc)
+        # monotone-ish: block means of 20 steps never rise by more than 10 % of the initial loss
+        blocks = [sum(ls[i:i + 20]) / 20 for i in range(0, steps, 20)]
+        assert all(b1 <= b0 + 0.1 * ls[0] for b0, b1 in zip(blocks, blocks[1:])), (dt, blocks)
+        # the early part of the trajectory is the fp32 one (before the runs decorrelate)
+        assert abs(sum(ls[:20]) - sum(l32[:20])) / 20 < 0.05 * ls[0], (dt, log)
+    # float16: a static scale of 65536 may overflow in the first steps (each overflow skips that whole step and the poll
+    # halves the scale); after the warm-up (64 steps = two polls) the scale stands still and nothing is skipped
+    sc = res[torch.float16][2]
+    assert sc[-1] == sc[64] and sc[-1] >= 256.0, sc[::32]
+    assert not res[torch.float16][3], 'an overflow was pending at the end of the float16 run'
