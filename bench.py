@@ -47,7 +47,7 @@ FAMILY = {'istgcn_tconv': 'tconv (temporal conv fwd + data-grad, MFMA implicit G
           'istgcn_bneck_wgrad': 'bneck_wgrad (+ taps: bottleneck weight gradients)'}
 
 
-PMC_KEY = {'istgcn_tconv': 'tconv kernels', 'istgcn_tconv_wgrad': 'twg_ws_kernel', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
+PMC_KEY = {'istgcn_tconv': 'tconv kernels', 'istgcn_tconv_wgrad': 'tconv_wgrad kernels', 'istgcn_gcn_fwd': 'gcn_rc_fwd_kernel',
            'istgcn_gcn_bwd_data': 'gcn_rc_bwd_kernel', 'istgcn_gcn_wgrad': 'gcn_rc_wgrad_kernel',
            'istgcn_block_out_fwd': 'block_out_fwd_kernel', 'istgcn_block_out_bwd': 'block_out_bwd_kernel',
            'istgcn_affine2': 'affine2_kernel', 'istgcn_bneck': 'bneck_in/out kernels', 'istgcn_bneck_wgrad': 'bneck_wgrad kernels'}
@@ -55,6 +55,34 @@ PMC_KEY = {'istgcn_tconv': 'tconv kernels', 'istgcn_tconv_wgrad': 'twg_ws_kernel
 # configs 1/3/4 -- SURVEY 8a; config 2 bf16, config 5 fp16); --dtype / --batch on the command line override.
 CONFIGS = {1: ('st_gcnold', 'f32', 2), 2: ('st_gcn_msgcn', 'bf16', 64), 3: ('st_gcn_mstcn_1x1', 'f32', 256),
            4: ('st_gcn_multi3_fix_3A_mstcn', 'f32', 64), 5: ('st_gcn_mstcn_1x1_deep', 'f16', 128)}
+
+
+# Whole-step roofline (measured there with FlopCounterMode on the reference): GFLOP per clip forward + backward
+# (= 3 x forward) as the REFERENCE executes them, and the compulsory HBM bytes per clip of the whole st_gcn block chain under
+# the 3-kernel train-BN fusion model, forward, per byte of element size (x 3 for forward + backward).
+STEP_WORK = {'st_gcnold': (102.6, 0.277 / 4), 'st_gcn_msgcn': (112.9, 0.138 / 2), 'st_gcn_mstcn_1x1': (22.4, 0.199 / 4),
+             'st_gcn_multi3_fix_3A_mstcn': (258.9, 0.277 / 4), 'st_gcn_mstcn_1x1_deep': (84.9, 0.357 / 2)}
+
+
+def vendor_gemm_tflops(dev, seconds=0.25):
+    """What the vendor GEMM (hipBLASLt through torch.matmul) sustains on THIS box, bf16, 8192^3, random operands: the
+    practical ceiling of an MFMA-bound kernel next to the 2.5 PFLOP/s dense peak the roofline divides by (the clock the
+    chip holds under matrix load is data dependent: all-zero operands run 1.3x faster, tools/gemm_peak.py)."""
+    a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    it = 0
+    e0.record()
+    t0 = time.perf_counter()
+    while it < 20 or (time.perf_counter() - t0 < seconds and it < 400):
+        torch.matmul(a, b)
+        it += 1
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * 8192 ** 3 * it / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
 
 
 def pmc_file(model, dtype, batch):
@@ -133,6 +161,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-vendor-gemm', action='store_true', help='skip the 0.3 s hipBLASLt reference measurement (16-bit runs)')
     ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
     ap.add_argument('--graph', action='store_true',
                     help='replay forward+backward from one hipGraph (harness.GraphedStep) in the timed region.  Measured: no gain\n'
@@ -201,6 +230,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ISTGCN_TRACE_KERNELS=<file>: the library's dispatch trace around the whole run -> "<config tag>\tlaunches\tkernel symbol"
+    # lines appended to <file> (tools/kernel_coverage.py: which kernels of the library the BASELINE configurations reach)
+    trace_file = os.environ.get('ISTGCN_TRACE_KERNELS') if rank == 0 else None
+    tracer = ops.trace() if trace_file else None
+    if tracer:
+        tracer.__enter__()
     use_graph = args.graph and not args.breakdown
     # graph mode: EVERY step of this process (eager warm-up, capture, replays, the eager roofline pass) runs on one side
     # stream -- capture is not allowed on the default stream, and autograd's gradient accumulators stay bound to the
@@ -253,6 +288,11 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_ONLY = None
     stack.close()
+    if tracer:
+        tracer.__exit__(None, None, None)
+        with open(trace_file, 'a') as f:
+            for k, nl in sorted(tracer.kernels.items()):
+                f.write('bench:%s/%s/b%d\t%d\t%s\n' % (args.model, args.dtype, B, nl, k))
     per_rank_ms = None
     if world > 1:
         # every rank's own clock around the same K steps (the line's time is their MAX), gathered through the job's
@@ -285,6 +325,7 @@ def main():
     # (tools/profile_bench.sh: FETCH_SIZE / WRITE_SIZE / SQ_* in separate rocprofv3 runs, corrected as MI355X_MICROARCH.md
     # prescribes; summary committed under profiles/) -- only for the configuration they were collected on
     roof['traffic'] = None
+    counter_bytes_step = None
     roof['algorithmic_bytes_per_launch'] = round(nbytes / n)
     pf = pmc_file(args.model, args.dtype, B)
     if pf and T == (600 if args.model.endswith('deep') else 300):
@@ -301,6 +342,7 @@ def main():
             roof['traffic'] = pmc.get('hbm_bytes_avg')
             roof['mfma_util'] = pmc.get('mfma_util')
             roof['pmc_source'] = os.path.relpath(pf, ROOT)
+            counter_bytes_step = summary.get('hbm_bytes_per_step')
     roof['kernel'] = FAMILY.get(dom, dom)
     roof['launches'] = n
     roof['avg_launch_ms'] = round(secs / n * 1e3, 4)
@@ -317,6 +359,22 @@ def main():
                 k, v[0], v[1] / args.steps * 1e3, 100 * v[1] / tot, v[2] / v[1] / 1e12, v[3] / v[1] / 1e9))
         sys.stderr.write('kernels %.2f ms/step of %.2f ms/step wall\n' % (tot / args.steps * 1e3, elapsed / args.steps * 1e3))
 
+    # ---- the whole step against ITS roofline: max(reference FLOPs / dense MFMA peak of the storage type, compulsory block
+    #      bytes / 8 TB/s) / measured step time (per GPU: weak scaling) ----
+    gf_clip, gb_clip_per_byte = STEP_WORK[args.model]
+    tscale = T / (600.0 if args.model.endswith('deep') else 300.0)
+    step_flops = gf_clip * 1e9 * B * tscale
+    step_bytes = gb_clip_per_byte * (2 if half else 4) * 3 * 1e9 * B * tscale
+    ms_f = step_flops / ((PEAK['mfma_bf16'] if half else PEAK['mfma_f32']) * 1e12) * 1e3
+    ms_b = step_bytes / (PEAK['hbm'] * 1e9) * 1e3
+    step_roof = {'flops_per_step': step_flops, 'bytes_per_step': step_bytes, 'ms_at_mfma_peak': round(ms_f, 3),
+                 'ms_at_hbm_peak': round(ms_b, 3), 'bound': 'hbm' if ms_b >= ms_f else 'mfma',
+                 'frac': round(max(ms_f, ms_b) / (elapsed / args.steps * 1e3), 4),
+                 'counter_bytes_per_step': counter_bytes_step,
+                 'source': 'SURVEY.md 8(d): reference FLOPs per clip (forward x 3), compulsory block bytes per clip x 3'}
+    if rank == 0 and half and not args.no_vendor_gemm:
+        roof['vendor_gemm_bf16_tflops'] = vendor_gemm_tflops(dev)
+        roof['frac_of_vendor_gemm'] = round(roof['achieved'] / roof['vendor_gemm_bf16_tflops'], 4) if roof['bound'] == 'mfma' else None
     if rank == 0:
         line = {
             'metric': 'skeleton-clips/sec fwd+bwd, NTU V=25 T=300',
@@ -336,7 +394,7 @@ def main():
                            'early_all_reduces_launched_from_backward': getattr(opt, 'early_launches', 0)},
                        'storage': ('%s activations, fp32 accumulate/params, fp64 BN sums%s' % (
                            args.dtype, ', static loss scale %g' % loss_scale if loss_scale != 1.0 else '')) if half else 'fp32'},
-            'roofline': roof, 'final_loss': round(loss_val, 4),
+            'roofline': roof, 'step_roofline': step_roof, 'final_loss': round(loss_val, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.model, T)

@@ -13,16 +13,6 @@
 // the (k,i) outputs of the current input-channel chunk are the MFMA rows.  Weight fragments stream from L2 one k-group
 // ahead of the MFMAs that consume them.
 #include "common.hpp"
-// Diagnostic hooks (ablation masks whose results are WRONG, in-kernel cycle stamps with their debug buffer) exist only in
-// experiment builds (-DISTGCN_EXPERIMENT through tools/build_variant.sh); the shipped library reads no such switch.
-#ifdef ISTGCN_EXPERIMENT
-#define X_ABL(P) ((P).abl)
-#define X_DBG(P) ((P).dbg)
-#else
-#define X_ABL(P) 0
-#define X_DBG(P) ((unsigned long long*)nullptr)
-#endif
-
 namespace {
 
 constexpr int NTHREADS = 256;
@@ -40,9 +30,6 @@ struct GbdParams {
   int NM, T, V, Cin, Cout, K, nnz_cap;
   int F, tiles_per_seq, total_tiles, CCi, nchi, CCc, nchc, NKGc, ds_stride;
   int off_rv, off_rkw, off_ra, off_dacc, off_rows, off_afrag, off_dys, off_dxa;
-  // wave-specialised kernel only
-  int off_dal, off_dy1, off_xb, off_img, abl;
-  unsigned long long* dbg;
 };
 
 template <typename T, int MTK, bool VEC, bool AGGM>
@@ -491,471 +478,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gcn_bwd_kernel(const GbdParams P)
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-specialised variant for the 16-bit trunk layers (V <= 32, K == 3, Cin and Cout multiples of 64).
-//
-// One 512-thread workgroup per CU walks the steps (tile, input chunk, output chunk) of its tiles:
-//   * waves 0-3 ("compute") contract the staged dy chunk with the step's weight fragments (registers, fetched from L2
-//     one step ahead), and at the last output chunk of an (tile, input chunk) ITEM write the K dxa images to LDS and
-//     aggregate them with A^T on the matrix cores into the dx image;
-//   * waves 4-7 ("memory") keep two dy chunks in flight in registers, commit chunk j+1 while chunk j is contracted,
-//     (x tile and the first half of the previous item's dx stores while the dxa images are written,)
-//     accumulate the adjacency gradient of item s (x tile^T . dxa images, one 16-channel slice per wave, on the matrix
-//     cores) while the compute waves aggregate it, and store dx (+ the residual addend) of item s while item s+1 is
-//     being contracted.
-// Barriers per step: one (chunk hand-over); per item two more (dxa free / dxa written).  Barriers are the raw
-// s_waitcnt lgkmcnt(0); s_barrier pair so the register prefetches stay in flight across them.
-constexpr int WB_NTH = 512, WB_NROLE = 256, WB_UV = 4;
-
-__device__ static inline void gb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// NCHC = output chunks per item (Cout / 64), a template parameter so that the memory waves' loop body is one fixed
-// sequence of loads and stores: with a run-time "is this the item's last chunk" branch the compiler cannot count the
-// loads in flight and every wait degrades to "all of them" (a full memory round trip per step).
-// RESW: one step per tile (Cin == Cout == 64) -- the weight fragments are loop-invariant and stay in registers.
-template <typename T, int NCHC, bool RESW>
-__global__ __launch_bounds__(WB_NTH, 2) void gcn_bwd_ws_kernel(const GbdParams P) {
-  using E = Elem<T>;
-  constexpr int EPL = E::EPL, KGS = E::KGS;
-  typedef typename E::frag frag_t;
-  static_assert(sizeof(T) == 2, "16-bit path");
-  constexpr int K = 3, CC = 64, NCH = CC / EPL, MTK = K * CC / 32, MH = MTK / 2, NTW = 2, NKG = CC / KGS, DS = CC + EPL;
-  constexpr int RB = DS * (int)sizeof(T);                  // bytes per staged row
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* dal = reinterpret_cast<float*>(smem + P.off_dal);                            // [K][V][V] workgroup sums of the adjacency gradient
-  // dxa images: [K][2 channel halves][TR rows][32 channels] = 64-byte rows, the 16-byte block index of a row XOR-swizzled
-  // by (row >> 1) & 3: the accumulator stores (32 consecutive rows, same channels) land 2-way instead of 16-way, the
-  // transposed reads of the aggregation stay conflict-free.  (+ 32 zero rows: the last frame's k-range overhang)
-  unsigned char* dxa = smem + P.off_dxa;
-  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);
-  // dx images of the items, [2][TR][DS] (item parity): the stores of item s-1 overlap the aggregation of item s
-
-  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63, ltid = tid & (WB_NROLE - 1);
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_mem = wave8 >= 4;
-  const int V = P.V, F = P.F;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-
-  // ---- setup: A^T fragments for the aggregation, the zero rows behind the last dxa image ----
-  {
-    for (int i = tid; i < K * V * V; i += WB_NTH) dal[i] = 0.f;
-    for (int idx = tid; idx < K * 2 * 64; idx += WB_NTH) {
-      const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
-      const int v = ln & 31, h = ln >> 5;
-      frag_t fr;
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        const int w = 16 * sstep + 8 * h + j;
-        fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
-      }
-      *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
-    }
-    for (int idx = tid; idx < 32 * 4; idx += WB_NTH) {
-      frag_t z;
-      zero_frag<T>(z);
-      *reinterpret_cast<frag_t*>(dxa + (size_t)K * 2 * TR * 64 + idx * 16) = z;
-    }
-    gb_barrier();
-  }
-  const T* dyg = reinterpret_cast<const T*>(P.dy);
-  const T* xg = reinterpret_cast<const T*>(P.x);
-  const T* Wb = reinterpret_cast<const T*>(P.Wb);
-  const T* addg = reinterpret_cast<const T*>(P.addend);
-  T* dxg = reinterpret_cast<T*>(P.dx);
-
-  const int bid = blockIdx.x, gx = gridDim.x;
-  const int ntile = bid < P.total_tiles ? (P.total_tiles - bid + gx - 1) / gx : 0;
-  const int spt = P.nchi * P.nchc;                         // steps per tile
-  const int nsteps = ntile * spt;
-  // adjacency gradient on the matrix cores: memory wave m owns channels [16m, 16m+16) of every item and keeps the dense
-  // 32x32 tiles dA_k[v][w] (its channel slice's share) in accumulators across the whole walk:
-  //     dA_k[v][w] += sum_f sum_i x[(f,v)][i] * dxa_k[(f,w)][i]
-  // Both operands are plain 16-byte reads (x rows; chunk-major dxa slots).  Rows/columns >= V collect the neighbouring
-  // frame and are never flushed.
-  f32x16 dacc[K];
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dacc[kk][r] = 0.f;
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) X_DBG(P)[6] = tlast - t_begin;
-#define BSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
-
-  if (!is_mem) {
-    // ================================================ compute role ================================================
-    const int ph = wave8 & 1, mh = wave8 >> 1;
-    f32x16 acc[MH][NTW];
-#pragma unroll
-    for (int m = 0; m < MH; ++m)
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
-    u32x4 WA[NKG][MH], WB[NKG][MH];
-    auto loadw = [&](int widx, u32x4 (&W)[NKG][MH]) __attribute__((always_inline)) {
-      const T* wf = Wb + ((size_t)widx * NKG * MTK * 64 + lane) * EPL;
-#pragma unroll
-      for (int kg = 0; kg < NKG; ++kg)
-#pragma unroll
-        for (int m = 0; m < MH; ++m) W[kg][m] = *reinterpret_cast<const u32x4*>(wf + (size_t)(kg * MTK + mh * MH + m) * 64 * EPL);
-    };
-    int widx = 0, cch = 0, par = 0;
-    int wofs[4];                                            // swizzled block offsets of this lane's accumulator stores
-#pragma unroll
-    for (int g = 0; g < 4; ++g) wofs[g] = (lane & 31) * 64 + ((g ^ (((lane & 31) >> 1) & 3)) << 4) + 8 * (lane >> 5);
-    const int boff = ((ph * 32 * NTW + (lane & 31)) * DS + (lane >> 5) * EPL) * (int)sizeof(T);
-    const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
-    const int q4 = (lane & 15) >> 2, pp = lane & 3, v = lane & 31;
-    auto cstep = [&](int j, const u32x4 (&Wc)[NKG][MH], u32x4 (&Wn)[NKG][MH]) __attribute__((always_inline)) {
-      const int wn = widx + 1 == spt ? 0 : widx + 1;
-      if constexpr (!RESW) loadw(wn, Wn);                   // next step's fragments: a whole step of lead
-      BSTAMP(5)
-      gb_barrier();                                         // chunk j staged
-      BSTAMP(0)
-      {
-        const unsigned char* bb = smem + ((j & 1) ? P.off_dy1 : P.off_dys) + boff;
-#pragma unroll
-        for (int kg = 0; kg < NKG; ++kg) {
-          frag_t bf[NTW];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) bf[t] = *reinterpret_cast<const frag_t*>(bb + (t * 32 * DS + kg * KGS) * (int)sizeof(T));
-#pragma unroll
-          for (int m = 0; m < MH; ++m)
-#pragma unroll
-            for (int t = 0; t < NTW; ++t) mma_kgroup(acc[m][t], __builtin_bit_cast(frag_t, Wc[kg][m]), bf[t]);
-        }
-      }
-      BSTAMP(1)
-      if (cch + 1 == NCHC) {
-        gb_barrier();                                       // dxa free (the memory waves finished the previous item's dot products)
-        BSTAMP(2)
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-          for (int m = 0; m < MH; ++m) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              // m-tile mt = (k, channel half); position p; channels 8g + 4*(lane>>5) .. +3 of the half
-              float v4[4] = {acc[m][t][4 * g], acc[m][t][4 * g + 1], acc[m][t][4 * g + 2], acc[m][t][4 * g + 3]};
-              store4(reinterpret_cast<T*>(dxa + ((mh * MH + m) * TR + ph * 32 * NTW + t * 32) * 64 + wofs[g]), v4);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[m][t][4 * g + r] = 0.f;
-            }
-          }
-        }
-        BSTAMP(3)
-        gb_barrier();                                       // dxa written
-        BSTAMP(2)
-        // transposed aggregation on the matrix cores: D[i][v] = sum_k sum_w dxa_k[(f,w)][i] * A_k[v][w]
-        // two (frame, 32-channel) units at a time (their MFMA chains interleave); the odd unit out goes alone
-        for (int pr = wave8; pr < F * 2; pr += 8) {
-          const bool two = pr + 4 < F * 2;
-          const int fa = pr >> 1, ct = pr & 1, fb = (pr + 4) >> 1;
-          f32x16 d0, d1;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-          const int blk = (cblk >> 3) + (pp >> 1), inb = 8 * (pp & 1);
-          T* const imgp = reinterpret_cast<T*>(smem + (par ? P.off_img + TR * RB : P.off_img));
-          // rows fV + 16*sstep + 8h + q4 (lo) and + 4 (hi: its swizzle differs in bit 1 of the block index)
-          auto unit_off = [&](int f, int sstep) __attribute__((always_inline)) {
-            const int rw = f * V + 16 * sstep + 8 * h + q4;
-            return (ct * TR + rw) * 64 + ((blk ^ ((rw >> 1) & 3)) << 4) + inb;
-          };
-          if (two) {
-#pragma unroll
-            for (int sstep = 0; sstep < 2; ++sstep) {
-              const int oa = unit_off(fa, sstep), ob = unit_off(fb, sstep);
-#pragma unroll
-              for (int k = 0; k < K; ++k) {
-                const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
-                const unsigned char* ka = dxa + k * 2 * TR * 64;
-                const frag_t a0 = tr_pair<T>(reinterpret_cast<const T*>(ka + oa), reinterpret_cast<const T*>(ka + (oa ^ 32) + 256));
-                const frag_t a1 = tr_pair<T>(reinterpret_cast<const T*>(ka + ob), reinterpret_cast<const T*>(ka + (ob ^ 32) + 256));
-                mma_kgroup(d0, a0, bfr);
-                mma_kgroup(d1, a1, bfr);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int sstep = 0; sstep < 2; ++sstep) {
-              const int oa = unit_off(fa, sstep);
-#pragma unroll
-              for (int k = 0; k < K; ++k) {
-                const frag_t bfr = *reinterpret_cast<const frag_t*>(afrag + ((k * 2 + sstep) * 64 + lane) * EPL);
-                const unsigned char* ka = dxa + k * 2 * TR * 64;
-                const frag_t a0 = tr_pair<T>(reinterpret_cast<const T*>(ka + oa), reinterpret_cast<const T*>(ka + (oa ^ 32) + 256));
-                mma_kgroup(d0, a0, bfr);
-              }
-            }
-          }
-          if (v < V) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int il = ct * 32 + 8 * g + 4 * (lane >> 5);
-              float v4[4] = {d0[4 * g], d0[4 * g + 1], d0[4 * g + 2], d0[4 * g + 3]};
-              store4(imgp + (fa * V + v) * DS + il, v4);
-              if (two) {
-                float w4[4] = {d1[4 * g], d1[4 * g + 1], d1[4 * g + 2], d1[4 * g + 3]};
-                store4(imgp + (fb * V + v) * DS + il, w4);
-              }
-            }
-          }
-        }
-        BSTAMP(4)
-        cch = 0;
-        par ^= 1;
-      } else {
-        ++cch;
-      }
-      widx = wn;
-    };
-    if (nsteps > 0) loadw(0, WA);
-    for (int j = 0; j < nsteps; j += 2) {
-      if constexpr (RESW) {
-        cstep(j, WA, WB);
-        if (j + 1 < nsteps) cstep(j + 1, WA, WB);
-      } else {
-        cstep(j, WA, WB);
-        if (j + 1 < nsteps) cstep(j + 1, WB, WA);
-      }
-    }
-    gb_barrier();                                           // the last item's dx image is complete
-    if (X_DBG(P) && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 6; ++i) X_DBG(P)[i] = tacc[i]; X_DBG(P)[7] = (unsigned long long)nsteps; }
-  } else {
-    // ================================================ memory role ================================================
-    const int q = ltid & 7, r0 = ltid >> 3;                 // this thread's 16-byte vector of a 64-channel row; rows r0 + 32u
-    // step / item cursors walk tile = bid + ti*gx as (sequence n, tile-in-sequence tq) without divisions
-    struct SC { int ti, ich, cch, n, tq, rows; size_t pos0; };
-    const int dn = gx / P.tiles_per_seq, dq = gx - dn * P.tiles_per_seq;
-    auto fill = [&](SC& c) __attribute__((always_inline)) {
-      if (c.ti < ntile) {
-        const int t0 = c.tq * F;
-        c.rows = min(F, P.T - t0) * V;
-        c.pos0 = (size_t)(c.n * P.T + t0) * V;
-      } else {
-        c.rows = 0; c.pos0 = 0;
-      }
-    };
-    auto place = [&](SC& c) __attribute__((always_inline)) {       // next tile of this workgroup
-      c.n += dn; c.tq += dq;
-      if (c.tq >= P.tiles_per_seq) { c.tq -= P.tiles_per_seq; ++c.n; }
-      fill(c);
-    };
-    auto adv = [&](SC& c) __attribute__((always_inline)) {
-      if (++c.cch == P.nchc) {
-        c.cch = 0;
-        if (++c.ich == P.nchi) { c.ich = 0; ++c.ti; place(c); }
-      }
-    };
-    auto adv_item = [&](SC& c) __attribute__((always_inline)) {
-      if (++c.ich == P.nchi) { c.ich = 0; ++c.ti; place(c); }
-    };
-    // fixed load counts (dead rows read the chunk's first row and are zeroed on commit)
-    auto issue_dy = [&](const SC& c, u32x4 (&R)[WB_UV]) __attribute__((always_inline)) {
-      const T* b = dyg + c.pos0 * P.Cout + c.cch * CC + q * EPL;
-#pragma unroll
-      for (int u = 0; u < WB_UV; ++u) R[u] = *reinterpret_cast<const u32x4*>(b + (r0 + 32 * u < c.rows ? (size_t)(r0 + 32 * u) * P.Cout : 0));
-    };
-    auto commit_rows = [&](int off, int rows, const u32x4 (&R)[WB_UV]) __attribute__((always_inline)) {
-      unsigned char* d = smem + off + q * 16;
-#pragma unroll
-      for (int u = 0; u < WB_UV; ++u) {
-        const int r = r0 + 32 * u;
-        u32x4 vv = R[u];
-        if (r >= rows) vv = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<u32x4*>(d + r * RB) = vv;
-      }
-    };
-    // (a null tensor still issues its loads -- from the start of dy -- so the count in flight never depends on a branch)
-    auto issue_rows = [&](const T* g, const SC& c, u32x4 (&R)[WB_UV]) __attribute__((always_inline)) {
-      const bool live = g != nullptr;
-      const T* b = live ? g + c.pos0 * P.Cin + c.ich * CC + q * EPL : dyg + q * EPL;
-#pragma unroll
-      for (int u = 0; u < WB_UV; ++u) R[u] = *reinterpret_cast<const u32x4*>(b + (live && r0 + 32 * u < c.rows ? (size_t)(r0 + 32 * u) * P.Cin : 0));
-    };
-    u32x4 ZA[WB_UV], ZB[WB_UV], XR[WB_UV], AR[WB_UV];
-    SC c0{0, 0, 0, 0, 0, 0, 0}, c1, c3, ix, ia, ist;
-    c0.n = bid / P.tiles_per_seq;
-    c0.tq = bid - c0.n * P.tiles_per_seq;
-    fill(c0);
-    ix = c0; ia = c0; ist = c0;                             // item cursors: next x tile to commit, next addend, next dx store
-    // prologue: chunk 0 synchronously, chunks 1 and 2 in flight; x and addend of item 0 in flight
-    issue_dy(c0, ZA);
-    c1 = c0; adv(c1);
-    issue_dy(c1, ZB);
-    issue_rows(P.dA ? xg : nullptr, ix, XR);
-    issue_rows(addg, ia, AR);
-    commit_rows(P.off_dys, c0.rows, ZA);
-    c3 = c1; adv(c3);
-    issue_dy(c3, ZA);
-    adv(c3);
-    bool first = true;                                      // no dx image pending yet
-    int item_par = 0;                                       // parity of the item being contracted
-    int spar = 0;                                           // parity of the item whose dx image is pending
-    // dx image (+ addend) -> HBM, whole 16-byte vectors of contiguous rows; in two halves (rows r0 + 32u, u in [u0, u0+2))
-    auto store_half = [&](int u0) __attribute__((always_inline)) {
-      T* ob = dxg + ist.pos0 * P.Cin + ist.ich * CC + q * EPL;
-      const unsigned char* ib = smem + (spar ? P.off_img + TR * RB : P.off_img) + q * 16;
-      const int srows = first ? 0 : ist.rows;
-#pragma unroll
-      for (int uu = 0; uu < 2; ++uu) {
-        const int u = u0 + uu;
-        const int r = r0 + 32 * u;
-        if (r < srows) {
-          frag_t o = *reinterpret_cast<const frag_t*>(ib + r * RB);
-          if (addg) {
-            const frag_t av = __builtin_bit_cast(frag_t, u == 0 ? AR[0] : u == 1 ? AR[1] : u == 2 ? AR[2] : AR[3]);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] = E::from_f(E::to_f(o[e]) + E::to_f(av[e]));
-          }
-          *reinterpret_cast<frag_t*>(ob + (size_t)r * P.Cin) = o;
-        }
-      }
-    };
-    auto store_done = [&]() __attribute__((always_inline)) {
-      if (!first) { adv_item(ist); adv_item(ia); }
-      first = false;
-      issue_rows(addg, ia, AR);                             // the next item's addend: a whole item of lead
-    };
-    auto mstep = [&](int j, u32x4 (&Zn)[WB_UV], const bool item_end) __attribute__((always_inline)) {
-      BSTAMP(5)
-      gb_barrier();                                         // chunk j handed over
-      BSTAMP(0)
-      commit_rows((j & 1) ? P.off_dys : P.off_dy1, c1.rows, Zn);        // chunk j+1 -> the buffer chunk j-1 was read from
-      issue_dy(c3, Zn);
-      adv(c0); adv(c1); adv(c3);
-      BSTAMP(2)
-      if (item_end) {
-        gb_barrier();                                       // (dxa free: nothing of ours pending on it)
-        BSTAMP(0)
-        commit_rows(P.off_xb, P.dA ? ix.rows : 0, XR);
-        adv_item(ix);
-        issue_rows(P.dA ? xg : nullptr, ix, XR);
-        BSTAMP(3)
-        store_half(0);                                      // previous item's dx image, first half
-        BSTAMP(1)
-        gb_barrier();                                       // dxa written, x tile staged
-        BSTAMP(0)
-        if (P.dA && !(X_ABL(P) & 1)) {
-          const int mw = wave8 - 4;
-          const unsigned char* xa = smem + P.off_xb + ((lane & 31) * DS + 16 * mw + 8 * (lane >> 5)) * (int)sizeof(T);
-          const unsigned char* db = dxa + (mw >> 1) * TR * 64;
-          const int blk = 2 * (mw & 1) + (lane >> 5);
-          for (int f = 0; f < F; ++f) {
-            const frag_t a = *reinterpret_cast<const frag_t*>(xa + f * V * RB);
-            const int rw = f * V + (lane & 31);
-            const int o = rw * 64 + ((blk ^ ((rw >> 1) & 3)) << 4);
-#pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-              const frag_t b = *reinterpret_cast<const frag_t*>(db + kk * 2 * TR * 64 + o);
-              mma_kgroup(dacc[kk], a, b);
-            }
-          }
-        }
-        BSTAMP(4)
-        store_half(2);
-        store_done();
-        BSTAMP(1)
-        spar = item_par;
-        item_par ^= 1;
-      }
-    };
-    constexpr int BODY = NCHC == 1 ? 2 : NCHC;              // steps per loop body: whole items, an even number of steps
-    static_assert(BODY % 2 == 0, "register sets alternate per step");
-    for (int j = 0; j < nsteps; j += BODY) {
-#pragma unroll
-      for (int b = 0; b < BODY; ++b) {
-        if (NCHC == 1 && b == 1 && j + 1 >= nsteps) break;
-        const bool ie = (b % NCHC) == NCHC - 1;
-        if (b & 1) mstep(j + b, ZA, ie); else mstep(j + b, ZB, ie);
-      }
-    }
-    gb_barrier();
-    store_half(0);
-    store_half(2);
-    if (X_DBG(P) && blockIdx.x == 0 && ltid == 0) for (int i = 0; i < 6; ++i) X_DBG(P)[8 + i] = tacc[i];
-  }
-#undef BSTAMP
-
-  // ---- adjacency gradient: the four channel-slice shares -> workgroup sums (LDS) -> global, pattern entries only ----
-  const unsigned long long t_flush = __builtin_amdgcn_s_memtime();
-  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) X_DBG(P)[14] = t_flush - t_begin;
-  if (P.dA) {
-    if (is_mem) {
-      const int w = lane & 31;
-#pragma unroll
-      for (int kk = 0; kk < K; ++kk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int vv = mfma_row(r, lane);
-          if (vv < V && w < V) atomicAdd(dal + (kk * V + vv) * V + w, dacc[kk][r]);
-        }
-    }
-    gb_barrier();
-    const float* patg = P.pat ? P.pat : P.A;
-    for (int e = tid; e < K * V * V; e += WB_NTH)
-      if (patg[e] != 0.f) atomicAdd(P.dA + e, dal[e]);
-  }
-  if (X_DBG(P) && blockIdx.x == 0 && tid == 0) { __builtin_amdgcn_s_waitcnt(0); X_DBG(P)[15] = __builtin_amdgcn_s_memtime() - t_begin; }
-}
-
-template <typename T, int NCHC, bool RESW>
-int launch_ws_n(GbdParams& P, int grid_cap, hipStream_t stream) {
-  if constexpr (sizeof(T) != 2) return -1;
-  else {
-    static const int forced = [] { const char* e = getenv("ISTGCN_GCNBWD_WS"); return e ? atoi(e) : -1; }();
-    if (forced == 0) return -1;
-    if (P.V > 32 || P.K != 3 || P.Cin % 64 || P.Cout % 64 || P.CCi != 64 || P.CCc != 64) return -1;
-    const int esz = 2, ds = 64 + 8;
-    size_t off = 0;
-    P.off_dal = (int)off; off += (size_t)P.K * P.V * P.V * 4;
-    off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)P.K * 2 * 64 * 16;
-    const size_t tileb = (size_t)TR * ds * esz;
-    off = (off + 15) & ~(size_t)15; P.off_dys = (int)off; off += tileb;
-    P.off_dy1 = (int)off; off += tileb;
-    P.off_xb = (int)off; off += tileb;
-    P.off_img = (int)off; off += 2 * tileb;
-    P.off_dxa = (int)off; off += ((size_t)P.K * 2 * TR + 32) * 64;
-    if (off > 160 * 1024) return -1;
-    auto kfn = gcn_bwd_ws_kernel<T, NCHC, RESW>;
-    static std::atomic<unsigned long long> optin{0};
-    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
-    int gx = grid_cap > 0 ? grid_cap : istgcn_resident_blocks((const void*)kfn, WB_NTH, off);
-    gx = gx < 1 ? 1 : (gx > P.total_tiles ? P.total_tiles : gx);
-    unsigned long long* dbuf = nullptr;
-#ifdef ISTGCN_EXPERIMENT
-    { const char* e = getenv("ISTGCN_GCNBWD_ABL"); P.abl = e ? atoi(e) : 0; }
-    if (getenv("ISTGCN_GCNBWD_DBG")) {
-      static unsigned long long* dbuf_s = nullptr;
-      if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
-      dbuf = dbuf_s;
-      (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
-      P.dbg = dbuf;
-    }
-#endif
-    ISTGCN_LAUNCH(kfn, dim3(gx), dim3(WB_NTH), off, stream, P);
-    ISTGCN_CHECK_LAUNCH();
-    if (dbuf) {
-      unsigned long long h[16];
-      (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, stream);
-      (void)hipStreamSynchronize(stream);
-      fprintf(stderr, "gcn_bwd_ws dbg Cin=%d Cout=%d steps/wg=%llu | compute: wait %llu contract %llu wait(dxa) %llu write %llu aggregate %llu wload %llu | memory: wait %llu store %llu commit+issue %llu xcommit %llu dots %llu top %llu | setup %llu walk-end %llu end %llu\n",
-              P.Cin, P.Cout, h[7], h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13], h[6], h[14], h[15]);
-    }
-    return ISTGCN_OK;
-  }
-}
-
-template <typename T>
-int launch_ws(GbdParams& P, int grid_cap, hipStream_t stream) {
-  switch (P.nchc) {
-    case 1: return P.nchi == 1 ? launch_ws_n<T, 1, true>(P, grid_cap, stream) : launch_ws_n<T, 1, false>(P, grid_cap, stream);
-    case 2: return launch_ws_n<T, 2, false>(P, grid_cap, stream);
-    case 4: return launch_ws_n<T, 4, false>(P, grid_cap, stream);
-    default: return -1;
-  }
-}
-
 struct GbdGeom { int CCi, nchi, CCc, nchc, NKGc, KKp, MTK; };
 
 inline void gbd_geom(int Cin, int Cout, int K, int dtype, GbdGeom* G) {
@@ -999,11 +521,6 @@ int launch_T(GbdParams& P, const GbdGeom& G, int grid_cap, hipStream_t stream) {
   P.F = TR / P.V;
   P.tiles_per_seq = ceil_div(P.T, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  {
-    GbdParams Q = P;
-    const int rc = launch_ws<T>(Q, grid_cap, stream);
-    if (rc >= 0) return rc;
-  }
   const int wide = P.CCc > P.CCi ? P.CCc : P.CCi;
   P.ds_stride = wide + epl;
   size_t off = (size_t)(P.V + 1) * 4;
@@ -1062,12 +579,9 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
   {
     // dispatch override ISTGCN_GCN_RC=0 (the round-2 kernels: A/B timing, one process per setting), read once
     static const bool rc_on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
-#ifdef ISTGCN_EXPERIMENT
-    static const bool rc_split = getenv("ISTGCN_RC_SPLIT") != nullptr;     // the split-role variant for 256 channels with dA (measured slower)
-#else
-    constexpr bool rc_split = false;
-#endif
-    if (rc_on && V <= 32 && !(dA && Cout > 128 && !rc_split) && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
+    // (round 5: 256 output channels WITH the adjacency gradient too -- H' transposed from H, gcn_rc_bwd.hip; the
+    //  wave-specialised round-2 kernel that served them is gone)
+    if (rc_on && V <= 32 && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
         (Cin != 3 ? dx != nullptr : (!dx && dA && !addend))) {
       const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
       if (off >= 0)

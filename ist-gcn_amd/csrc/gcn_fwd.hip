@@ -881,11 +881,7 @@ static bool gcn_use_rc() {       // dispatch override ISTGCN_GCN_RC=0 (A/B timin
   static const bool on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
   return on;
 }
-static bool gcn_use_v1(int dtype) {
-  static const int forced = [] { const char* e = getenv("ISTGCN_GCN_V1"); return e ? atoi(e) : -1; }();
-  if (forced == 0 || forced == 1) return forced == 1;
-  return dtype == 0;
-}
+static bool gcn_use_v1(int dtype) { return dtype == 0; }      // float32: the round-1 kernel (gcn_fwd_small.hip)
 
 extern "C" int istgcn_gcn_fwd(const void* x, const float* A, const void* Wp, const float* bterm,
                               const void* addend, void* y, double* stats, int stats_rep, int* status,

@@ -16,6 +16,17 @@
 // image.  The W fragments are packed with the channel of MFMA row / column r permuted (bits 2 and 3 of r swapped) so that
 // H' converted pairwise carries the channels of a k-step in memory order: its partner, x, is then a plain 16-byte load.
 // dA_k^T lives in 16 accumulator registers per partition for the whole walk and is reduced once per workgroup.
+//
+// Round 5: where a wave computes BOTH chains, H' is no longer a second contraction (SO MFMAs per partition) but the
+// exact transpose of the converted H: the register pairs of H that feed `dx += A_k . H` as a B operand, read as an A operand
+// (rows = channel, k = joints in the chained order), times an identity fragment in the same k order -- two MFMAs, x * 1.0
+// summed with zeros in fp32 and converted back: bit-exact 16-bit values.  Per (frame, tile, partition) SO + 6 MFMAs instead
+// of 2 SO + 4 (256 output channels: 22 instead of 36), the second accumulator chain starts from registers instead of LDS
+// fragments, and the 256-channel layers with the adjacency gradient fit one wave (no split roles, no round-2 kernel).
+// Measured (bf16, NM = 128, per call, second contraction -> identity transpose; tools/ab_gbwd.sh): 64 -> 64 118 -> 113 us,
+// 64 -> 128 152-167 -> 139-142, 128 -> 128 156 -> 145, 128 -> 256 216 (round-2 kernel) -> 190-197, 256 -> 256 215-220
+// (round-2 kernel) -> 202: less than the MFMA count promises -- the walk is bound by the weight fragments' LDS reads
+// (one 1 KB fragment per contraction MFMA) and the chains' latency, not by the matrix pipe.
 #include "gcn_rc.hpp"
 #include <type_traits>
 
@@ -44,13 +55,14 @@ constexpr int BIMG_BYTES = 16 * BIMG_RS * 4;
 __device__ static inline int perm23(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
 
 // SO = Cout / 16 (k-steps of the contraction over output channels), NCT = 32-channel tiles of dx per workgroup slice,
-// DA / ADD = with the adjacency gradient / with an addend, SPLIT = dx and dA on separate waves (see below).
-template <typename T, int SO, int K, int NCT, bool DA, bool ADD, bool SPLIT, int CN>
+// DA / ADD = with the adjacency gradient / with an addend.
+// (HIP: the second launch bound is WAVES PER SIMD -- 2 = the 8 waves of one workgroup per CU, 256 registers each)
+template <typename T, int SO, int K, int NCT, bool DA, bool ADD, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams P) {
   // CN != 0: the models' first layer (CN = 3 input channels, net/st_gcnold.py:44).  Its input needs no gradient, so only
   // the adjacency gradient is computed (no dx chain, no image, no stores): one zero-padded 32-channel tile per frame,
   // x rows read with 16-bit loads.
-  static_assert(CN == 0 || (NCT == 1 && DA && !ADD && !SPLIT && CN <= 4), "narrow input: dA only");
+  static_assert(CN == 0 || (NCT == 1 && DA && !ADD && CN <= 4), "narrow input: dA only");
   using E = Elem<T>;
   typedef typename E::frag frag_t;
   constexpr int COUT = 16 * SO;
@@ -63,13 +75,11 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Roles.  SPLIT: waves 0-3 compute dx tiles, waves 4-7 the dA products (equal matrix work, no hand-off; each role has
-  // the registers for a whole-frame prefetch).  Otherwise every wave does both for its (frame, tile) and the W fragment
-  // read from LDS feeds two MFMAs; at >= 128 output channels that form has no registers for a second dy set and reloads
-  // dy in place after its last use (PF2 = false).
-  constexpr int NWR = SPLIT ? 4 : 8;                          // waves per role
-  const int role = SPLIT ? wave8 / 4 : 0;                     // SPLIT: 0 dx, 1 dA
-  const int wr = wave8 % NWR;
+  // Every wave runs both chains for its (frame, tile).  At >= 128 output channels there are no registers for a second dy
+  // set: dy is reloaded in place right after its last use (PF2 = false); at 256 x likewise.  (Round 3's split-role form for
+  // 256 channels -- dx waves / dA waves -- measured slower than the round-2 kernel and went with it in round 5.)
+  constexpr int NWR = 8;
+  const int wr = wave8;
   const int itl = wr % NCT, fwl = wr / NCT;
   const int b = blockIdx.x;
   const int slice = (b >> 3) % P.gy;
@@ -102,6 +112,18 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
     adl[idx] = __builtin_bit_cast(u32x4, f);
   }
   __syncthreads();
+  // identity in the chained k order: as a B operand, lane (n, h), k-step s, element j is [joint 16s + 8(j>>2) + 4h + (j&3) == n].
+  // Per-lane constants: in 8 registers, or (IDL: 256 output channels, where every register counts) in LDS behind the A fragments
+  constexpr bool IDL = SO >= 16;
+  u32x4 idf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    frag_t f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = E::from_f((16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) == c ? 1.f : 0.f);
+    idf[s] = __builtin_bit_cast(u32x4, f);
+    if constexpr (IDL) adl[(2 * K + s) * 64 + lane] = idf[s];          // (each lane reads back its own entry: no barrier needed)
+  }
 
   const T* dyg = reinterpret_cast<const T*>(P.dy);
   const T* xg = reinterpret_cast<const T*>(P.x);
@@ -148,6 +170,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   auto frame = [&](auto dx_tag, auto da_tag, auto reload_tag, int fn, int ft, u32x4 (&df)[SO], u32x4 (&xf)[2], int n2,
                    int t2) __attribute__((always_inline)) {
     constexpr bool DX = decltype(dx_tag)::value, DAF = decltype(da_tag)::value, RELOAD = decltype(reload_tag)::value;
+    constexpr bool TRI = DX && DAF;                           // H' from the converted H (both chains on this wave)
     f32x16 Y;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       for (int s = 0; s < SO; ++s) {
         const u32x4 wv = wlane[(k * SO + s) * 64];
         if constexpr (DX) mma_kgroup(H, __builtin_bit_cast(frag_t, df[s]), __builtin_bit_cast(frag_t, wv));
-        if constexpr (DAF) mma_kgroup(HT, __builtin_bit_cast(frag_t, wv), __builtin_bit_cast(frag_t, df[s]));
+        if constexpr (DAF && !TRI) mma_kgroup(HT, __builtin_bit_cast(frag_t, wv), __builtin_bit_cast(frag_t, df[s]));
       }
       if constexpr (RELOAD) {
         if (k == K - 1) load_dy(n2, t2, df);
@@ -175,6 +198,16 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
         }
         mma_kgroup(Y, __builtin_bit_cast(frag_t, adl[(2 * k) * 64 + lane]), __builtin_bit_cast(frag_t, hb[0]));
         mma_kgroup(Y, __builtin_bit_cast(frag_t, adl[(2 * k + 1) * 64 + lane]), __builtin_bit_cast(frag_t, hb[1]));
+        if constexpr (TRI) {
+          // H'[i][w] = sum over joints of (converted H as the A operand: rows = channel, k = joint) x identity
+          if constexpr (IDL) {
+            mma_kgroup(HT, __builtin_bit_cast(frag_t, hb[0]), __builtin_bit_cast(frag_t, adl[(2 * K) * 64 + lane]));
+            mma_kgroup(HT, __builtin_bit_cast(frag_t, hb[1]), __builtin_bit_cast(frag_t, adl[(2 * K + 1) * 64 + lane]));
+          } else {
+            mma_kgroup(HT, __builtin_bit_cast(frag_t, hb[0]), __builtin_bit_cast(frag_t, idf[0]));
+            mma_kgroup(HT, __builtin_bit_cast(frag_t, hb[1]), __builtin_bit_cast(frag_t, idf[1]));
+          }
+        }
       }
       if constexpr (DAF) {
         u32x4 ht[2];
@@ -186,6 +219,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
         if constexpr (CN == 0) mma_kgroup(Z[k], __builtin_bit_cast(frag_t, ht[1]), __builtin_bit_cast(frag_t, xf[1]));
       }
     }
+    if constexpr (RELOAD && TRI && SO >= 16) load_x(n2, t2, xf);      // (one x set: refilled right after its last use, like dy)
     if constexpr (DX) {
       // dx tile -> pair-row image (column c of the tile is channel perm23(c)) -> 16-byte row vectors -> HBM
 #pragma unroll
@@ -260,6 +294,16 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
         if (!more2) break;
         n = n2; t = t2;
       }
+    } else if constexpr (DAF && decltype(dx_tag)::value && SO >= 16) {
+      // 256 output channels, both chains: ONE set of dy and ONE of x, each refilled by frame() right after its last use
+      for (;;) {
+        int n2 = n, t2 = t;
+        next(n2, t2);
+        const bool more = n2 < P.NM;
+        frame(dx_tag, da_tag, reload_t{}, n, t, da, xa, more ? n2 : n, more ? t2 : t);
+        if (!more) break;
+        n = n2; t = t2;
+      }
     } else {
       for (;;) {
         int n2 = n, t2 = t;
@@ -284,26 +328,20 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   typedef std::false_type no;
   if constexpr (CN != 0) walk(no{}, yes{}, yes{});
   else if constexpr (!DA) walk(yes{}, no{}, yes{});
-  else if constexpr (!SPLIT) walk(yes{}, yes{}, std::integral_constant<bool, (SO <= 4)>{});
-  else {
-    if (role == 0) walk(yes{}, no{}, yes{});
-    else walk(no{}, yes{}, yes{});
-  }
+  else walk(yes{}, yes{}, std::integral_constant<bool, (SO <= 4)>{});
 
   // ---- adjacency gradient: Z[k] (rows w in registers, lane = v) of the waves -> LDS -> one atomic per pattern entry ----
   if constexpr (DA) {
-    constexpr int NZ = SPLIT ? 4 : 8;                         // waves that hold partial sums
+    constexpr int NZ = 8;                                     // waves that hold partial sums
     __syncthreads();                                          // every wave is done with the weights and its image
     float* red = reinterpret_cast<float*>(smem);              // [NZ][K][32][32]
-    if (!SPLIT || role == 1) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+    for (int k = 0; k < K; ++k)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int w = (i & 3) + 8 * (i >> 2) + 4 * h;
-          red[((wr * K + k) * 32 + w) * 32 + c] = Z[k][i];
-        }
-    }
+      for (int i = 0; i < 16; ++i) {
+        const int w = (i & 3) + 8 * (i >> 2) + 4 * h;
+        red[((wr * K + k) * 32 + w) * 32 + c] = Z[k][i];
+      }
     __syncthreads();
     const float* pat = P.pat ? P.pat : P.A;
     for (int e = tid; e < K * V * V; e += RC_NTH) {
@@ -320,11 +358,9 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
 
 template <typename T, int SO, int K, int NCT, bool DA, bool ADD, int CN = 0>
 int rc_bwd_launch(RcBwdParams P, int grid_cap, hipStream_t stream) {
-  // 256 output channels: 64 operand registers of dy next to the 48 of dA^T do not fit one wave -> roles on separate waves
-  constexpr bool SPLIT = DA && SO > 8 && CN == 0;
-  auto kfn = gcn_rc_bwd_kernel<T, SO, K, NCT, DA, ADD, SPLIT, CN>;
-  size_t lds = (size_t)NCT * K * SO * 64 * 16 + 8 * BIMG_BYTES + (size_t)K * 2 * 64 * 16;
-  if (DA && (size_t)(SPLIT ? 4 : 8) * K * 32 * 32 * 4 > lds) lds = (size_t)(SPLIT ? 4 : 8) * K * 32 * 32 * 4;
+  auto kfn = gcn_rc_bwd_kernel<T, SO, K, NCT, DA, ADD, CN>;
+  size_t lds = (size_t)NCT * K * SO * 64 * 16 + 8 * BIMG_BYTES + (size_t)(K + 1) * 2 * 64 * 16;      // (+ the identity fragments)
+  if (DA && (size_t)8 * K * 32 * 32 * 4 > lds) lds = (size_t)8 * K * 32 * 32 * 4;
   if (lds > 160 * 1024) return ISTGCN_EINVAL;
   static std::atomic<unsigned long long> optin{0};
   if (int ea = istgcn_lds_optin((const void*)kfn, optin)) return ea;
@@ -333,7 +369,7 @@ int rc_bwd_launch(RcBwdParams P, int grid_cap, hipStream_t stream) {
   int G = res / P.gy / 8 * 8;
   if (G < 8) G = 8;
   const long long frames = (long long)P.NM * P.T;
-  const int fwpg = (SPLIT ? 4 : 8) / NCT;       // frame workers per group and role
+  const int fwpg = 8 / NCT;                     // frame workers per group
   while (G > 8 && (long long)(G - 8) * fwpg >= frames) G -= 8;
   P.nfw = G * fwpg;
   P.step_n = P.nfw / P.T;

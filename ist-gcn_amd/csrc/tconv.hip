@@ -742,13 +742,12 @@ template <typename T, int MT, int NT, int WM>
 int launch4(const TconvParams& P, int grid_cap, int gy, size_t lds, hipStream_t stream) {
   const bool vec = (P.Cin % Elem<T>::EPL) == 0 && (P.Cout % Elem<T>::EPL) == 0;
   // static k-structure (see the kernel): 16-bit storage, whole channel vectors, two k-groups per tap, taps in threes
-  static const bool sk_off = [] { const char* e = getenv("ISTGCN_TCONV_SK"); return e && atoi(e) == 0; }();
   // Where it pays (measured, us generic -> SK at NM=128, bf16; profiles/r03_tconv_static_k.txt): the data gradient at every
   // width (64 ch 136 -> 126, 128 ch 183 -> 171, 256 ch 287 -> 270) and the 64-channel forward (117 -> 113).  NOT the
   // 128 / 256-channel forward (145 -> 152, 258 -> 272): there the memory waves' BatchNorm + ReLU transform is vector-ALU
   // work on the same SIMDs, the denser MFMA stream starves it (stamps: `commit` 2297 -> 3857 ticks at 256 channels) and
   // the compute waves end up waiting longer at the item barrier than the leaner loop saved.
-  const bool sk = sizeof(T) == 2 && vec && P.NKG == 2 && P.ntaps % 3 == 0 && !sk_off && (P.mode == 1 || (P.mode == 0 && MT == 2));
+  const bool sk = sizeof(T) == 2 && vec && P.NKG == 2 && P.ntaps % 3 == 0 && (P.mode == 1 || (P.mode == 0 && MT == 2));
 #define GO(VV, MD, SKV)                                                                                      \
   do {                                                                                                      \
     auto kfn = tconv_kernel<T, MT, NT, VV, MD, WM, SKV>;                                                    \
@@ -812,11 +811,8 @@ extern "C" int istgcn_tconv_v1(const void* in, const void* Wp, const float* bias
                                int NM, int Tin, int Tout, int Mlog, int V, int Cin, int Cout, int ntaps,
                                const int* tap_off, int in_mul, int out_mul, int out_off, int dtype, int grid_cap,
                                void* stream);
-// Which kernel serves a shape (the packed-weight geometry follows the same decision).  ISTGCN_TCONV_V1=0/1 forces one
-// of them for A/B runs (set it before any weight is packed).
+// Which kernel serves a shape (the packed-weight geometry follows the same decision).
 static bool tconv_use_v1(int Cin, int Cout) {
-  static const int forced = [] { const char* e = getenv("ISTGCN_TCONV_V1"); return e ? atoi(e) : -1; }();
-  if (forced == 0 || forced == 1) return forced == 1;
   // measured on config 5's bottleneck (fp16, NM=256; us new / round-1 kernel): 64->8 244/201, 128->11 831/552, 256->16
   // 207/140, but 8->64 163/194, 16->256 131/182, 8->8 (15 taps) 160/195, 11->11 235/188: few OUTPUT channels behind many
   // input channels (or unaligned ones) stream better from eight loading waves

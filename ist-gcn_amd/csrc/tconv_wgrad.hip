@@ -721,555 +721,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-// ======================================================================================================================
-// Wave-specialised variant (round 2) for the shapes that carry the bench: 16-bit storage, stride 1, whole 16-byte channel
-// vectors, a 64 x 64 channel block per workgroup, up to 9 taps.  ONE 8-wave workgroup per CU:
-//   waves 0-3 "compute": one (o-tile, i-tile) pair each, all JT accumulator tiles in registers.  Stride 1 puts position
-//                        p at row p of the halo window, so every operand address of a tile is one per-lane base per tap
-//                        plus a compile-time offset: the loop is 72 MFMAs + 160 transposed LDS reads + ~35 others.
-//   waves 4-7 "memory":  dz tile (double-buffered) and the NEW frames of the halo window: BatchNorm affine + ReLU on the
-//                        way into LDS, conv-bias column sums on the way.
-// Budget rule that shaped it: a wave retires about one instruction per 4-5 cycles whatever its SIMD partner does, so a
-// tile takes max over waves of (instructions x ~4.5).  Re-staging the whole 13-frame halo per 5-frame tile put ~1000
-// instructions per tile on each memory wave (measured: 8000 cycles per tile against 2304 of MFMA work, no faster than the
-// round-1 kernel).  Hence the SLIDING window: the halo of consecutive tiles overlaps in Fin - F frames that stay in LDS,
-// only the F new frames are fetched and transformed, into a region of capf = Fin + n*F frames that the window slides
-// through; when it reaches the end (or a new sequence starts) the tile is FRESH: staged whole at the front.  While the
-// compute waves work on tile k the memory waves stage tile k+1 -- behind window k for a slide; at the front for a fresh
-// tile, which is disjoint from window k when that sits at frame >= Fin (always the case at an overflow), else the fresh
-// tile is staged after the barrier (one extra barrier; once per sequence).
-// One raw s_barrier per tile.  Loads of tile k+2 are issued after the commit of tile k+1 (so the commit's wait is simply
-// "everything outstanding" and the number of loads per tile may vary).
-// ======================================================================================================================
-// cache policy of the wave-specialised kernel's global loads (experiment builds: -DTWG_NT_U / -DTWG_NT_DZ = streaming loads)
-#ifdef TWG_NT_U
-#define TWG_LD_U(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
-#else
-#define TWG_LD_U(p) (*reinterpret_cast<const u32x4*>(p))
-#endif
-#ifdef TWG_NT_DZ
-#define TWG_LD_DZ(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p))
-#else
-#define TWG_LD_DZ(p) (*reinterpret_cast<const u32x4*>(p))
-#endif
-// packed-pair helpers of the memory role's BatchNorm + ReLU transform (see tconv_lean.hip)
-template <typename T> __device__ static inline void twg_unpack2(uint32_t p, float& lo, float& hi);
-template <> __device__ inline void twg_unpack2<__bf16>(uint32_t p, float& lo, float& hi) {
-  lo = __builtin_bit_cast(float, p << 16);
-  hi = __builtin_bit_cast(float, p & 0xffff0000u);
-}
-template <> __device__ inline void twg_unpack2<_Float16>(uint32_t p, float& lo, float& hi) {
-  const f16x2 v = __builtin_bit_cast(f16x2, p);
-  lo = (float)v[0];
-  hi = (float)v[1];
-}
-template <typename T> __device__ static inline uint32_t twg_pk2(float a, float b);
-template <> __device__ inline uint32_t twg_pk2<__bf16>(float a, float b) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-template <> __device__ inline uint32_t twg_pk2<_Float16>(float a, float b) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
-}
-__device__ static inline uint32_t twg_relu_pk(uint32_t w) {
-  typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const s16x2 z = {0, 0};
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), z));
-}
-constexpr int WS_NROLE = 256;
-constexpr int WS_NTH = 2 * WS_NROLE;
-constexpr int WS_UZ = 4;              // dz vectors per memory thread and tile: 128 rows x 8 vectors / 256
-constexpr int WS_UF = 11;             // u vectors per memory thread of a FRESH tile: Fin*V rows x 8 vectors <= 11 * 256
-constexpr int WS_US = 4;              // ... of a SLIDE tile: F*V rows x 8 vectors <= 4 * 256
-
-__device__ static inline void ws_barrier() {
-  // LDS traffic of this wave retired, then the workgroup barrier; NOT __syncthreads() (its fence drains the prefetches)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <typename T, int JT>
-__global__ __launch_bounds__(WS_NTH, 2) void twg_ws_kernel(const TwgParams P) {
-  using E = Elem<T>;
-  constexpr int EPL = E::EPL;
-  static_assert(EPL == 8, "16-bit storage only");
-  typedef typename E::frag frag_t;
-  constexpr int RB = CB * (int)sizeof(T);                  // bytes per sub-tile row (64)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem + P.off_S);                          // [64] conv-bias column sums
-  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_compute = wave8 < 4;
-  const int ltid = tid & (WS_NROLE - 1);
-  const int V = P.V;
-  const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
-  const int o0 = oblk * 64, i0 = iblk * 64;
-  const int dz_sub = TR * CB, u_sub = P.urows * CB;        // elements per 32-channel sub-tile
-
-  if (tid < 64) red[tid] = 0.f;
-  {
-    // both dz halves and the whole u region start as zeros: everything the contraction can reach is finite from the
-    // first tile on (pad positions behind a tile's frames meet zero dz rows and whatever finite u rows lie there)
-    frag_t z;
-    zero_frag<T>(z);
-    const int n0 = 2 * 2 * dz_sub / EPL, n1 = 2 * u_sub / EPL;
-    T* d0 = reinterpret_cast<T*>(smem + P.off_dz);
-    T* u0 = reinterpret_cast<T*>(smem + P.off_u);
-    for (int i = tid; i < n0; i += WS_NTH) *reinterpret_cast<frag_t*>(d0 + i * EPL) = z;
-    for (int i = tid; i < n1; i += WS_NTH) *reinterpret_cast<frag_t*>(u0 + i * EPL) = z;
-  }
-  __syncthreads();
-
-  const T* dzg = reinterpret_cast<const T*>(P.dz);
-  const T* gg = reinterpret_cast<const T*>(P.g);
-  const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
-  const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
-  const int ntile = (t_end > t_begin && !(X_ABL(P) & 1)) ? t_end - t_begin : 0;
-  const int adv = P.F, keep = P.Fin - adv;                 // frames a window advances by / shares with its predecessor
-  // window schedule, computed identically by both roles: tile k is FRESH (window at frame 0, staged whole) at the start of
-  // the walk, at a sequence start, or when sliding on would leave the region; otherwise its window is adv frames further on
-  // (tiles of a workgroup are consecutive: (sequence n, tile-in-sequence mq) advance by increments, no divisions per tile)
-  struct TPos { int n, mq; };
-  auto tpos_first = [&]() __attribute__((always_inline)) { TPos c; c.n = t_begin / P.tiles_per_seq; c.mq = t_begin - c.n * P.tiles_per_seq; return c; };
-  auto tpos_next = [&](TPos c) __attribute__((always_inline)) { if (++c.mq == P.tiles_per_seq) { c.mq = 0; ++c.n; } return c; };
-  auto next_window = [&](int k, const TPos& c, int w_prev, bool& fresh) __attribute__((always_inline)) {
-    fresh = k == 0 || c.mq == 0 || w_prev + adv + P.Fin > P.capf;
-    return fresh ? 0 : w_prev + adv;
-  };
-
-  f32x16 acc[JT];
-  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = 0;
-#define WSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
-#ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
-  if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
-#endif
-  if (is_compute) {
-    // =========================================== compute waves ===========================================
-    const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-    for (int j = 0; j < JT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    int toff[JT];                                           // byte offset of a tap's rows in a u sub-tile
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int jv = j < P.ntaps ? j : 0;                   // padding taps alias tap 0 (computed, never flushed)
-      toff[j] = (P.tap_off[jv] - P.min_off) * V * RB;
-    }
-    const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
-    const int q = (lane & 15) >> 2, pp = lane & 3;
-    const int coff = cblk + 4 * pp;
-    const int lrow = 8 * h + q;                             // this lane addresses rows 16*ks + lrow and + 4 of every k-step
-    ws_barrier();                                           // tile 0 staged (the memory waves' prologue)
-    tlast = __builtin_amdgcn_s_memtime();
-    int w = 0;
-    bool fresh = true;
-    TPos cpos = tpos_first();
-    for (int k = 0; k < ntile; ++k) {
-      w = next_window(k, cpos, w, fresh);
-      cpos = tpos_next(cpos);
-      // byte offsets in LDS, never pointers selected at run time (those decay to flat loads)
-      const int dzb = ((k & 1) ? P.off_dz1 : P.off_dz) + (ot * dz_sub + coff) * (int)sizeof(T);
-      const int ub = P.off_u + (it * u_sub + coff) * (int)sizeof(T) + w * V * RB;
-      constexpr int NK = TR / 16;
-      const unsigned char* ap = smem + dzb + lrow * RB;
-      const unsigned char* up[JT];
-#pragma unroll
-      for (int j = 0; j < JT; ++j) up[j] = smem + ub + lrow * RB + toff[j];
-      frag_t a0, a1, b0[JT], b1[JT];
-      auto load_k = [&](int ks, frag_t& a, frag_t (&b)[JT]) __attribute__((always_inline)) {
-        a = tr_pair<T>(reinterpret_cast<const T*>(ap + ks * 16 * RB), reinterpret_cast<const T*>(ap + ks * 16 * RB + 4 * RB));
-#pragma unroll
-        for (int j = 0; j < JT; ++j)
-          b[j] = tr_pair<T>(reinterpret_cast<const T*>(up[j] + ks * 16 * RB), reinterpret_cast<const T*>(up[j] + ks * 16 * RB + 4 * RB));
-      };
-      auto mma_k = [&](const frag_t& a, const frag_t (&b)[JT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < JT; ++j) mma_kgroup(acc[j], a, b[j]);
-      };
-      load_k(0, a0, b0);
-#pragma unroll
-      for (int ks = 0; ks < NK; ks += 2) {
-        load_k(ks + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < NK) load_k(ks + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      WSTAMP(0)
-      ws_barrier();                                         // tile k contracted, tile k+1 staged (unless it is a late fresh one)
-      if (k + 1 < ntile) {
-        bool f1;
-        next_window(k + 1, cpos, w, f1);                    // (cpos is tile k+1 by now)
-        if (f1 && w < P.Fin) ws_barrier();                  // fresh tile whose front window overlaps window k: staged now
-      }
-      WSTAMP(1)
-    }
-    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { X_DBG(P)[0] = tacc[0]; X_DBG(P)[1] = tacc[1]; X_DBG(P)[7] = (unsigned long long)ntile; }
-  } else {
-    // =========================================== memory waves ============================================
-    const int q = ltid & 7;                                 // this thread's channel vector of a 64-channel row (both tensors)
-    const int sub = q >> 2, ql = q & 3;
-    const bool zlive_q = o0 + q * EPL < P.Cout, ulive_q = i0 + q * EPL < P.Cin;
-    float scv[EPL], shv[EPL], bs[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) {
-      scv[e] = (P.pre && ulive_q) ? P.pre[i0 + q * EPL + e] : 1.f;
-      shv[e] = (P.pre && ulive_q) ? P.pre[P.Cin + i0 + q * EPL + e] : 0.f;
-      bs[e] = 0.f;
-    }
-    // per-thread constants: row r of slot u never changes; element offsets of that row in the two tensors
-    unsigned zoff[WS_UZ], uoff[WS_UF];
-#pragma unroll
-    for (int u = 0; u < WS_UZ; ++u) zoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cout + q * EPL);
-#pragma unroll
-    for (int u = 0; u < WS_UF; ++u) uoff[u] = (unsigned)(((ltid >> 3) + u * (WS_NROLE / 8)) * P.Cin + q * EPL);
-    // geometry of a tile's staging.  Every tile stages the LAST adv frames of its window through the two-deep register
-    // pipeline (a constant 8 loads per tile: the compiler's "all but the youngest 8" wait stays exact); a FRESH tile
-    // stages the first keep frames as well, synchronously at commit time (once per n+1 tiles: the pipeline drains there).
-    struct Geo { int rows; size_t pos0; long long row0; int nrow, lo, hi, wrow; bool valid; };
-    auto geo = [&](int k, const TPos& c, int w, int f_lo, int f_n) __attribute__((always_inline)) {   // window frames [f_lo, f_lo + f_n)
-      Geo t;
-      t.valid = k < ntile;
-      const int n = t.valid ? c.n : 0;
-      const int m0 = (t.valid ? c.mq : 0) * P.F;
-      const int nf = min(P.F, P.Tz - m0);
-      t.rows = t.valid ? nf * V : 0;
-      const int fin0 = m0 + P.min_off;                      // first input frame of the window (stride 1)
-      const int win_frames = nf - 1 + P.Fin - (P.F - 1);    // frames the tile needs
-      const int fr0 = fin0 + f_lo;                          // first staged frame as an input frame
-      t.nrow = t.valid ? max(0, min(f_n, win_frames - f_lo)) * V : 0;
-      t.lo = fr0 < 0 ? min(t.nrow, -fr0 * V) : 0;           // staged rows [lo, hi) exist in the sequence, the others are zeros
-      t.hi = max(t.lo, min(t.nrow, (P.Tin - fr0) * V));
-      t.wrow = (w + f_lo) * V;                              // first destination row in the region
-      t.pos0 = (size_t)(n * P.Tz + m0) * V;
-      t.row0 = (long long)(n * P.Tin + fr0) * V;
-      return t;
-    };
-    // INTERIOR tiles (all F frames present, the staged frames entirely inside the sequence, full 64-channel blocks: all but
-    // the first and last tiles of a sequence) skip every per-slot test: which slots exist is a per-thread constant there
-    const bool allq = P.Cout - o0 >= 64 && P.Cin - i0 >= 64;
-    bool zex[WS_UZ], sex[WS_US];
-    unsigned zoffm[WS_UZ], uoffm[WS_US];
-#pragma unroll
-    for (int u = 0; u < WS_UZ; ++u) { zex[u] = (ltid >> 3) + u * (WS_NROLE / 8) < P.F * V; zoffm[u] = zex[u] ? zoff[u] : 0u; }
-#pragma unroll
-    for (int u = 0; u < WS_US; ++u) { sex[u] = (ltid >> 3) + u * (WS_NROLE / 8) < adv * V; uoffm[u] = sex[u] ? uoff[u] : 0u; }
-    auto interior = [&](const Geo& t) __attribute__((always_inline)) {
-      return allq && t.valid && t.rows == P.F * V && t.lo == 0 && t.hi == adv * V && t.nrow == adv * V;
-    };
-    // conv-bias column sums of a dz vector without unpacking it: v_dot2 against (1,0) and (0,1)
-    // (the (1,0) / (0,1) selectors are kept in registers behind an asm: as literal bf16 vectors the compiler encoded them
-    //  as packed fp16 inline constants and the sums came out wrong)
-    unsigned sel_lo, sel_hi;
-    {
-      const unsigned one = std::is_same<T, __bf16>::value ? 0x3f80u : 0x3c00u;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(sel_lo) : "s"(one));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(sel_hi) : "s"(one << 16));
-    }
-    auto bias_add = [&](const frag_t& v) __attribute__((always_inline)) {
-#ifdef TWG_X_NOBIAS         /* experiment build: no conv-bias column sums (dbias wrong) */
-      return;
-#endif
-#pragma unroll
-      for (int e = 0; e < EPL; e += 2) {
-        if constexpr (std::is_same<T, __bf16>::value) {
-          const bf16x2 p = {v[e], v[e + 1]};
-          bs[e] = __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel_lo), bs[e], false);
-          bs[e + 1] = __builtin_amdgcn_fdot2_f32_bf16(p, __builtin_bit_cast(bf16x2, sel_hi), bs[e + 1], false);
-        } else {
-          const f16x2 p = {v[e], v[e + 1]};
-          bs[e] = __builtin_amdgcn_fdot2(p, __builtin_bit_cast(f16x2, sel_lo), bs[e], false);
-          bs[e + 1] = __builtin_amdgcn_fdot2(p, __builtin_bit_cast(f16x2, sel_hi), bs[e + 1], false);
-        }
-      }
-    };
-    auto transform = [&](frag_t& v) __attribute__((always_inline)) {
-      // per dword: unpack two elements (shift / and), two plain fma, ONE conversion of the pair, ReLU as v_pk_max_i16 on the
-      // packed result (a negative float is a negative int16) -- the form of tconv_lean.hip; packed fp32 math (v_pk_fma_f32)
-      // costs 22 cycles per instruction next to the MFMA waves (tools/valu_beside_mfma.hip)
-      u32x4 w = __builtin_bit_cast(u32x4, v);
-      uint32_t d4[4] = {w[0], w[1], w[2], w[3]};
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        float lo, hi;
-        twg_unpack2<T>(d4[d], lo, hi);
-        lo = __builtin_fmaf(lo, scv[2 * d], shv[2 * d]);
-        hi = __builtin_fmaf(hi, scv[2 * d + 1], shv[2 * d + 1]);
-        uint32_t p = twg_pk2<T>(lo, hi);
-        if (P.pre_relu) p = twg_relu_pk(p);
-        d4[d] = p;
-      }
-      const u32x4 o = {d4[0], d4[1], d4[2], d4[3]};
-      v = __builtin_bit_cast(frag_t, o);
-    };
-    // pipelined part: dz tile + the window's last adv frames.  UNCONDITIONAL loads with clamped addresses.
-    auto issue = [&](int k, const TPos& c, int w, u32x4 (&RZ)[WS_UZ], u32x4 (&RS)[WS_US]) __attribute__((always_inline)) {
-      const Geo t = geo(k, c, w, keep, adv);
-      const T* zb = dzg + (t.valid ? t.pos0 * P.Cout + o0 : 0);                       // wave-uniform
-      const T* ub = gg + (t.valid ? (t.row0 + t.lo) * P.Cin + i0 : 0);              // first row that exists
-      if (interior(t)) {
-#pragma unroll
-        for (int u = 0; u < WS_UZ; ++u) RZ[u] = TWG_LD_DZ(zb + zoffm[u]);
-#pragma unroll
-        for (int u = 0; u < WS_US; ++u) RS[u] = TWG_LD_U(ub + uoffm[u]);
-        return;
-      }
-      const unsigned ushift = (unsigned)(t.lo * P.Cin);
-#pragma unroll
-      for (int u = 0; u < WS_UZ; ++u) {
-        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-        const bool live = zlive_q && r < t.rows;
-        RZ[u] = TWG_LD_DZ(zb + (live ? zoff[u] : 0u));
-      }
-#pragma unroll
-      for (int u = 0; u < WS_US; ++u) {
-        const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-        const bool live = ulive_q && r >= t.lo && r < t.hi;
-        RS[u] = TWG_LD_U(ub + (live ? uoff[u] - ushift : 0u));
-      }
-    };
-    auto commit = [&](int k, const TPos& c, int w, bool fresh, u32x4 (&RZ)[WS_UZ], u32x4 (&RS)[WS_US]) __attribute__((always_inline)) {
-      const Geo t = geo(k, c, w, keep, adv);
-      if (!t.valid) return;
-      T* dzs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_dz1 : P.off_dz)) + sub * dz_sub + ql * EPL;
-      T* ureg = reinterpret_cast<T*>(smem + P.off_u) + sub * u_sub + ql * EPL;
-      if (interior(t)) {
-#pragma unroll
-        for (int u = 0; u < WS_UZ; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          frag_t v = __builtin_bit_cast(frag_t, RZ[u]);
-          if (!zex[u]) zero_frag<T>(v);
-          else if (P.dbias) bias_add(v);
-          *reinterpret_cast<frag_t*>(dzs + r * CB) = v;
-        }
-        T* us = ureg + t.wrow * CB;
-#pragma unroll
-        for (int u = 0; u < WS_US; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          if (sex[u]) {
-            frag_t v = __builtin_bit_cast(frag_t, RS[u]);
-            if (P.pre) transform(v);
-            *reinterpret_cast<frag_t*>(us + r * CB) = v;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < WS_UZ; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          frag_t v = __builtin_bit_cast(frag_t, RZ[u]);
-          if (!(zlive_q && r < t.rows)) zero_frag<T>(v);
-          else if (P.dbias) bias_add(v);
-          *reinterpret_cast<frag_t*>(dzs + r * CB) = v;
-        }
-        T* us = ureg + t.wrow * CB;
-#pragma unroll
-        for (int u = 0; u < WS_US; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          if (r < t.nrow) {
-            frag_t v = __builtin_bit_cast(frag_t, RS[u]);
-            if (!(ulive_q && r >= t.lo && r < t.hi)) zero_frag<T>(v);
-            else if (P.pre) transform(v);
-            *reinterpret_cast<frag_t*>(us + r * CB) = v;
-          }
-        }
-      }
-      if (fresh) {
-        // the first keep frames of a fresh window: loaded and staged here (7 more vectors, rare)
-        const Geo f = geo(k, c, w, 0, keep);
-        const T* ub = gg + (f.row0 + f.lo) * P.Cin + i0;
-        const unsigned ushift = (unsigned)(f.lo * P.Cin);
-        T* us = ureg + f.wrow * CB;
-        u32x4 RX[WS_UF - WS_US];
-#pragma unroll
-        for (int u = 0; u < WS_UF - WS_US; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          const bool live = ulive_q && r >= f.lo && r < f.hi;
-          RX[u] = TWG_LD_U(ub + (live ? uoff[u] - ushift : 0u));
-        }
-#pragma unroll
-        for (int u = 0; u < WS_UF - WS_US; ++u) {
-          const int r = (ltid >> 3) + u * (WS_NROLE / 8);
-          if (r < f.nrow) {
-            frag_t v = __builtin_bit_cast(frag_t, RX[u]);
-            if (!(ulive_q && r >= f.lo && r < f.hi)) zero_frag<T>(v);
-            else if (P.pre) transform(v);
-            *reinterpret_cast<frag_t*>(us + r * CB) = v;
-          }
-        }
-      }
-    };
-    // window schedule of the tiles in flight: tile k (being contracted), k+1 (being committed), k+2 (being issued)
-    u32x4 ZA[WS_UZ], SA[WS_US], ZB[WS_UZ], SB[WS_US];
-    int w1 = 0, w2 = 0;
-    bool f1 = true, f2 = true;
-    const TPos c0 = tpos_first();
-    TPos c1 = tpos_next(c0), c2 = c1;                       // positions of tiles k+1 and k+2
-    issue(0, c0, 0, ZA, SA);
-    w1 = next_window(1, c1, 0, f1);
-    issue(1, c1, w1, ZB, SB);
-    __builtin_amdgcn_sched_barrier(0);
-    commit(0, c0, 0, true, ZA, SA);
-    ws_barrier();                                           // tile 0 staged
-    tlast = __builtin_amdgcn_s_memtime();
-    int w_k = 0;                                            // window of the tile the compute waves are on
-    auto iteration = [&](int k, u32x4 (&Zn)[WS_UZ], u32x4 (&Sn)[WS_US], u32x4 (&Zf)[WS_UZ], u32x4 (&Sf)[WS_US]) __attribute__((always_inline)) {
-      // (Zn, Sn): tile k+1, loaded;  (Zf, Sf): free -> tile k+2
-      c2 = tpos_next(c1);
-      w2 = next_window(k + 2, c2, w1, f2);
-      issue(k + 2, c2, w2, Zf, Sf);                         // (past the last tile: dead slots, same number of loads)
-      __builtin_amdgcn_sched_barrier(0);
-      WSTAMP(1)
-      const bool have = k + 1 < ntile;
-      const bool late = have && f1 && w_k < P.Fin;         // fresh window at the front would overlap window k: after the barrier
-      if (have && !late) commit(k + 1, c1, w1, f1, Zn, Sn);
-      WSTAMP(0)
-      ws_barrier();                                         // tile k contracted
-      if (late) {
-        commit(k + 1, c1, w1, f1, Zn, Sn);
-        ws_barrier();
-      }
-      w_k = w1; w1 = w2; f1 = f2; c1 = c2;
-      WSTAMP(2)
-    };
-    for (int k = 0; k < ntile; k += 2) {
-      iteration(k, ZB, SB, ZA, SA);
-      if (k + 1 < ntile) iteration(k + 1, ZA, SA, ZB, SB);
-    }
-    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) { X_DBG(P)[8] = tacc[0]; X_DBG(P)[9] = tacc[1]; X_DBG(P)[10] = tacc[2]; }
-    if (P.dbias) {
-      // threads sharing a channel vector: lanes q, q+8, ... of every memory wave -> LDS (once per kernel)
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        float a = bs[e];
-#pragma unroll
-        for (int msk = 8; msk < 64; msk <<= 1) a += __shfl_xor(a, msk);
-        if (lane < 8) atomicAdd(&red[q * EPL + e], a);
-      }
-    }
-  }
-#undef WSTAMP
-  __syncthreads();
-
-  // ---- flush: D tile rows = o (registers), cols = i (lanes): two 128-byte segments per instruction ----
-  // (every element of a workspace slice is written by exactly one workgroup of that blockIdx.x: its (o, i) block of every
-  //  tap, and the bias slots of its o-block by the workgroup with i-block 0 -- workgroups without tiles write zeros)
-  const bool aux_wg = iblk == 0;
-  if (P.ws) {
-    float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
-    if (is_compute) {
-      const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        if (j < P.ntaps) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-            if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[j][r];
-          }
-        }
-      }
-    } else if (aux_wg && P.dbias) {
-      float* aux = sl + (size_t)P.ntaps * P.Cout * P.Cin;
-      if (ltid < 64 && o0 + ltid < P.Cout) aux[o0 + ltid] = red[ltid];
-    }
-  } else {
-    if (is_compute) {
-      const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-      for (int j = 0; j < JT; ++j) {
-        if (j < P.ntaps) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = o0 + ot * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-            if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[j][r]);
-          }
-        }
-      }
-    } else if (aux_wg && P.dbias) {
-      if (ltid < 64 && o0 + ltid < P.Cout) atomicAdd(P.dbias + o0 + ltid, red[ltid]);
-    }
-  }
-}
-
-// host side of the wave-specialised variant; returns -1 when the shape is not one it serves (caller falls back)
-template <typename T, int JT>
-int launch_ws(TwgParams& P, int grid_cap, hipStream_t stream) {
-  if constexpr (sizeof(T) != 2) return -1;
-  else {
-    static const int forced = [] { const char* e = getenv("ISTGCN_WGRAD_WS"); return e ? atoi(e) : -1; }();
-    if (forced == 0) return -1;
-    if (P.in_mul != 1 || P.Cin % 8 || P.Cout % 8 || P.Cin < 64 || P.Cout < 64) return -1;
-    if (P.Fin * P.V * 8 > WS_UF * WS_NROLE || P.F * P.V * 8 > WS_US * WS_NROLE || P.Fin <= P.F) return -1;
-    P.n_iblk = ceil_div(P.Cin, 64);
-    const int n_oblk = ceil_div(P.Cout, 64);
-    const int esz = 2;
-    size_t base = 0;
-    base = (base + 15) & ~(size_t)15; P.off_S = (int)base; base += 64 * 4;
-    const size_t dzb = (size_t)2 * TR * CB * esz;
-    base = (base + 15) & ~(size_t)15; P.off_dz = (int)base; base += dzb;
-    P.off_dz1 = (int)base; base += dzb;
-    base = (base + 15) & ~(size_t)15; P.off_u = (int)base;
-    // region: as many slides as fit, at least until an overflow re-stage can run beside the window it replaces (n*F >= Fin)
-    const int span_rows = (P.Fin - P.F) * P.V;              // tap span in rows; pad positions of a tile read TR + span rows
-    int n_adv = 0;
-    for (int n = 8; n >= 1; --n) {
-      const size_t rows = (size_t)(n * P.F) * P.V + TR + span_rows;
-      if (base + 2 * rows * CB * esz <= 158 * 1024) { n_adv = n; break; }
-    }
-    if (n_adv * P.F < P.Fin) return -1;
-    P.capf = P.Fin + n_adv * P.F;
-    P.urows = n_adv * P.F * P.V + TR + span_rows;
-    const size_t off = base + (size_t)2 * P.urows * CB * esz;
-    const int blocks = n_oblk * P.n_iblk;
-    auto kfn = twg_ws_kernel<T, JT>;
-    static std::atomic<unsigned long long> optin{0};
-    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
-    if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, WS_NTH, off);
-    int gx = grid_cap / blocks;
-    if (gx < 1) gx = 1;
-    if (gx > P.total_tiles) gx = P.total_tiles;
-    const int n0 = P.ntaps * P.Cout * P.Cin, n1 = P.Cout;
-    const int nsl = gx;
-    if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;   // too small / atomics are as fast
-    P.ws_slice = n0 + n1;
-    unsigned long long* dbuf = nullptr;
-#ifdef ISTGCN_EXPERIMENT
-    { const char* e = getenv("ISTGCN_WGRAD_ABL"); P.abl = e ? atoi(e) : 0; }
-    if (getenv("ISTGCN_WGRAD_DBG")) {
-      static unsigned long long* dbuf_s = nullptr;
-      if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
-      dbuf = dbuf_s;
-      (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
-      P.dbg = dbuf;
-    }
-#endif
-    ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(WS_NTH), off, stream, P);
-    ISTGCN_CHECK_LAUNCH();
-    if (dbuf) {
-      unsigned long long h[16];
-      (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, stream);
-      (void)hipStreamSynchronize(stream);
-      fprintf(stderr, "wgrad_ws dbg Cin=%d Cout=%d tiles/wg=%llu capf=%d | compute: mfma %llu barrier %llu | memory: commit %llu issue %llu barrier %llu\n",
-              P.Cin, P.Cout, h[7], P.capf, h[0], h[1], h[8], h[9], h[10]);
-    }
-    if (P.ws) {
-      int ny = nsl / 16;
-      ny = ny < 1 ? 1 : (ny > 16 ? 16 : ny);
-      dim3 rgrid(ceil_div(n0 + (P.dbias ? n1 : 0), 1024), ny);
-      ISTGCN_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)P.ws, P.ws_slice, nsl, P.dW, n0,
-                    P.dbias, P.dbias ? n1 : 0);
-      ISTGCN_CHECK_LAUNCH();
-    }
-    return ISTGCN_OK;
-  }
-}
-
 template <typename T, int JT, int OT, int IT, int PS, bool AGG, bool VEC>
 int launch_vec(TwgParams& P, int grid_cap, hipStream_t stream) {
   constexpr int TS = JT >= 9 ? 3 : 1;
@@ -1385,421 +836,8 @@ int launch_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.total_tiles = P.NM * P.tiles_per_seq;
   if (P.ntaps <= 1) return launch_JT<T, 1, false>(P, grid_cap, stream);
   if (P.ntaps <= 3) return launch_JT<T, 3, false>(P, grid_cap, stream);
-  if (P.ntaps <= 9) {
-    if (P.ntaps > 3) {
-      TwgParams Q = P;
-      const int rc = launch_ws<T, 9>(Q, grid_cap, stream);
-      if (rc >= 0) return rc;
-    }
-    return launch_JT<T, 9, false>(P, grid_cap, stream);
-  }
+  if (P.ntaps <= 9) return launch_JT<T, 9, false>(P, grid_cap, stream);
   return launch_JT<T, 15, false>(P, grid_cap, stream);
-}
-
-// ======================================================================================================================
-// Wave-specialised graph-conv weight gradient (round 2): dW[k][c][i] += sum_p dz[p][c] * u_k[p][i],  u_k = A_k-aggregated x,
-// S[w][c] += sum_f dz[(f,w)][c].  16-bit storage, V <= 32, 64 x 64 channel block per workgroup, K <= 4.  ONE 8-wave
-// workgroup per CU, two phases per tile of 128 positions (F frames):
-//   A  all eight waves: aggregation of the staged x tile into the K images  (units = (frame, 32-channel tile, partition):
-//      x^T by ds_read_b64_tr_b16, A_k fragments from LDS, 2 MFMAs, convert, swizzled image rows)
-//   B  waves 0-3: contraction of the images with the dz tile (K MFMAs per k-step of 16 positions, compile-time operand
-//      offsets);  waves 4-7: x / dz tiles of tile k+1 registers -> LDS (double-buffered), tile k+2's loads, S column sums
-// The round-1 kernel did the same work on two 8-wave workgroups per CU, every wave through every phase in lock-step.
-// ======================================================================================================================
-template <typename T, int KT, int OTW>
-__global__ __launch_bounds__(WS_NTH, 2) void gwg_ws_kernel(const TwgParams P) {
-  // OTW = o-tiles per compute wave: the workgroup's channel block is (64 * OTW) x 64.  Two o-tiles halve how often an x
-  // block is aggregated (once per o-block) for layers with >= 128 output channels.
-  constexpr int OB = 64 * OTW;                             // output channels per workgroup
-  constexpr int NZQ = OB / 8;                              // 16-byte vectors per dz row
-  constexpr int UZ = TR * NZQ / WS_NROLE;                  // dz vectors per memory thread and tile
-  using E = Elem<T>;
-  constexpr int EPL = E::EPL;
-  static_assert(EPL == 8, "16-bit storage only");
-  typedef typename E::frag frag_t;
-  constexpr int RB = CB * (int)sizeof(T);                  // bytes per sub-tile row (64)
-  constexpr int SLS = OB + 1;                              // S_l row stride (odd: joints land in different banks)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* S_l = reinterpret_cast<float*>(smem + P.off_S);                          // [V][SLS]
-  T* afrag = reinterpret_cast<T*>(smem + P.off_afrag);                            // [K][2][64][8] fragments of A_k
-  T* img = reinterpret_cast<T*>(smem + P.off_u);                                  // [2 sub][K][TR][CB]
-  const int tid = (int)(threadIdx.x ^ ISTGCN_ROLE_FLIP), lane = tid & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_compute = wave8 < 4;
-  const int ltid = tid & (WS_NROLE - 1);
-  const int V = P.V, K = P.ntaps;
-  const int oblk = blockIdx.y / P.n_iblk, iblk = blockIdx.y - oblk * P.n_iblk;
-  const int o0 = oblk * OB, i0 = iblk * 64;
-  const int dz_sub = TR * CB, x_sub = P.dz_rows * CB;      // elements per 32-channel sub-tile
-  const int dz_half = 2 * OTW * dz_sub * (int)sizeof(T);   // bytes of one dz half ([2*OTW sub][TR][CB])
-
-  for (int idx = tid; idx < V * SLS; idx += WS_NTH) S_l[idx] = 0.f;
-  // B-operand fragments of the adjacency: lane (w = lane&31, h = lane>>5), k-step s, element j = A[k][v = 16s + 8h + j][w]
-  for (int idx = tid; idx < K * 2 * 64; idx += WS_NTH) {
-    const int ln = idx & 63, sstep = (idx >> 6) & 1, k = idx >> 7;
-    const int w = ln & 31, h = ln >> 5;
-    frag_t fr;
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      const int v = 16 * sstep + 8 * h + j;
-      fr[j] = E::from_f((v < V && w < V) ? P.A[(k * V + v) * V + w] : 0.f);
-    }
-    *reinterpret_cast<frag_t*>(afrag + idx * EPL) = fr;
-  }
-  {
-    // zeros once: the x halves (the aggregation reads a 32-row range per frame: rows behind the tile must be finite and
-    // meet zero adjacency rows), the dz halves, the images (rows behind a short tile meet zero dz rows)
-    frag_t z;
-    zero_frag<T>(z);
-    T* x0 = reinterpret_cast<T*>(smem + P.off_dz);          // [dz0][dz1][x0][x1][img] are contiguous
-    const int nv = (int)((P.off_u - P.off_dz) / 16) + 2 * K * dz_sub / EPL;
-    for (int i = tid; i < nv; i += WS_NTH) *reinterpret_cast<frag_t*>(x0 + i * EPL) = z;
-  }
-  __syncthreads();
-
-  const T* dzg = reinterpret_cast<const T*>(P.dz);
-  const T* xg = reinterpret_cast<const T*>(P.g);
-  const int chunk = (P.total_tiles + gridDim.x - 1) / gridDim.x;
-  const int t_begin = blockIdx.x * chunk, t_end = min(P.total_tiles, t_begin + chunk);
-  const int ntile = t_end > t_begin ? t_end - t_begin : 0;
-  struct TPos { int n, mq; };
-  auto tpos_first = [&]() __attribute__((always_inline)) { TPos c; c.n = t_begin / P.tiles_per_seq; c.mq = t_begin - c.n * P.tiles_per_seq; return c; };
-  auto tpos_next = [&](TPos c) __attribute__((always_inline)) { if (++c.mq == P.tiles_per_seq) { c.mq = 0; ++c.n; } return c; };
-  auto tile_nf = [&](const TPos& c) __attribute__((always_inline)) { return min(P.F, P.Tz - c.mq * P.F); };
-
-  // ---- phase A: aggregation, units dealt round-robin to the eight waves ----
-  const int a_grp = lane >> 4, a_h = a_grp >> 1, a_cblk = (a_grp & 1) * 16, a_q4 = (lane & 15) >> 2, a_pp = lane & 3;
-  const int a_w = lane & 31;
-  const int a_src = (8 * a_h + a_q4) * CB + a_cblk + 4 * a_pp;       // element offset in an x sub-tile (frame 0, k-step 0)
-  const int NC = 2 * K;                                              // unit columns (32-channel tile ct, partition kk)
-  const unsigned rcpNC = (65536u + NC - 1) / NC, rcpK = (65536u + K - 1) / K;
-  auto aggregate = [&](int half, int nf) __attribute__((always_inline)) {
-    const T* xs = reinterpret_cast<const T*>(smem + (half ? P.off_x1 : P.off_dz + 2 * dz_half));
-    const int nunit = nf * NC;
-    for (int u = wave8; u < nunit; u += 8) {
-      const int f = (int)(((unsigned)u * rcpNC) >> 16), c = u - f * NC;
-      const int ct = (int)(((unsigned)c * rcpK) >> 16), kk = c - ct * K;
-      const T* r0 = xs + ct * x_sub + f * V * CB + a_src;
-      const frag_t x0 = tr_pair<T>(r0, r0 + 4 * CB);
-      const frag_t x1 = tr_pair<T>(r0 + 16 * CB, r0 + 20 * CB);
-      const T* af = afrag + kk * (2 * 64 * EPL) + lane * EPL;
-      const frag_t b0 = *reinterpret_cast<const frag_t*>(af);
-      const frag_t b1 = *reinterpret_cast<const frag_t*>(af + 64 * EPL);
-      f32x16 d;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d[r] = 0.f;
-      mma_kgroup(d, x0, b0);
-      mma_kgroup(d, x1, b1);
-      if (a_w < V) {
-        // a lane owns one image row; rows are 64 bytes apart (what the contraction's transposed reads want), so sixteen
-        // lanes storing the same 16-byte block would share two banks: the block index is XOR-swizzled with row bits 1-2
-        const int row = f * V + a_w, sw = (row >> 1) & 3;
-        T* dst = img + ((ct * K + kk) * TR + row) * CB + 4 * (lane >> 5);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v4[4] = {d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]};
-          store4(dst + 8 * (g ^ sw), v4);
-        }
-      }
-    }
-  };
-
-  f32x16 acc[OTW][KT];
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
-#define GSTAMP(i) if (X_DBG(P)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; }
-#ifdef ISTGCN_X_PRIO        /* experiment build: issue priority per role (1: compute waves high, 2: memory waves high) */
-  if ((ISTGCN_X_PRIO == 1) == is_compute) __builtin_amdgcn_s_setprio(3);
-#endif
-  if (is_compute) {
-    // =========================================== compute waves ===========================================
-    const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-    for (int o = 0; o < OTW; ++o)
-#pragma unroll
-      for (int j = 0; j < KT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[o][j][r] = 0.f;
-    const int grp = lane >> 4, h = grp >> 1, cblk = (grp & 1) * 16;
-    const int q = (lane & 15) >> 2, pp = lane & 3;
-    const int coff = cblk + 4 * pp;
-    const int lrow = 8 * h + q;
-    // swizzled column offsets of this lane's two image rows (8h + q and + 4, mod 16, in every k-step)
-    const int coff_u0 = (((coff >> 3) ^ ((lrow >> 1) & 3)) << 3) + (coff & 7);
-    const int coff_u1 = (((coff >> 3) ^ (((lrow + 4) >> 1) & 3)) << 3) + (coff & 7);
-    // indicator fragments (B operand: lane (w = lane & 31, kg = lane >> 5) holds rows p = 16 ks + 8 kg + j, j = 0..7)
-    constexpr int NKS = TR / 16;
-    const bool s_wave = it == 0 && P.S != nullptr;
-    frag_t ind[NKS];
-    f32x16 accS[OTW];
-#pragma unroll
-    for (int o = 0; o < OTW; ++o)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accS[o][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-      for (int jj = 0; jj < EPL; ++jj) {
-        const int p = 16 * ks + 8 * (lane >> 5) + jj;
-        ind[ks][jj] = E::from_f((p % V) == (lane & 31) ? 1.f : 0.f);
-      }
-    }
-    TPos c = tpos_first();
-    ws_barrier();                                           // tile 0 staged
-    tlast = __builtin_amdgcn_s_memtime();
-    for (int k = 0; k < ntile; ++k) {
-      aggregate(k & 1, tile_nf(c));
-      c = tpos_next(c);
-      GSTAMP(0)
-      ws_barrier();                                         // A done: images complete
-      GSTAMP(1)
-      // this wave's o-tiles are sub-tiles ot * OTW + o of the dz tile
-      const unsigned char* ap = smem + ((k & 1) ? P.off_dz1 : P.off_dz) + (ot * OTW * dz_sub + coff) * (int)sizeof(T) + lrow * RB;
-      const unsigned char* u0 = smem + P.off_u + (it * K * dz_sub + coff_u0) * (int)sizeof(T) + lrow * RB;
-      const unsigned char* u1 = smem + P.off_u + (it * K * dz_sub + coff_u1) * (int)sizeof(T) + (lrow + 4) * RB;
-      constexpr int NK = TR / 16;
-      frag_t a0[OTW], a1[OTW], b0[KT], b1[KT];
-      auto load_k = [&](int ks, frag_t (&a)[OTW], frag_t (&b)[KT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int o = 0; o < OTW; ++o)
-          a[o] = tr_pair<T>(reinterpret_cast<const T*>(ap + o * TR * RB + ks * 16 * RB), reinterpret_cast<const T*>(ap + o * TR * RB + ks * 16 * RB + 4 * RB));
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          const int jv = j < K ? j : 0;                     // padding partitions alias partition 0 (computed, never flushed)
-          b[j] = tr_pair<T>(reinterpret_cast<const T*>(u0 + jv * TR * RB + ks * 16 * RB), reinterpret_cast<const T*>(u1 + jv * TR * RB + ks * 16 * RB));
-        }
-      };
-      auto mma_k = [&](int ks, const frag_t (&a)[OTW], const frag_t (&b)[KT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int o = 0; o < OTW; ++o) {
-#pragma unroll
-          for (int j = 0; j < KT; ++j) mma_kgroup(acc[o][j], a[o], b[j]);
-          if (s_wave) mma_kgroup(accS[o], a[o], ind[ks]);
-        }
-      };
-      load_k(0, a0, b0);
-#pragma unroll
-      for (int ks = 0; ks < NK; ks += 2) {
-        load_k(ks + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(ks, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < NK) load_k(ks + 2, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(ks + 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      GSTAMP(2)
-      ws_barrier();                                         // B done: images free, tile k+1 staged
-      GSTAMP(3)
-    }
-    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { for (int i = 0; i < 4; ++i) X_DBG(P)[i] = tacc[i]; X_DBG(P)[7] = (unsigned long long)ntile; }
-    if (s_wave && (lane & 31) < V) {
-      // D tile rows = output channel (registers), cols = joint (lanes) -> S_l[w][c] for the common flush below
-#pragma unroll
-      for (int o = 0; o < OTW; ++o)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S_l[(lane & 31) * SLS + (ot * OTW + o) * CB + mfma_row(r, lane)] = accS[o][r];
-    }
-  } else {
-    // =========================================== memory waves ============================================
-    // thread maps: x rows are 8 vectors (64 channels) wide, dz rows NZQ vectors (64 * OTW channels)
-    const int qx = ltid & 7, rx0 = ltid >> 3;
-    const int qz = ltid & (NZQ - 1), rz0 = ltid / NZQ;
-    constexpr int RXS = WS_NROLE / 8, RZS = WS_NROLE / NZQ;   // rows per sweep
-    const bool zlive_q = o0 + qz * EPL < P.Cout, xlive_q = i0 + qx * EPL < P.Cin;
-    unsigned zoff[UZ], xoff[WS_UZ];
-#pragma unroll
-    for (int u = 0; u < UZ; ++u) zoff[u] = (unsigned)((rz0 + u * RZS) * P.Cout + qz * EPL);
-#pragma unroll
-    for (int u = 0; u < WS_UZ; ++u) xoff[u] = (unsigned)((rx0 + u * RXS) * P.Cin + qx * EPL);
-    // a constant UZ + 4 loads per tile (dead slots read the tile's first vector and are zeroed on commit)
-    auto issue = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
-      const bool valid = k < ntile;
-      const int rows = valid ? tile_nf(c) * V : 0;
-      const size_t pos0 = valid ? (size_t)(c.n * P.Tz + c.mq * P.F) * V : 0;
-      const T* zb = dzg + pos0 * P.Cout + (valid ? o0 : 0);
-      const T* xb = xg + pos0 * P.Cin + (valid ? i0 : 0);
-#pragma unroll
-      for (int u = 0; u < UZ; ++u)
-        RZ[u] = TWG_LD_DZ(zb + ((zlive_q && rz0 + u * RZS < rows) ? zoff[u] : 0u));
-#pragma unroll
-      for (int u = 0; u < WS_UZ; ++u)
-        RX[u] = TWG_LD_U(xb + ((xlive_q && rx0 + u * RXS < rows) ? xoff[u] : 0u));
-    };
-    auto commit = [&](int k, const TPos& c, u32x4 (&RZ)[UZ], u32x4 (&RX)[WS_UZ]) __attribute__((always_inline)) {
-      if (k >= ntile) return;
-      const int rows = tile_nf(c) * V;
-      T* dzs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_dz1 : P.off_dz)) + (qz >> 2) * dz_sub + (qz & 3) * EPL;
-      T* xs = reinterpret_cast<T*>(smem + ((k & 1) ? P.off_x1 : P.off_dz + 2 * dz_half)) + (qx >> 2) * x_sub + (qx & 3) * EPL;
-#pragma unroll
-      for (int u = 0; u < UZ; ++u) {
-        const int r = rz0 + u * RZS;
-        frag_t vz = __builtin_bit_cast(frag_t, RZ[u]);
-        if (!(zlive_q && r < rows)) zero_frag<T>(vz);
-        *reinterpret_cast<frag_t*>(dzs + r * CB) = vz;
-      }
-#pragma unroll
-      for (int u = 0; u < WS_UZ; ++u) {
-        const int r = rx0 + u * RXS;
-        frag_t vx = __builtin_bit_cast(frag_t, RX[u]);
-        if (!(xlive_q && r < rows)) zero_frag<T>(vx);
-        *reinterpret_cast<frag_t*>(xs + r * CB) = vx;
-      }
-    };
-    u32x4 ZA[UZ], XA[WS_UZ], ZB[UZ], XB[WS_UZ];
-    const TPos c0 = tpos_first();
-    TPos ck = c0, c1 = tpos_next(c0), c2 = c1;
-    issue(0, c0, ZA, XA);
-    issue(1, c1, ZB, XB);
-    __builtin_amdgcn_sched_barrier(0);
-    commit(0, c0, ZA, XA);
-    ws_barrier();                                           // tile 0 staged
-    tlast = __builtin_amdgcn_s_memtime();
-    auto iteration = [&](int k, u32x4 (&Zn)[UZ], u32x4 (&Xn)[WS_UZ], u32x4 (&Zf)[UZ], u32x4 (&Xf)[WS_UZ]) __attribute__((always_inline)) {
-      aggregate(k & 1, tile_nf(ck));                        // phase A, this role's share
-      GSTAMP(0)
-      ws_barrier();
-      GSTAMP(1)
-      c2 = tpos_next(c1);
-      issue(k + 2, c2, Zf, Xf);
-      __builtin_amdgcn_sched_barrier(0);
-      commit(k + 1, c1, Zn, Xn);
-      GSTAMP(2)
-      ck = c1; c1 = c2;
-      ws_barrier();
-      GSTAMP(4)
-    };
-    for (int k = 0; k < ntile; k += 2) {
-      iteration(k, ZB, XB, ZA, XA);
-      if (k + 1 < ntile) iteration(k + 1, ZA, XA, ZB, XB);
-    }
-    if (X_DBG(P) && blockIdx.x == 0 && blockIdx.y == 0 && ltid == 0) for (int i = 0; i < 5; ++i) X_DBG(P)[8 + i] = tacc[i];
-  }
-#undef GSTAMP
-  __syncthreads();
-
-  // ---- flush (as the convolution variant; the aux slots are S[w][c] of this o-block, reported by i-block 0) ----
-  const bool aux_wg = iblk == 0;
-  if (P.ws) {
-    float* sl = P.ws + (size_t)blockIdx.x * P.ws_slice;
-    if (is_compute) {
-      const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-      for (int ow = 0; ow < OTW; ++ow)
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          if (j < K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int o = o0 + (ot * OTW + ow) * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-              if (o < P.Cout && i < P.Cin) sl[((size_t)j * P.Cout + o) * P.Cin + i] = acc[ow][j][r];
-            }
-          }
-        }
-    } else if (aux_wg && P.S) {
-      float* aux = sl + (size_t)K * P.Cout * P.Cin;
-      for (int idx = ltid; idx < V * OB; idx += WS_NROLE) {
-        const int w = idx / OB, cc = idx - w * OB;
-        if (o0 + cc < P.Cout) aux[w * P.Cout + o0 + cc] = S_l[w * SLS + cc];
-      }
-    }
-  } else {
-    if (is_compute) {
-      const int ot = wave8 & 1, it = wave8 >> 1;
-#pragma unroll
-      for (int ow = 0; ow < OTW; ++ow)
-#pragma unroll
-        for (int j = 0; j < KT; ++j) {
-          if (j < K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int o = o0 + (ot * OTW + ow) * CB + mfma_row(r, lane), i = i0 + it * CB + (lane & 31);
-              if (o < P.Cout && i < P.Cin) atomicAdd(P.dW + ((size_t)j * P.Cout + o) * P.Cin + i, acc[ow][j][r]);
-            }
-          }
-        }
-    } else if (aux_wg && P.S) {
-      for (int idx = ltid; idx < V * OB; idx += WS_NROLE) {
-        const int w = idx / OB, cc = idx - w * OB;
-        if (o0 + cc < P.Cout) atomicAdd(P.S + w * P.Cout + o0 + cc, S_l[w * SLS + cc]);
-      }
-    }
-  }
-}
-
-template <typename T, int KT, int OTW>
-int launch_gws_o(TwgParams& P, int grid_cap, hipStream_t stream) {
-  if constexpr (sizeof(T) != 2) return -1;
-  else {
-    static const int forced = [] { const char* e = getenv("ISTGCN_WGRAD_WS"); return e ? atoi(e) : -1; }();
-    if (forced == 0) return -1;
-    if (P.V > 32 || P.Cin % 8 || P.Cout % 8 || P.Cin < 64 || P.Cout < 64 * OTW || P.ntaps > KT) return -1;
-    P.n_iblk = ceil_div(P.Cin, 64);
-    const int n_oblk = ceil_div(P.Cout, 64 * OTW);
-    const int esz = 2, K = P.ntaps;
-    P.dz_rows = (P.F - 1) * P.V + 32 > TR ? (P.F - 1) * P.V + 32 : TR;      // x sub-tile rows (32-row k-range of the last frame)
-    size_t off = 0;
-    P.off_S = (int)off; off += (size_t)P.V * (64 * OTW + 1) * 4;
-    off = (off + 15) & ~(size_t)15; P.off_afrag = (int)off; off += (size_t)K * 2 * 64 * 16;
-    const size_t dzb = (size_t)2 * OTW * TR * CB * esz, xb = (size_t)2 * P.dz_rows * CB * esz;
-    off = (off + 15) & ~(size_t)15; P.off_dz = (int)off; off += dzb;
-    P.off_dz1 = (int)off; off += dzb;
-    /* x half 0 sits right behind the dz halves */ off += xb;
-    P.off_x1 = (int)off; off += xb;
-    P.off_u = (int)off; off += (size_t)2 * K * TR * CB * esz;
-    if (off > 160 * 1024) return -1;
-    if (OTW == 2 && P.total_tiles * n_oblk * P.n_iblk < 2 * 256) return -1;   // too few tiles to keep every CU busy with wide blocks
-    const int blocks = n_oblk * P.n_iblk;
-    auto kfn = gwg_ws_kernel<T, KT, OTW>;
-    static std::atomic<unsigned long long> optin{0};
-    if (int ea_ = istgcn_lds_optin((const void*)kfn, optin)) return ea_;
-    if (grid_cap < 1) grid_cap = istgcn_resident_blocks((const void*)kfn, WS_NTH, off);
-    int gx = grid_cap / blocks;
-    if (gx < 1) gx = 1;
-    if (gx > P.total_tiles) gx = P.total_tiles;
-    const int n0 = K * P.Cout * P.Cin, n1 = P.V * P.Cout;
-    const int nsl = gx;
-    if (P.ws && ((long long)nsl * (n0 + n1) > P.ws_slice || nsl < 128)) P.ws = nullptr;
-    P.ws_slice = n0 + n1;
-    unsigned long long* dbuf = nullptr;
-#ifdef ISTGCN_EXPERIMENT
-    if (getenv("ISTGCN_WGRAD_DBG")) {
-      static unsigned long long* dbuf_s = nullptr;
-      if (!dbuf_s) (void)hipMalloc(&dbuf_s, 16 * sizeof(unsigned long long));
-      dbuf = dbuf_s;
-      (void)hipMemsetAsync(dbuf, 0, 16 * sizeof(unsigned long long), stream);
-      P.dbg = dbuf;
-    }
-#endif
-    ISTGCN_LAUNCH(kfn, dim3(gx, blocks), dim3(WS_NTH), off, stream, P);
-    ISTGCN_CHECK_LAUNCH();
-    if (dbuf) {
-      unsigned long long h[16];
-      (void)hipMemcpyAsync(h, dbuf, sizeof(h), hipMemcpyDeviceToHost, stream);
-      (void)hipStreamSynchronize(stream);
-      fprintf(stderr, "gwgrad_ws dbg Cin=%d Cout=%d tiles/wg=%llu | compute: agg %llu barA %llu contract %llu barB %llu | memory: agg %llu barA %llu issue+commit %llu ssums %llu barB %llu\n",
-              P.Cin, P.Cout, h[7], h[0], h[1], h[2], h[3], h[8], h[9], h[10], h[11], h[12]);
-    }
-    if (P.ws) {
-      int ny = nsl / 16;
-      ny = ny < 1 ? 1 : (ny > 16 ? 16 : ny);
-      dim3 rgrid(ceil_div(n0 + (P.S ? n1 : 0), 1024), ny);
-      ISTGCN_LAUNCH(wgrad_reduce_kernel, rgrid, dim3(256), 0, stream, (const float*)P.ws, P.ws_slice, nsl, P.dW, n0,
-                    P.S, P.S ? n1 : 0);
-      ISTGCN_CHECK_LAUNCH();
-    }
-    return ISTGCN_OK;
-  }
-}
-
-template <typename T, int KT>
-int launch_gws(TwgParams& P, int grid_cap, hipStream_t stream) {
-  if (P.Cout >= 128) {                                    // 128 x 64 blocks: each x block aggregated once per 128 output channels
-    TwgParams Q = P;
-    const int rc = launch_gws_o<T, KT, 2>(Q, grid_cap, stream);
-    if (rc >= 0) return rc;
-  }
-  return launch_gws_o<T, KT, 1>(P, grid_cap, stream);
 }
 
 template <typename T>
@@ -1809,22 +847,12 @@ int launch_agg_T(TwgParams& P, int grid_cap, hipStream_t stream) {
   P.Fin = P.F;
   P.tiles_per_seq = ceil_div(P.Tz, P.F);
   P.total_tiles = P.NM * P.tiles_per_seq;
-  if (P.ntaps == 3) {
-    TwgParams Q = P;
-    const int rc = launch_gws<T, 3>(Q, grid_cap, stream);
-    if (rc >= 0) return rc;
-  }
   if (P.ntaps <= 1) return launch_JT<T, 1, true>(P, grid_cap, stream);
   if (P.ntaps <= 3) return launch_JT<T, 3, true>(P, grid_cap, stream);
   return launch_JT<T, 4, true>(P, grid_cap, stream);
 }
 
 }  // namespace
-
-extern "C" int istgcn_tconv_wgrad_rc_ok(int V, int Cin, int Cout, int ntaps, const int* tap_off, int in_mul, int dtype);
-extern "C" int istgcn_tconv_wgrad_rc(const void* dz, const void* g, const float* pre, int pre_relu, float* dW, float* dbias,
-                                     int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps, const int* tap_off,
-                                     int in_mul, int dtype, int grid_cap, float* ws, long long ws_floats, void* stream);
 
 extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pre, int pre_relu, float* dW,
                                   float* dbias, int NM, int Tin, int Tz, int V, int Cin, int Cout, int ntaps,
@@ -1835,26 +863,13 @@ extern "C" int istgcn_tconv_wgrad(const void* dz, const void* g, const float* pr
     return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype)) return ISTGCN_EINVAL;
   if (NM == 0 || Tz == 0) return ISTGCN_OK;
-  // lean form of twg_ws (tconv_wgrad_lean.hip) for the 16-bit trunk shapes; a conv-bias gradient, when asked for (the training
+  // the lean kernel (tconv_wgrad_lean.hip) for the 16-bit trunk shapes; a conv-bias gradient, when asked for (the training
   // step does not: functional.py), is a column-sum kernel of its own next to it
   if (twg_lean_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype, Tin, Tz) && (!dbias || (Cout <= 256 && 256 % (Cout / 8) == 0))) {
     const int rc = twg_lean_launch(dz, g, pre, pre_relu, dW, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype, grid_cap, ws,
                                    ws_floats, (hipStream_t)stream);
     if (rc == ISTGCN_OK && dbias) return twg_lean_dbias(dz, dbias, NM, Tz, V, Cout, dtype, (hipStream_t)stream);
     if (rc >= 0) return rc;      // (-1: the LDS plan does not fit -- decided before anything was launched)
-  }
-  {
-    // frame-tiled kernel (tconv_rc_wgrad.hip): consecutive taps, stride 1 or 2, 64-channel blocks, 16-bit storage.  Measured
-    // (tools/twg_exp.py, bf16, NM = 128): it wins where the round-2 kernels have no wave-specialised form for the 9-tap
-    // stride-2 layers (128 ch T=300: 307 -> 265 us, 256 ch T=150: 537 -> 478); at stride 1 twg_ws is 5-8 % faster (the
-    // 32-row frame tiles cost 28 % more matrix work than its 125-of-128-row tiles), and the 16-tap variant has no
-    // registers left for its staging pipeline -- those stay with the round-2 kernels.
-    // ISTGCN_TWG_RC=0: round-2 kernels everywhere (A/B timing); =2: the frame-tiled kernel wherever it applies
-    static const int mode = [] { const char* e = getenv("ISTGCN_TWG_RC"); return e ? atoi(e) : 1; }();   // dispatch override, read once
-    if (mode != 0 && istgcn_tconv_wgrad_rc_ok(V, Cin, Cout, ntaps, tap_off, in_mul, dtype) &&
-        (mode == 2 || (in_mul == 2 && ntaps <= 10)))
-      return istgcn_tconv_wgrad_rc(dz, g, pre, pre_relu, dW, dbias, NM, Tin, Tz, V, Cin, Cout, ntaps, tap_off, in_mul, dtype,
-                                   grid_cap, ws, ws_floats, stream);
   }
   TwgParams P{};
   P.dz = dz; P.g = g; P.pre = pre; P.dW = dW; P.dbias = dbias;

@@ -54,4 +54,4 @@ def _kernel_coverage(request):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, 'kernel_coverage.tsv'), 'a') as f:
         for k, n in sorted(tr.kernels.items()):
-            f.write('%s\t%d\t%s\n' % (request.node.nodeid, n, k))
+            f.write('%s%s\t%d\t%s\n' % (request.node.nodeid, os.environ.get('ISTGCN_COVERAGE_TAG', ''), n, k))

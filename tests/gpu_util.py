@@ -79,7 +79,7 @@ def gate16(name, value, gate):
     return value < gate
 
 
-def sub_close(name, got, g, key, tol, dt):
+def sub_close(name, got, g, key, tol, dt, zero_gate=0.5):
     """`close()` against a WIDE fixture entry (tests/golden/detinit.py: a deterministic subsample of the reference tensor
     plus its L2 norm): fp32 -- scale-aware max error on the subsample and the norm; 16-bit storage -- relative L2 error on
     the subsample (recorded next to its gate in gpurun_out/err16_measured.txt)."""
@@ -98,7 +98,7 @@ def sub_close(name, got, g, key, tol, dt):
             diag(name, s, ref, 0.0)
         return ok
     if float(ref.norm()) < 1e-3 * max(1, ref.numel()) ** 0.5:
-        return bool(got.abs().max() < 0.5)                  # structurally-zero gradient (see close())
+        return gate16(name + ' max-abs (structural zero) ' + str(dt)[6:], float(got.abs().max()), zero_gate)   # (see close())
     ok = gate16(name + ' rel-L2 ' + str(dt)[6:], l2rel(s, ref), tol) and bool(torch.isfinite(got).all())
     if not ok:
         diag(name, s, ref, 0.0)

@@ -214,11 +214,29 @@ def test_blocks_wide_golden(golden, kind, dt):
             (y.float() * r.to(d)).sum().backward()
         if dt != torch.float32:
             # the kernels this fixture is meant to pin are the ones that ran (the library's dispatch trace, not its predicates):
-            # register-chained graph conv forward / weight gradient; its data gradient WITH the adjacency gradient -- the
-            # register-chained kernel up to 128 output channels, `gcn_bwd_ws` at 256 (cases 3 / 4); the lean temporal conv and
-            # its lean weight gradient, or the bottleneck stream kernels
-            want = ['gcn_rc_fwd_kernel', 'gcn_rc_wgrad_kernel', 'gcn_bwd_ws_kernel' if cout == 256 else 'gcn_rc_bwd_kernel']
-            want += ['bneck_'] if kind == 'st_gcn_mstcn_1x1' else ['tconv_lean_kernel', 'twg_lean_kernel']
+            # register-chained graph conv forward / weight gradient / data gradient WITH the adjacency gradient (256 output
+            # channels -- cases 3 / 4 -- included since round 5); the lean temporal conv and its lean weight gradient, or the
+            # bottleneck stream kernels
+            want = ['gcn_rc_fwd_kernel', 'gcn_rc_wgrad_kernel', 'gcn_rc_bwd_kernel']
+            if kind == 'st_gcn_mstcn_1x1':
+                want += ['bneck_']
+            elif stride == 2 and kind in ('st_gcn_mstcn', 'st_gcn_multi3_fix_3A_mstcn'):
+                # the 15-tap fold at stride 2: a 33-frame window (forward) and 8 + 7 taps per output phase (data gradient) are
+                # outside tconv_lean_geom() -> the round-3 kernel; the weight gradient is lean (8 + 7 taps per parity)
+                want += ['tconv_kernel', 'twg_lean_kernel']
+            else:
+                want += ['tconv_lean_kernel', 'twg_lean_kernel']
+            # (the three dispatch overrides the library keeps select the previous generation of a family; this test runs under
+            #  each of them in tests/test_gpu_overrides.py, and then THOSE kernels must be the ones that ran)
+            older = {}
+            if os.environ.get('ISTGCN_GCN_RC') == '0':
+                older.update(gcn_rc_fwd_kernel='gcn_fwd_kernel', gcn_rc_wgrad_kernel='tconv_wgrad_kernel', gcn_rc_bwd_kernel='gcn_bwd_kernel')
+            if os.environ.get('ISTGCN_TCONV_LEAN') == '0':
+                older.update(tconv_lean_kernel='tconv_kernel')
+            if os.environ.get('ISTGCN_TWG_LEAN') == '0':
+                older.update(twg_lean_kernel='tconv_wgrad_kernel')
+            assert not [w for w in older if w in want and tr.ran(w)], ('override ignored', sorted(tr.kernels))
+            want = [older.get(w, w) for w in want]
             missing = [w for w in want if not tr.ran(w)]
             assert not missing, (missing, sorted(tr.kernels))
         assert sub_close(name + '_dx', xx.grad.float(), g, b + 'dx', tol_g, dt)
@@ -230,7 +248,9 @@ def test_blocks_wide_golden(golden, kind, dt):
                 #  their rel-L2 error is 0.07-0.10 over the ten fixtures, gpurun_out/err16_measured.txt -- 1.3 x the gate of the
                 #  weight tensors; fp32 and fp16 keep one gate)
                 tg = 1.3 * tol_g if (dt == torch.bfloat16 and k.endswith('bias')) else tol_g
-                assert sub_close(name + '_grad_' + k, p.grad, g, b + 'grad.' + k, tg, dt), k
+                # (a structurally-zero gradient -- a conv bias in front of a batch-statistics BatchNorm -- is the rounding noise of
+                #  a sum over positions x channels of 16-bit-rounded terms: it grows with the square root of the channel count)
+                assert sub_close(name + '_grad_' + k, p.grad, g, b + 'grad.' + k, tg, dt, zero_gate=0.5 * (cout / 64.0) ** 0.5), k
                 n_grad += 1
             else:
                 assert p.grad is None, k

@@ -49,8 +49,9 @@ def test_shipped_library_has_no_experiment_hooks_and_knows_its_sources(lib):
     names = set(m.group(0).decode() for m in re.finditer(rb'ISTGCN_[A-Z0-9_]{3,}', blob))
     bad = [n for n in names if n.endswith('_ABL') or '_DBG' in n or n in ('ISTGCN_RC_NCT', 'ISTGCN_GWG_OT', 'ISTGCN_RC_SPLIT', 'ISTGCN_DEBUG')]
     assert not bad, bad
-    assert names <= {'ISTGCN_GCN_RC', 'ISTGCN_GCN_V1', 'ISTGCN_GCNBWD_WS', 'ISTGCN_WGRAD_WS', 'ISTGCN_TWG_RC', 'ISTGCN_TCONV_SK',
-                     'ISTGCN_TCONV_V1', 'ISTGCN_TCONV_LEAN', 'ISTGCN_TWG_LEAN'}, names
+    # (round 5: three of round 4's nine overrides are left -- one per kernel family that still has two generations in the
+    #  library; each is exercised against the reference fixtures by tests/test_gpu_overrides.py)
+    assert names <= {'ISTGCN_GCN_RC', 'ISTGCN_TCONV_LEAN', 'ISTGCN_TWG_LEAN'}, names
     assert _lib.build_id() == _lib.csrc_hash() and len(_lib.csrc_hash()) == 16
 
 

@@ -23,13 +23,15 @@ done; done
 timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --breakdown > /dev/null 2> gpurun_out/${tag}_breakdown_cfg2.txt; grep "ms/step" gpurun_out/${tag}_breakdown_cfg2.txt
 for c in $prof; do
   case $c in
+    1) n=st_gcnold_f32_b2; a="--config 1";;
     2) n=st_gcn_msgcn_bf16_b64; a="";;
     3) n=st_gcn_mstcn_1x1_f32_b256; a="--config 3";;
     4) n=st_gcn_multi3_fix_3A_mstcn_bf16_b64; a="--config 4 --dtype bf16";;
+    4f) n=st_gcn_multi3_fix_3A_mstcn_f32_b64; a="--config 4";;
     5) n=st_gcn_mstcn_1x1_deep_f16_b128; a="--config 5";;
   esac
-  tools/profile_bench.sh r04_$n $a > gpurun_out/${tag}_prof_$c.log 2>&1 || { tail -5 gpurun_out/${tag}_prof_$c.log; exit 1; }
+  tools/profile_bench.sh r05_$n $a > gpurun_out/${tag}_prof_$c.log 2>&1 || { tail -5 gpurun_out/${tag}_prof_$c.log; exit 1; }
   tail -3 gpurun_out/${tag}_prof_$c.log
-  rm -rf gpurun_out/prof_r04_$n
+  rm -rf gpurun_out/prof_r05_$n
 done
 exit $rc

@@ -19,7 +19,9 @@ def fam(name):
         return 'bneck_in/out kernels'
     if 'tconv_lean_kernel' in n or 'tconv_kernel' in n:      # (one C-ABI entry point, istgcn_tconv, dispatches to both)
         return 'tconv kernels'
-    for key in ('gcn_rc_fwd_kernel', 'gcn_rc_bwd_kernel', 'gcn_rc_wgrad_kernel', 'twg_ws_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
+    if 'twg_lean_kernel' in n or 'twg_ws_kernel' in n or 'tconv_rc_wgrad_kernel' in n or 'dz_colsum_kernel' in n:
+        return 'tconv_wgrad kernels'                          # (istgcn_tconv_wgrad: lean, round-2 and frame-tiled variants)
+    for key in ('gcn_rc_fwd_kernel', 'gcn_rc_bwd_kernel', 'gcn_rc_wgrad_kernel', 'gwg_ws_kernel', 'gcn_bwd_ws_kernel', 'tconv_wgrad_kernel', 'tconv_kernel', 'gcn_fwd_kernel', 'gcn_bwd_kernel', 'wgrad_reduce_kernel', 'block_out_fwd_kernel',
                 'block_out_bwd_kernel', 'affine2_kernel', 'bn_finalize_kernel', 'bn_bwd_coef_kernel', 'fold_fwd_kernel', 'fold_bwd_kernel',
                 'sgd_step_kernel', 'pool_fwd_kernel', 'pool_bwd_kernel', 'tcn_fold_fwd_kernel', 'tcn_fold_bwd_kernel', 'input_stats_kernel', 'input_apply_kernel', 'input_bwd_kernel', 'pack_'):
         if key in n:
@@ -67,6 +69,14 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
                  wave_cycles_parked=round(c.get('SQ_WAIT_ANY', 0) / wc, 3), wave_cycles_issue_stalled=round(c.get('SQ_WAIT_INST_ANY', 0) / wc, 3),
                  wave_cycles_issuing=round(c.get('SQ_ACTIVE_INST_ANY', 0) / wc, 3), mfma_instructions=int(c.get('SQ_INSTS_MFMA', 0)))
     res['kernels'][k] = r
+# whole-step HBM traffic: every kernel's counter bytes x its launches, over the steps the profiled command ran (bench.py
+# --steps 4 --warmup 2: six steps; set-up launches -- packs, the optimizer's first layout -- are in, i.e. an upper bound)
+STEPS = 6
+tot_b = sum(v.get('hbm_bytes_avg', 0) * v.get('launches', 0) for v in res['kernels'].values())
+res['steps_profiled'] = STEPS
+res['hbm_bytes_per_step'] = int(tot_b / STEPS)
+res['hbm_bytes_per_step_by_kernel'] = {k: int(v.get('hbm_bytes_avg', 0) * v.get('launches', 0) / STEPS) for k, v in res['kernels'].items()
+                                       if v.get('hbm_bytes_avg', 0) * v.get('launches', 0) / STEPS > 1e6}
 json.dump(res, open(os.path.join(OUT, '%s_pmc.json' % tag), 'w'), indent=1)
 print(json.dumps({k: {x: v[x] for x in ('hbm_bytes_avg', 'mfma_util') if x in v} for k, v in res['kernels'].items()}, indent=0))
 if stats:
