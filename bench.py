@@ -161,6 +161,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--h2d', action='store_true',
+                    help='feed every timed step from HOST memory through harness.DeviceStager (pinned double buffer, copy on a side\n'
+                         'stream under the previous step): the PCIe-inclusive rate.  Never the headline `value` (inputs resident in HBM).')
     ap.add_argument('--no-vendor-gemm', action='store_true', help='skip the 0.3 s hipBLASLt reference measurement (16-bit runs)')
     ap.add_argument('--breakdown', action='store_true', help='print a per-kernel-family table to stderr')
     ap.add_argument('--graph', action='store_true',
@@ -278,6 +281,16 @@ def main():
         for _ in range(args.steps):
             harness.train_step(model, opt, x, y, sync)
         barrier()
+    elif args.h2d:
+        # the same K steps, every batch coming from pageable host memory (what a DataLoader hands over)
+        xh, yh = x.cpu(), y.cpu()
+        ops.PROFILE = []
+        barrier()
+        t0 = time.perf_counter()
+        for data, label in harness.DeviceStager(((xh, yh) for _ in range(args.steps)), dev):
+            loss = harness.train_step(model, opt, data, label, sync)
+        barrier()
+        elapsed = time.perf_counter() - t0
     else:
         ops.PROFILE = []
         t0 = time.perf_counter()
@@ -385,6 +398,7 @@ def main():
             'config': {'workload': 'net/%s.py NTU xsub shape (N,3,%d,%d,2), %d clips/GPU, train step (fwd+bwd+SGD-nesterov), '
                                    'dropout 0.5, random-init weights' % (args.model, T, V, B),
                        'launch': 'fwd+bwd replayed from one hipGraph; all-reduce + SGD eager' if use_graph else 'eager',
+                       'input': 'host batches through harness.DeviceStager (pinned double buffer, H2D on a side stream) -- PCIe-inclusive' if args.h2d else 'resident in HBM',
                        'global_batch': B * world, 'parallelism': 'dp%d (batch-sharded, flat-bucket RCCL all-reduce)' % world,
                        'exchange': None if world == 1 else {
                            'backend': dist.get_backend(), 'world_size_reported': dist.get_world_size(),

@@ -896,6 +896,11 @@ extern "C" int istgcn_wgrad_reduce(const float* ws, long long slice, int nsl, fl
   return ISTGCN_OK;
 }
 
+// fewest joints for which the fp32 register-chained weight gradient (gcn_rc_f32.hip: 32-row frame tiles) is dispatched; below it
+// the 32 / V padding of the frame tile costs more matrix work than the round-1 kernel's flattened 128-row tiles save elsewhere
+#ifndef RCF32_WG_MINV
+#define RCF32_WG_MINV 20
+#endif
 extern "C" int istgcn_gcn_wgrad_rc_ok(int V, int Cin, int Cout, int K, int dtype);
 extern "C" int istgcn_gcn_wgrad_rc_f32(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T,
                                        int V, int Cin, int Cout, int K, int grid_cap, float* ws, long long ws_floats,
@@ -917,7 +922,7 @@ extern "C" int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, f
     static const bool rc_on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
     if (rc_on && istgcn_gcn_wgrad_rc_ok(V, Cin, Cout, K, dtype))
       return istgcn_gcn_wgrad_rc(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, dtype, grid_cap, ws, ws_floats, stream);
-    if (rc_on && dtype == 0 && V <= 32 && V >= 20 && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
+    if (rc_on && dtype == 0 && V <= 32 && V >= RCF32_WG_MINV && Cin >= 64 && Cin % 64 == 0 && Cout >= 64 && Cout % 64 == 0 && K <= 3)
       return istgcn_gcn_wgrad_rc_f32(dy, x, A, dW, S, NM, T, V, Cin, Cout, K, grid_cap, ws, ws_floats, stream);
   }
   TwgParams P{};

@@ -417,6 +417,83 @@ class GraphedStep:
         return self.loss
 
 
+def _host_copy(dst, src):
+    """dst (pinned, contiguous) <- src on the host.  Same type and contiguous: ONE memmove -- `Tensor.copy_` fans an 11.5 MB
+    copy out over every host core torch sees, which on the MI355X boxes (256 cores visible, 16 usable) took 16.9 ms against
+    0.18 ms single-threaded (tools/h2d_probe.py); else torch's converting copy."""
+    if src.dtype == dst.dtype and src.is_contiguous() and not src.is_cuda and src.numel() == dst.numel():
+        import ctypes
+        ctypes.memmove(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size())
+    else:
+        dst.copy_(src)
+
+
+class DeviceStager:
+    """Pinned host -> device staging of the training batches (first half): the reference moves every batch with
+    a blocking `data.float().to(dev)` from pageable memory (processor/recognition.py:258; `pin_memory` is commented out in
+    processor/processor.py:72).  Here the batches of any iterable of (data, label) host tensors -- a torch DataLoader over
+    feeder.Feeder included -- go through TWO pinned host buffers and TWO device buffers on a side stream: while step k
+    computes on the current stream, batch k+1 is copied host -> pinned -> device (`non_blocking`), and the consumer only
+    waits on an event.  Yields (data fp32 [N,C,T,V,M] on `device`, label int64 on `device`).
+
+        for data, label in DeviceStager(loader, dev):
+            loss = train_step(model, opt, data, label)
+
+    A yielded pair stays valid until the NEXT-but-one batch is requested (two buffers).  Batches of another shape (the last,
+    ragged one without drop_last) are staged through buffers of their own."""
+
+    def __init__(self, batches, device, depth=2):
+        self.batches, self.device, self.depth = batches, torch.device(device), max(2, int(depth))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._slots = {}
+
+    def _slot(self, i, data, label):
+        key = (i, tuple(data.shape), tuple(label.shape))
+        sl = self._slots.get(key)
+        if sl is None:
+            # the device buffers come out of the SIDE stream's allocator pool: a block handed out on the consumer's stream may
+            # still be the scratch of a kernel queued there, and the copy on the side stream would race with it (found by the
+            # test: a slot allocated mid-run -- the ragged last batch -- arrived corrupted)
+            with torch.cuda.stream(self.stream):
+                dx = torch.empty(data.shape, dtype=torch.float32, device=self.device)
+                dy = torch.empty(label.shape, dtype=torch.int64, device=self.device)
+            sl = self._slots[key] = (torch.empty(data.shape, dtype=torch.float32).pin_memory(),
+                                     torch.empty(label.shape, dtype=torch.int64).pin_memory(), dx, dy,
+                                     torch.cuda.Event(), torch.cuda.Event())
+        return sl
+
+    def _stage(self, i, data, label):
+        hx, hy, dx, dy, ready, free = self._slot(i % self.depth, data, label)
+        free.synchronize()                                 # the step that read this slot's device buffers has been issued AND run
+        _host_copy(hx, data)                               # (host-side cast to fp32 + copy into pinned memory)
+        _host_copy(hy, label)
+        with torch.cuda.stream(self.stream):
+            dx.copy_(hx, non_blocking=True)
+            dy.copy_(hy, non_blocking=True)
+            ready.record(self.stream)
+        return dx, dy, ready, free
+
+    def __iter__(self):
+        # batch i+1 is staged AFTER batch i has been handed over, i.e. while the consumer's step i runs on the GPU; its slot
+        # (depth 2: the one of batch i-1) is free once step i-1 has run -- `free` is recorded when the consumer comes back,
+        # behind the work it issued on the slot's buffers
+        pending, i = None, 0
+        for data, label in self.batches:
+            if pending is not None:
+                dx, dy, ready, free = pending
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ready)                      # device-side wait: the host runs ahead
+                yield dx, dy
+                free.record(torch.cuda.current_stream(self.device))
+            pending = self._stage(i, data, label)
+            i += 1
+        if pending is not None:
+            dx, dy, ready, free = pending
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            yield dx, dy
+            free.record(torch.cuda.current_stream(self.device))
+
+
 def weights_init(m):
     """recognition.py:31-44 (applied by REC_Processor.load_model via model.apply)."""
     classname = m.__class__.__name__

@@ -263,7 +263,9 @@ def test_blocks_wide_golden(golden, kind, dt):
             #  terms -- the branch outputs are recomputed from the folded taps: measured 0.106 in bfloat16, 1.5x the gate)
             # (the bottleneck block's branches are 8 / 11 channels wide: measured 0.22 in bfloat16, 0.034 in float16 -- the
             #  ratio of the two formats' rounding steps, i.e. rounding noise, not a defect)
-            gate = 0.3 if (kind == 'st_gcn_mstcn_1x1' and dt == torch.bfloat16) else 1.5 * tol_g
+            # (and 0.20 in float16 on the round-1/2 graph-conv kernels -- ISTGCN_GCN_RC=0, tests/test_gpu_overrides.py --, which
+            #  round the aggregated tile to 16 bits in LDS before the channel contraction)
+            gate = 0.3 if (kind == 'st_gcn_mstcn_1x1' and (dt == torch.bfloat16 or os.environ.get('ISTGCN_GCN_RC') == '0')) else 1.5 * tol_g
             assert close(name + '_dmst', mst.grad, g[b + 'dmst'], gate, dt)
         for k, v in blk.state_dict().items():
             if 'running' in k:

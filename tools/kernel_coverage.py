@@ -41,7 +41,11 @@ bk, bw = read(os.path.join(ROOT, 'gpurun_out', 'kernel_coverage_bench.tsv'))
 print('| kernel template | instantiations built | launched by the GPU suite | launched by bench configs | bench configurations | tests (up to 3 of n) |')
 print('|---|---|---|---|---|---|')
 for b in sorted(built, key=lambda b: (-(len(bk.get(b, ())) > 0), -len(built[b]))):
-    tests = sorted({t.split('::')[0].replace('tests/', '') + '::' + t.split('::')[1].split('[')[0] for t in tw.get(b, ())})
+    # reference-pinned (golden) tests first, then whole-model tests, then the rest
+    def rank(t):
+        return (0 if 'golden' in t else 1 if 'model' in t or 'reference' in t else 2, t)
+    tests = sorted({t.split('::')[0].replace('tests/', '') + '::' + t.split('::')[1].split('[')[0] + (' ' + t.split('] ')[1] if '] {' in t else '')
+                    for t in tw.get(b, ())}, key=rank)
     cfgs = sorted({t[len('bench:'):] for t in bw.get(b, ())})
     print('| `%s` | %d | %d | %d | %s | %s |' % (b, len(built[b]), len(tk.get(b, ())), len(bk.get(b, ())), ', '.join(cfgs) or '--',
                                                  (', '.join(tests[:3]) + (' (of %d)' % len(tests) if len(tests) > 3 else '')) or '**none**'))
