@@ -88,9 +88,14 @@ int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int* CCi, int* 
  * 32-channel tile); for it dx may be NULL: only dA is computed. */
 int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
 long long istgcn_gcn_bwd_rc_offset(int Cin, int Cout, int K, int dtype);
+/* addend_mask (round 5; NULL or, where istgcn_gcn_bwd_addend_mask_ok(...) == 1: the register-chained kernel): the ReLU byte mask
+ * of istgcn_block_out_fwd over the addend's shape -- dx += addend * [bit], i.e. the identity-residual gradient
+ * dout * [out > 0] of the st_gcn block (net/st_gcnold.py:181-182,201-203) read from dout itself, so that istgcn_block_out_bwd
+ * need not write it (dres == NULL there). */
+int istgcn_gcn_bwd_addend_mask_ok(int V, int Cin, int Cout, int K, int dtype);
 int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
-                        const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout, int K,
-                        int nnz_cap, int dtype, int grid_cap, void* stream);
+                        const void* addend, const unsigned char* addend_mask, void* dx, float* dA, int NM, int T, int V,
+                        int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream);
 int istgcn_gcn_wgrad(const void* dy, const void* x, const float* A, float* dW, float* S, int NM, int T, int V, int Cin,
                      int Cout, int K, int nnz_cap, int dtype, int grid_cap, float* ws, long long ws_floats,
                      void* stream);
@@ -220,7 +225,10 @@ int istgcn_bn_bwd_coef(double* stats, int stats_rep, int clear, double count, co
  * istgcn_block_out_bwd: dres = dout * [out > 0] (the gradient of both the residual branch and, after dropout, of
  *   tcn.3); stats2 += (sum dres*mask, sum dres*mask*zhat); statsr += (sum dres, sum dres*rhat) when the residual
  *   branch has a BatchNorm (r = its input, coefr = its coef[4][C]); r == NULL otherwise.
+ *   dres may be NULL when relu_mask is given (round 5): the sums only; every consumer of dres then takes dout and the
+ *   byte mask itself (istgcn_affine2m, the addend_mask of istgcn_gcn_bwd_data) -- one tensor write less per block.
  * istgcn_affine2: out = abc[0]*d*mask + abc[1]*x + abc[2]  (elementwise part of BatchNorm backward; x may be NULL).
+ * istgcn_affine2m: the same with d := d * [bit of relu_mask] first (relu_mask NULL: istgcn_affine2).
  * relu_mask (optional, both directions; only where istgcn_relu_mask_ok(C, dtype) == 1): [rows * C / vector width] bytes,
  *   bit j of byte i = (element j of the i-th 16-byte vector of `out`, as stored, is > 0).  The forward writes it; given
  *   to the backward it replaces the read of `out` (which may then be NULL): 1/16 of that tensor's bytes. */
@@ -234,6 +242,8 @@ int istgcn_block_out_bwd(const void* dout, const void* out, const unsigned char*
                          const unsigned long long* seed_epoch, int dtype, void* stream);
 int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C, float p_drop,
                    unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream);
+int istgcn_affine2m(const void* d, const unsigned char* relu_mask, const void* x, const float* abc, void* out, long long rows,
+                    int C, float p_drop, unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream);
 
 /* Global average pooling of the trunk output and its backward (net/st_gcnold.py:89-91: F.avg_pool2d over (T, V), then the
  * mean over the M persons of a clip).  y [NM][P = T*V][C] in `dtype`.

@@ -564,12 +564,19 @@ extern "C" int istgcn_gcn_bwd_geometry(int Cin, int Cout, int K, int dtype, int*
 extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype);
 extern "C" long long istgcn_gcn_bwd_rc_offset(int Cin, int Cout, int K, int dtype);
 extern "C" int istgcn_gcn_bwd_data_rc(const void* dy, const void* x, const float* A, const float* pattern, const void* Wq,
-                                      const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
-                                      int K, int dtype, int grid_cap, void* stream);
+                                      const void* addend, const unsigned char* addend_mask, void* dx, float* dA, int NM, int T,
+                                      int V, int Cin, int Cout, int K, int dtype, int grid_cap, void* stream);
+
+// Can istgcn_gcn_bwd_data take its addend as (tensor, ReLU byte mask)?  Only the register-chained kernel does (istgcn.h).
+extern "C" int istgcn_gcn_bwd_addend_mask_ok(int V, int Cin, int Cout, int K, int dtype) {
+  static const bool rc_on = [] { const char* e = getenv("ISTGCN_GCN_RC"); return !e || atoi(e) != 0; }();
+  return (rc_on && V <= 32 && Cin != 3 && Cin % 8 == 0 && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
+          istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype) >= 0) ? 1 : 0;
+}
 
 extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A, const float* pattern, const void* Wb,
-                                   const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
-                                   int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
+                                   const void* addend, const unsigned char* addend_mask, void* dx, float* dA, int NM, int T,
+                                   int V, int Cin, int Cout, int K, int nnz_cap, int dtype, int grid_cap, void* stream) {
   if (!dy || !A || !Wb || (!dx && !dA)) return ISTGCN_EINVAL;
   if (dA && !x) return ISTGCN_EINVAL;
   if (V < 1 || V > 128 || Cin < 1 || Cout < 1 || K < 1 || K > 4 || NM < 0 || T < 0) return ISTGCN_EINVAL;
@@ -585,11 +592,12 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
         (Cin != 3 ? dx != nullptr : (!dx && dA && !addend))) {
       const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
       if (off >= 0)
-        return istgcn_gcn_bwd_data_rc(dy, x, A, pattern, reinterpret_cast<const char*>(Wb) + (size_t)off * 2, addend, dx, dA, NM, T, V,
-                                      Cin, Cout, K, dtype, grid_cap, stream);
+        return istgcn_gcn_bwd_data_rc(dy, x, A, pattern, reinterpret_cast<const char*>(Wb) + (size_t)off * 2, addend, addend_mask, dx, dA,
+                                      NM, T, V, Cin, Cout, K, dtype, grid_cap, stream);
     }
   }
   if (!dx) return ISTGCN_EINVAL;          // dx == NULL (adjacency gradient only) exists for the 16-bit first layer only; callers allocate dx otherwise
+  if (addend_mask) return ISTGCN_EINVAL;  // the masked addend exists in the register-chained kernel only (istgcn_gcn_bwd_addend_mask_ok)
   GbdParams P{};
   P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wb = Wb; P.addend = addend; P.dx = dx; P.dA = dA;
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout; P.K = K; P.nnz_cap = nnz_cap;

@@ -45,6 +45,7 @@ namespace {
 
 struct RcBwdParams {
   const void* dy; const void* x; const float* A; const float* pat; const void* Wq; const void* addend; void* dx; float* dA;
+  const unsigned char* addm;     // ADD == 2: the ReLU byte mask of the addend (addend := addend * [bit]; one byte per 8 channels)
   int NM, T, V, Cin, Cout;
   int nfw, step_n, step_t, gy;
 };
@@ -55,14 +56,16 @@ constexpr int BIMG_BYTES = 16 * BIMG_RS * 4;
 __device__ static inline int perm23(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
 
 // SO = Cout / 16 (k-steps of the contraction over output channels), NCT = 32-channel tiles of dx per workgroup slice,
-// DA / ADD = with the adjacency gradient / with an addend.
+// DA = with the adjacency gradient; ADD = 0: no addend, 1: dx += addend, 2: dx += addend * [ReLU mask bit] -- the st_gcn block's
+// identity-residual gradient dout * [out > 0] taken from dout and the forward's byte mask (net/st_gcnold.py:181-182,201-203)
+// instead of a dres tensor written for it.
 // (HIP: the second launch bound is WAVES PER SIMD -- 2 = the 8 waves of one workgroup per CU, 256 registers each)
-template <typename T, int SO, int K, int NCT, bool DA, bool ADD, int CN>
+template <typename T, int SO, int K, int NCT, bool DA, int ADD, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams P) {
   // CN != 0: the models' first layer (CN = 3 input channels, net/st_gcnold.py:44).  Its input needs no gradient, so only
   // the adjacency gradient is computed (no dx chain, no image, no stores): one zero-padded 32-channel tile per frame,
   // x rows read with 16-bit loads.
-  static_assert(CN == 0 || (NCT == 1 && DA && !ADD && CN <= 4), "narrow input: dA only");
+  static_assert(CN == 0 || (NCT == 1 && DA && ADD == 0 && CN <= 4), "narrow input: dA only");
   using E = Elem<T>;
   typedef typename E::frag frag_t;
   constexpr int COUT = 16 * SO;
@@ -230,10 +233,19 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       const size_t fo = ((size_t)fn * P.T + ft) * x_frm;
       const rsrc_t ro = make_rsrc(dxg + fo, xfrm_b);
       u32x4 av[2];
-      if constexpr (ADD) {
+      uint32_t mb[2] = {0xffu, 0xffu};
+      if constexpr (ADD != 0) {
         const rsrc_t ra = make_rsrc(addg + fo, xfrm_b);
         av[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp) * orow_b, 0, RCB_ADD_AUX);
         av[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, ooff + (unsigned)(2 * rp + 1) * orow_b, 0, RCB_ADD_AUX);
+        if constexpr (ADD == 2) {
+          // one mask byte per 16-byte vector: frame f starts at byte f * V * Cin / 8, row w at w * Cin / 8 (rows >= V: outside
+          // the descriptor -> 0 -> nothing added to rows whose stores are dropped anyway)
+          const rsrc_t rm = make_rsrc(P.addm + (fo >> 3), (unsigned)(V * Cin) >> 3);
+          const unsigned mrow = (unsigned)Cin >> 3, moff = (unsigned)(4 * it + chunk);
+          mb[0] = (uint32_t)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rm, moff + (unsigned)(2 * rp) * mrow, 0, RCB_ADD_AUX);
+          mb[1] = (uint32_t)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(rm, moff + (unsigned)(2 * rp + 1) * mrow, 0, RCB_ADD_AUX);
+        }
       }
       const u32x4 u0 = *reinterpret_cast<const u32x4*>(img + rp * BIMG_RS + 8 * chunk);
       const u32x4 u1 = *reinterpret_cast<const u32x4*>(img + rp * BIMG_RS + 8 * chunk + 4);
@@ -242,7 +254,18 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       ev[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x05040100u); od[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x07060302u);
       ev[2] = __builtin_amdgcn_perm(u1[1], u1[0], 0x05040100u); od[2] = __builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u);
       ev[3] = __builtin_amdgcn_perm(u1[3], u1[2], 0x05040100u); od[3] = __builtin_amdgcn_perm(u1[3], u1[2], 0x07060302u);
-      if constexpr (ADD) {
+      if constexpr (ADD == 2) {
+        // keep the 16-bit halves whose mask bit is set (element j of the vector = bit j)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t lo = (uint32_t)(-(int32_t)((mb[m2] >> (2 * q)) & 1u)) & 0x0000ffffu;
+            const uint32_t hi = (uint32_t)(-(int32_t)((mb[m2] >> (2 * q + 1)) & 1u)) & 0xffff0000u;
+            av[m2][q] &= (lo | hi);
+          }
+      }
+      if constexpr (ADD != 0) {
         const frag_t a0 = __builtin_bit_cast(frag_t, av[0]), a1 = __builtin_bit_cast(frag_t, av[1]);
         frag_t o0 = __builtin_bit_cast(frag_t, ev), o1 = __builtin_bit_cast(frag_t, od);
 #pragma unroll
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   }
 }
 
-template <typename T, int SO, int K, int NCT, bool DA, bool ADD, int CN = 0>
+template <typename T, int SO, int K, int NCT, bool DA, int ADD, int CN = 0>
 int rc_bwd_launch(RcBwdParams P, int grid_cap, hipStream_t stream) {
   auto kfn = gcn_rc_bwd_kernel<T, SO, K, NCT, DA, ADD, CN>;
   size_t lds = (size_t)NCT * K * SO * 64 * 16 + 8 * BIMG_BYTES + (size_t)(K + 1) * 2 * 64 * 16;      // (+ the identity fragments)
@@ -383,11 +406,14 @@ template <typename T, int SO, int K, int NCT>
 int rc_bwd_flags(const RcBwdParams& P, int grid_cap, hipStream_t stream) {
   if constexpr ((size_t)NCT * K * SO * 64 * 16 > 100 * 1024) return ISTGCN_EINVAL;
   else {
-    const bool da = P.dA != nullptr, add = P.addend != nullptr;
-    if (da && add) return rc_bwd_launch<T, SO, K, NCT, true, true>(P, grid_cap, stream);
-    if (da) return rc_bwd_launch<T, SO, K, NCT, true, false>(P, grid_cap, stream);
-    if (add) return rc_bwd_launch<T, SO, K, NCT, false, true>(P, grid_cap, stream);
-    return rc_bwd_launch<T, SO, K, NCT, false, false>(P, grid_cap, stream);
+    const bool da = P.dA != nullptr;
+    const int add = P.addend == nullptr ? 0 : (P.addm ? 2 : 1);
+    if (da && add == 2) return rc_bwd_launch<T, SO, K, NCT, true, 2>(P, grid_cap, stream);
+    if (da && add == 1) return rc_bwd_launch<T, SO, K, NCT, true, 1>(P, grid_cap, stream);
+    if (da) return rc_bwd_launch<T, SO, K, NCT, true, 0>(P, grid_cap, stream);
+    if (add == 2) return rc_bwd_launch<T, SO, K, NCT, false, 2>(P, grid_cap, stream);
+    if (add == 1) return rc_bwd_launch<T, SO, K, NCT, false, 1>(P, grid_cap, stream);
+    return rc_bwd_launch<T, SO, K, NCT, false, 0>(P, grid_cap, stream);
   }
 }
 
@@ -421,10 +447,10 @@ template <typename T>
 int rc_bwd_first_layer(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
   if (P.Cout != 64 || !P.dA || P.addend || P.dx) return ISTGCN_EINVAL;
   switch (K) {
-    case 1: return rc_bwd_launch<T, 4, 1, 1, true, false, 3>(P, grid_cap, stream);
-    case 2: return rc_bwd_launch<T, 4, 2, 1, true, false, 3>(P, grid_cap, stream);
-    case 3: return rc_bwd_launch<T, 4, 3, 1, true, false, 3>(P, grid_cap, stream);
-    case 4: return rc_bwd_launch<T, 4, 4, 1, true, false, 3>(P, grid_cap, stream);
+    case 1: return rc_bwd_launch<T, 4, 1, 1, true, 0, 3>(P, grid_cap, stream);
+    case 2: return rc_bwd_launch<T, 4, 2, 1, true, 0, 3>(P, grid_cap, stream);
+    case 3: return rc_bwd_launch<T, 4, 3, 1, true, 0, 3>(P, grid_cap, stream);
+    case 4: return rc_bwd_launch<T, 4, 4, 1, true, 0, 3>(P, grid_cap, stream);
   }
   return ISTGCN_EINVAL;
 }
@@ -453,11 +479,11 @@ extern "C" int istgcn_gcn_bwd_rc_layout(int Cin, int Cout, int K, int dtype) {
 }
 
 extern "C" int istgcn_gcn_bwd_data_rc(const void* dy, const void* x, const float* A, const float* pattern, const void* Wq,
-                                      const void* addend, void* dx, float* dA, int NM, int T, int V, int Cin, int Cout,
-                                      int K, int dtype, int grid_cap, void* stream) {
-  if (!istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) || V > 32) return ISTGCN_EINVAL;
+                                      const void* addend, const unsigned char* addend_mask, void* dx, float* dA, int NM, int T,
+                                      int V, int Cin, int Cout, int K, int dtype, int grid_cap, void* stream) {
+  if (!istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) || V > 32 || (addend_mask && (!addend || Cin % 8 != 0))) return ISTGCN_EINVAL;
   RcBwdParams P{};
-  P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wq = Wq; P.addend = addend; P.dx = dx; P.dA = dA;
+  P.dy = dy; P.x = x; P.A = A; P.pat = pattern; P.Wq = Wq; P.addend = addend; P.addm = addend_mask; P.dx = dx; P.dA = dA;
   P.NM = NM; P.T = T; P.V = V; P.Cin = Cin; P.Cout = Cout;
   if (dtype == 1) return rc_bwd_T<__bf16>(P, K, grid_cap, (hipStream_t)stream);
   return rc_bwd_T<_Float16>(P, K, grid_cap, (hipStream_t)stream);

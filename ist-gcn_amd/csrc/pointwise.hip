@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT) void block_out_fwd_kernel(const T* z, const flo
   }
 }
 
-// d = dout*[out>0] -> dres ; stats2 += (sum d*mask, sum d*mask*zhat) ; statsr += (sum d, sum d*rhat)
+// d = dout*[out>0] -> dres (or nowhere: dres == NULL) ; stats2 += (sum d*mask, sum d*mask*zhat) ; statsr += (sum d, sum d*rhat)
 // HASR: the residual branch has its own BatchNorm (strided 1x1 conv, 2 of 10 blocks); a compile-time switch because the
 // second set of per-channel constants and sums costs 32 registers = one resident wave per SIMD (126 -> 94 VGPRs)
 template <typename T, int VW, bool HASR>
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
         b2[j] += d * (rv[j] - mr[j]) * rr_[j];
       }
     }
-    store_vec<T, VW>(dres + e0, dv);
+    if (dres) store_vec<T, VW>(dres + e0, dv);           // (round 5: NULL when every consumer takes dout + the ReLU mask itself)
   }
   // block reduction over the NT/QC threads that share a channel vector
 #pragma unroll
@@ -229,9 +229,11 @@ __global__ __launch_bounds__(NT) void block_out_bwd_kernel(const T* dout, const 
   bn_tail_run(tail, gridDim.x, reinterpret_cast<unsigned*>(&red[0][0]));                              // tcn.3's backward coefficients, when the caller armed them
 }
 
+// rmask (or NULL): the forward's ReLU byte mask of the tensor d is the gradient of -- d := d * [bit] first, i.e. the kernel reads
+// dout itself where block_out_bwd used to write dres = dout * [out > 0] for it (one byte per VW-element vector, VW = 16 bytes)
 template <typename T, int VW>
-__global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, const float* abc, T* out, size_t rows, int C,
-                                                    DropCfg D) {
+__global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const unsigned char* rmask, const T* x, const float* abc, T* out,
+                                                    size_t rows, int C, DropCfg D) {
   uint32_t dk0, dk1;
   drop_key(D, dk0, dk1);
   const int QC = C / VW;
@@ -253,6 +255,11 @@ __global__ __launch_bounds__(NT) void affine2_kernel(const T* d, const T* x, con
     float dv[VW], xv[VW], m[VW];
     load_vec<T, VW>(d + e0, dv);
     if (x) load_vec<T, VW, true>(x + e0, xv);
+    if (rmask) {
+      const unsigned bits = rmask[idx];
+#pragma unroll
+      for (int j = 0; j < VW; ++j) dv[j] = (bits >> j) & 1u ? dv[j] : 0.f;
+    }
     if (D.on) {
       if constexpr (VW % 4 == 0) drop_scales<VW>(m, e0, D.thr, D.inv_keep, dk0, dk1);
       else {
@@ -458,7 +465,8 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const uns
                                     const float* coef2, const void* r, const float* coefr, void* dres, double* stats2,
                                     double* statsr, int stats_rep, long long rows, int C, float p_drop,
                                     unsigned long long seed, const unsigned long long* seed_epoch, int dtype, void* stream) {
-  if (!dout || (!out && !relu_mask) || !z || !coef2 || !dres || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
+  if (!dout || (!out && !relu_mask) || !z || !coef2 || !stats2 || stats_rep < 1 || rows < 0 || C < 1) return ISTGCN_EINVAL;
+  if (!dres && !relu_mask) return ISTGCN_EINVAL;       // without dres the consumers re-derive it from dout and the byte mask
   if (relu_mask && !istgcn_relu_mask_ok(C, dtype)) return ISTGCN_EINVAL;
   if ((r != nullptr) != (coefr != nullptr) || (r && !statsr)) return ISTGCN_EINVAL;
   if (!istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f) return ISTGCN_EINVAL;
@@ -491,18 +499,25 @@ extern "C" int istgcn_block_out_bwd(const void* dout, const void* out, const uns
   return ISTGCN_OK;
 }
 
-extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C,
-                              float p_drop, unsigned long long seed, const unsigned long long* seed_epoch, int dtype,
-                              void* stream) {
+extern "C" int istgcn_affine2m(const void* d, const unsigned char* relu_mask, const void* x, const float* abc, void* out,
+                               long long rows, int C, float p_drop, unsigned long long seed,
+                               const unsigned long long* seed_epoch, int dtype, void* stream) {
   if (!d || !abc || !out || rows < 0 || C < 1 || !istgcn_dtype_ok(dtype) || p_drop < 0.f || p_drop > 1.f)
     return ISTGCN_EINVAL;
+  if (relu_mask && !istgcn_relu_mask_ok(C, dtype)) return ISTGCN_EINVAL;      // (the mask is one byte per 16-byte vector)
   if (rows == 0) return ISTGCN_OK;
   const int vw = dtype == 0 ? pick_vw<float>(C, false) : pick_vw<__bf16>(C, false);
   const DropCfg D = make_drop(p_drop, seed, seed_epoch);
   const dim3 grid(ew_grid((size_t)rows * (C / vw), ISTGCN_X_AFFCAP));
-  EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
+  EW_CASES(DISPATCH_VW(affine2_kernel, ET, VWB, grid, (const ET*)d, relu_mask, (const ET*)x, abc, (ET*)out, (size_t)rows, C, D));
   ISTGCN_CHECK_LAUNCH();
   return ISTGCN_OK;
+}
+
+extern "C" int istgcn_affine2(const void* d, const void* x, const float* abc, void* out, long long rows, int C,
+                              float p_drop, unsigned long long seed, const unsigned long long* seed_epoch, int dtype,
+                              void* stream) {
+  return istgcn_affine2m(d, nullptr, x, abc, out, rows, C, p_drop, seed, seed_epoch, dtype, stream);
 }
 
 extern "C" int istgcn_pool_fwd(const void* y, float* psum, int NM, int P, int C, int S, int dtype, void* stream) {

@@ -395,14 +395,21 @@ class STGCNBlockFn(torch.autograd.Function):
             dout = dout.to(dt)
         pk = cfg.packed or {}
         # 4'. ReLU + residual split, BatchNorm-backward sums of tcn.3 (and of the residual BN)
-        dres, st2b, strb, (abc2, dg2, db2) = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True,
-                                                               epoch=cfg.seed_epoch, relu_mask=rmask,
-                                                               tail=(NM * Tz * V, g2, training))
         # (bottleneck blocks at 64 / 128 channels in 16-bit storage: dz is never written -- the stream kernel that consumes it
         #  forms it in registers from dres and z, dropout mask included; ops.BNECK_FUSE_BN = False keeps the separate pass)
         fuse_in = (cfg.tcn == 'bneck' and ops.BNECK_FUSE_BN and _bneck_rc(cfg, V, dt, NM * T * V) and
                    ops.bneck_bwd_in_ok(cout, cfg.width, _pad_width(cfg.width, dt), dt))
-        dz = None if fuse_in else ops.affine2(dres, z, abc2, p, seed, epoch=cfg.seed_epoch)
+        # Round 5: dres = dout * [out > 0] is not written where every reader can take dout and the forward's 1-bit-per-element
+        # ReLU mask itself -- `affine2` (tcn.3's and the residual BatchNorm's backward) always can, the identity-residual addend
+        # of the graph conv's data gradient where the register-chained kernel serves it; the fused bottleneck stream kernel
+        # reads dres (one tensor write less per block: ops.DRES_FREE = False / ISTGCN_DRES_FREE=0 keeps the tensor)
+        dres_free = (ops.DRES_FREE and rmask is not None and not fuse_in and
+                     (cfg.residual != 'id' or ops.gcn_bwd_addend_mask_ok(V, cin, cout, A_eff.shape[0], dt)))
+        dres, st2b, strb, (abc2, dg2, db2) = ops.block_out_bwd(dout, out, z, coef2, r, coefr, p, seed, scratch=True,
+                                                               epoch=cfg.seed_epoch, relu_mask=rmask,
+                                                               tail=(NM * Tz * V, g2, training), want_dres=not dres_free)
+        dsrc, dmask = (dout, rmask) if dres_free else (dres, None)       # dres as (tensor, mask) for its readers
+        dz = None if fuse_in else ops.affine2(dsrc, z, abc2, p, seed, epoch=cfg.seed_epoch, relu_mask=dmask)
         # 2'. temporal conv: weight gradient + data gradient (ReLU mask of BN1 and its backward sums fused)
         taps, in_mul = ops.conv_taps_fwd(k, s)
         pre1 = coef1[:2].contiguous()
@@ -503,17 +510,17 @@ class STGCNBlockFn(torch.autograd.Function):
         dWr = dbr = dgr = dbetar = None
         dx = dA = None
         if ctx.needs_input_grad[4] or need_A or cfg.residual == 'conv':
-            addend = dres if cfg.residual == 'id' else None
+            addend = dsrc if cfg.residual == 'id' else None
             pat, cap = cfg.pattern, cfg.nnz_cap
             if need_A and pat is None:
                 pat, cap = torch.ones_like(A_eff), A_eff.numel()
             # (first block: the input needs no gradient -- only the adjacency gradient is computed where the kernel has that form)
             dx, dA = ops.gcn_bwd_data(dg, A_eff, Wg3, x=x, addend=addend, want_dA=need_A, nnz_cap=cap, dA_out=buf_A,
-                                      pattern=pat, wb=pk.get('wb'),
+                                      pattern=pat, wb=pk.get('wb'), addend_mask=dmask if addend is not None else None,
                                       want_dx=ctx.needs_input_grad[4] or cfg.residual == 'conv')
         if cfg.residual == 'conv':
             abcr, dgr, dbetar = ops.bn_bwd_coef(strb, NM * Tz * V, gr, coefr, training, clear=True)
-            dr = ops.affine2(dres, r, abcr)
+            dr = ops.affine2(dsrc, r, abcr, relu_mask=dmask)
             dWr3, dbr = ops.tconv_wgrad(dr, x, [0], in_mul=s, out=buf_r, want_bias=not training)     # (as for tcn.2 above)
             dWr = dWr3.view(cout, cin)
             eye = _eye(V, x.device)

@@ -588,8 +588,13 @@ def first_layer_da_only(cin, cout, K, dtype, V):
     return cin == 3 and V <= 32 and dtype != torch.float32 and bool(_lib.load().istgcn_gcn_bwd_rc_layout(cin, cout, K, _DT[dtype]))
 
 
+def gcn_bwd_addend_mask_ok(V, cin, cout, K, dtype):
+    """Does istgcn_gcn_bwd_data take its addend as (tensor, ReLU byte mask) for this shape (the register-chained kernel)?"""
+    return dtype != torch.float32 and bool(_lib.load().istgcn_gcn_bwd_addend_mask_ok(V, cin, cout, K, _DT[dtype]))
+
+
 def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, grid_cap=0, dA_out=None, pattern=None, wb=None,
-                 want_dx=True):
+                 want_dx=True, addend_mask=None):
     """istgcn_gcn_bwd_data -> (dx [NM,T,V,Cin], dA [K,V,V] fp32 or None).  pattern [K,V,V] fp32 (non-zero = entry whose
     gradient is wanted; None = the non-zeros of A): pass the constant adjacency of A = B * importance so that an
     importance value of exactly 0 keeps its gradient, or ones for a dense learnable A (autograd of tgcn.py:86)."""
@@ -618,9 +623,12 @@ def gcn_bwd_data(dy, A, w3, x=None, addend=None, want_dA=True, nnz_cap=None, gri
         # register-chained kernel (V <= 32) has no such limit
         raise RuntimeError('istgcn_gcn_bwd_data: the adjacency gradient of a graph with V = %d > 32 joints supports at most '
                            '4096 pattern entries (got nnz_cap = %d): pass a sparser `pattern`' % (V, nnz_cap))
-    dv = _check_dev(dy, x, A, pattern, wb, addend, dx, dA)
-    _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(pattern), _ptr(wb), _ptr(addend), _ptr(dx),
-          _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy), _gcap('istgcn_gcn_bwd_data', grid_cap), _stream(dy),
+    if addend_mask is not None:
+        assert addend is not None and addend_mask.dtype == torch.uint8 and addend_mask.numel() * 8 == addend.numel()
+    dv = _check_dev(dy, x, A, pattern, wb, addend, addend_mask, dx, dA)
+    _call('istgcn_gcn_bwd_data', _ptr(dy), _ptr(x if want_dA else None), _ptr(A), _ptr(pattern), _ptr(wb), _ptr(addend),
+          _ptr(addend_mask), _ptr(dx), _ptr(dA), NM, T, V, Cin, Cout, K, int(nnz_cap), dtype_code(dy),
+          _gcap('istgcn_gcn_bwd_data', grid_cap), _stream(dy),
           work=(2.0 * NM * T * V * Cout * K * Cin + 2.0 * NM * T * V * V * K * Cin,
                 float(NM * T * V) * (Cout + Cin * (1 + (1 if want_dA else 0) + (1 if addend is not None else 0))) * _esz(dy)), dev=dv)
     return dx, dA
@@ -691,6 +699,9 @@ def _scratch_consumed(stats):
 # ms/step, config 1: 7.46 vs 7.33, config 5: 46.9 vs 47.0 -- the serial tail of the last workgroup costs what the 5 us launch
 # did), hence off by default; ISTGCN_BN_TAILS=1 turns them on.
 BN_TAILS = os.environ.get('ISTGCN_BN_TAILS', '0') == '1'
+# Round 5: the st_gcn block's backward does not write dres = dout * [out > 0]; its readers take dout + the ReLU byte mask
+# (functional.STGCNBlockFn.backward).  ISTGCN_DRES_FREE=0: the tensor is written as before (A/B).
+DRES_FREE = os.environ.get('ISTGCN_DRES_FREE', '1') != '0'
 _TAIL = threading.local()
 _TICKETS = {}                # stats data_ptr -> int32[1] ticket of the "last workgroup finalises" protocol (zero between launches)
 
@@ -836,13 +847,16 @@ def block_out_fwd(z, coef2, res=None, coefr=None, p_drop=0.0, seed=0, epoch=None
 
 
 def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, scratch=False, epoch=None, relu_mask=None,
-                  tail=None):
+                  tail=None, want_dres=True):
     """-> (dres = dout*[out>0], stats2, statsr or None); scratch=True: the sums go to `stats_scratch` slots 0 / 1
     (consume them with bn_bwd_coef(clear=True)).  relu_mask: the forward's byte mask; `out` is then not read.
     tail = (count, gamma, training): tcn.3's backward coefficients are computed by the kernel's last workgroup (or by the
     stand-alone kernel right behind it) and returned as a fourth value (abc, dgamma, dbeta)."""
     C = z.shape[-1]
-    dres = torch.empty_like(z)
+    # want_dres=False (needs relu_mask): only the sums -- the consumers take dout and the byte mask themselves (affine2 with
+    # relu_mask, gcn_bwd_data with addend_mask); the first returned value is then None
+    assert want_dres or relu_mask is not None
+    dres = torch.empty_like(z) if want_dres else None
     if scratch:
         st2 = stats_scratch(0, C, z.device)
         str_ = stats_scratch(1, C, z.device) if r is not None else None
@@ -852,7 +866,7 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
     assert dout.shape == z.shape and dout.dtype == z.dtype and (out is None or out.shape == z.shape)
     assert out is not None or relu_mask is not None
     dv = _check_dev(dout, out, relu_mask, z, coef2, r, coefr, dres, st2, str_)
-    nt = (4 if r is not None else 3) + (1.0 / 16 if relu_mask is not None else 1)
+    nt = (4 if r is not None else 3) + (1.0 / 16 if relu_mask is not None else 1) - (0 if want_dres else 1)
     res2 = None
     if tail is not None:
         res2 = bn_bwd_coef(st2, tail[0], tail[1], coef2, tail[2], clear=True, defer=True)
@@ -866,13 +880,15 @@ def block_out_bwd(dout, out, z, coef2, r=None, coefr=None, p_drop=0.0, seed=0, s
     return dres, st2, str_
 
 
-def affine2(d, x, abc, p_drop=0.0, seed=0, epoch=None):
-    """out = abc[0]*d*dropmask + abc[1]*x + abc[2]  (BatchNorm backward, elementwise part)."""
+def affine2(d, x, abc, p_drop=0.0, seed=0, epoch=None, relu_mask=None):
+    """out = abc[0]*d*dropmask + abc[1]*x + abc[2]  (BatchNorm backward, elementwise part).  relu_mask: d := d * [bit] first
+    (the forward's byte mask of block_out_fwd: d is then dout itself, not the dres block_out_bwd would have written)."""
     out = torch.empty_like(d)
-    dv = _check_dev(d, x, abc, out)
-    _call('istgcn_affine2', _ptr(d), _ptr(x), _ptr(abc), _ptr(out), ctypes.c_longlong(_rows(d)), d.shape[-1],
+    dv = _check_dev(d, relu_mask, x, abc, out)
+    _call('istgcn_affine2m', _ptr(d), _ptr(relu_mask), _ptr(x), _ptr(abc), _ptr(out), ctypes.c_longlong(_rows(d)), d.shape[-1],
           ctypes.c_float(p_drop), ctypes.c_ulonglong(seed), _epoch_ptr(epoch, d), dtype_code(d), _stream(d),
-          work=(4.0 * d.numel(), float(d.numel()) * (3 if x is not None else 2) * _esz(d)), dev=dv)
+          work=(4.0 * d.numel(), float(d.numel()) * ((3 if x is not None else 2) + (1.0 / 16 if relu_mask is not None else 0)) * _esz(d)),
+          dev=dv, family='istgcn_affine2')
     return out
 
 

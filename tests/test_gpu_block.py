@@ -973,6 +973,52 @@ def test_block_out_relu_mask_equals_reading_out(ops, C, with_res, dt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float16])
+def test_dres_is_never_needed_as_a_tensor(ops, dt):
+    """Round 5: the block's backward does not write dres = dout * [out > 0] (net/st_gcnold.py:201-203) any more -- every reader
+    takes dout and the forward's byte mask.  Each reader's masked form is bit-identical to its form on the dres tensor:
+    block_out_bwd's sums without the store, affine2 (tcn.3's / the residual BatchNorm's backward, with the dropout mask), and
+    the identity-residual addend of the graph conv's data gradient (register-chained kernel: 16-bit storage)."""
+    from istgcn_amd.net.utils.graph import Graph
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    NM, T, V = 3, 9, 25
+    for C in (64, 128, 256):
+        z = torch.randn(NM, T, V, C, generator=g).to(d, dt)
+        res = torch.randn(NM, T, V, C, generator=g).to(d, dt)
+        coef = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2,
+                            torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).to(d)
+        out, rmask = ops.block_out_fwd(z, coef[:2].contiguous(), res, None, 0.3, 11, want_mask=True)
+        dout = torch.randn(NM, T, V, C, generator=g).to(d, dt)
+        dres, st_a, _ = ops.block_out_bwd(dout, None, z, coef, None, None, 0.3, 11, relu_mask=rmask)
+        none, st_b, _ = ops.block_out_bwd(dout, None, z, coef, None, None, 0.3, 11, relu_mask=rmask, want_dres=False)
+        assert none is None and (st_a - st_b).abs().max() <= 1e-9 * st_a.abs().max()
+        assert torch.equal(dres, torch.where(out > 0, dout, torch.zeros_like(dout)))
+        abc = torch.stack([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1]).to(d)
+        for p_drop in (0.0, 0.3):
+            a = ops.affine2(dres, z, abc, p_drop, 11)
+            b = ops.affine2(dout, z, abc, p_drop, 11, relu_mask=rmask)
+            assert torch.equal(a, b), (C, p_drop)
+        if dt == torch.float32:
+            assert not ops.gcn_bwd_addend_mask_ok(V, C, C, 3, dt)
+            continue
+        assert ops.gcn_bwd_addend_mask_ok(V, C, C, 3, dt)
+        gr = Graph('ntu-rgb+d', 'spatial_3')
+        A = torch.tensor(gr.A + gr.A2 + gr.A3, dtype=torch.float32, device=d)
+        W3 = (torch.randn(3, C, C, generator=g) * C ** -0.5).to(d)
+        dy = torch.randn(NM, T, V, C, generator=g).to(d, dt)
+        x = torch.randn(NM, T, V, C, generator=g).to(d, dt)
+        for want_dA in (True, False):
+            with ops.trace() as tr:
+                dx_a, dA_a = ops.gcn_bwd_data(dy, A, W3, x=x, addend=dres, want_dA=want_dA)
+                dx_b, dA_b = ops.gcn_bwd_data(dy, A, W3, x=x, addend=dout, addend_mask=rmask, want_dA=want_dA)
+            assert tr.ran('gcn_rc_bwd_kernel') and not tr.ran('_114gcn_bwd_kernel')      # (mangled: not the packer's name)
+            assert torch.equal(dx_a, dx_b), (C, want_dA)
+            if want_dA:
+                assert (dA_a - dA_b).abs().max() <= 1e-5 * dA_a.abs().max()
+
+
+@pytest.mark.gpu
 def test_flat_sgd_tap_major_layout_and_checkpoint_round_trip(tmp_path):
     """FlatSGD stores the temporal-conv weights [k][Cout][Cin] inside its flat buffers (the layout their gradient is computed
     in; the parameter keeps the Conv2d shape).  Updates must equal torch.optim.SGD's on a contiguous twin, gradients must

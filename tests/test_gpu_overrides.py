@@ -1,7 +1,8 @@
 """GPU: the three dispatch overrides the shipped library reads each select the PREVIOUS generation of one
 kernel family -- ISTGCN_GCN_RC=0 the round-1/2 graph-conv kernels, ISTGCN_TCONV_LEAN=0 the round-3 temporal conv,
 ISTGCN_TWG_LEAN=0 the round-1 temporal-conv weight gradient -- which also serve the shapes / storage types the newer kernels
-decline.  An override is read once per process, so each setting runs the reference-pinned wide-block test
+decline.  (`ISTGCN_DRES_FREE=0`, read by the Python side, is the fourth: the block's backward with the dres tensor written as
+before round 5.)  An override is read once per process, so each setting runs the reference-pinned wide-block test
 (test_gpu_block.py::test_blocks_wide_golden, all five block kinds, bfloat16 and float16) in a child process; that test asserts
 from the library's dispatch trace that the older kernels really ran, against the same reference fixtures and gates."""
 import os
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('var', ['ISTGCN_GCN_RC', 'ISTGCN_TCONV_LEAN', 'ISTGCN_TWG_LEAN'])
+@pytest.mark.parametrize('var', ['ISTGCN_GCN_RC', 'ISTGCN_TCONV_LEAN', 'ISTGCN_TWG_LEAN', 'ISTGCN_DRES_FREE'])
 def test_wide_blocks_golden_under_override(var):
     env = dict(os.environ)
     env[var] = '0'
