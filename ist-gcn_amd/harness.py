@@ -432,17 +432,19 @@ class DeviceStager:
     """Pinned host -> device staging of the training batches (first half): the reference moves every batch with
     a blocking `data.float().to(dev)` from pageable memory (processor/recognition.py:258; `pin_memory` is commented out in
     processor/processor.py:72).  Here the batches of any iterable of (data, label) host tensors -- a torch DataLoader over
-    feeder.Feeder included -- go through TWO pinned host buffers and TWO device buffers on a side stream: while step k
+    feeder.Feeder included -- go through `depth` (3) pinned host buffers and as many device buffers on a side stream: while step k
     computes on the current stream, batch k+1 is copied host -> pinned -> device (`non_blocking`), and the consumer only
     waits on an event.  Yields (data fp32 [N,C,T,V,M] on `device`, label int64 on `device`).
 
         for data, label in DeviceStager(loader, dev):
             loss = train_step(model, opt, data, label)
 
-    A yielded pair stays valid until the NEXT-but-one batch is requested (two buffers).  Batches of another shape (the last,
+    A yielded pair stays valid until `depth - 1` further batches have been requested.  Batches of another shape (the last,
     ragged one without drop_last) are staged through buffers of their own."""
 
-    def __init__(self, batches, device, depth=2):
+    def __init__(self, batches, device, depth=3):
+        # (depth 3: staging batch k+1 waits for the step that read its slot, k-2 -- with two slots it is k-1, which leaves the host
+        #  less than one step of run-ahead: 19.7 ms per step on a box with a slow host share against 12.3 resident)
         self.batches, self.device, self.depth = batches, torch.device(device), max(2, int(depth))
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = {}

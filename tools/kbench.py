@@ -76,5 +76,11 @@ for spec in args.layers.split(','):
     abc = torch.stack([torch.ones(c), torch.zeros(c), torch.zeros(c)]).to(d)
     timeit(tag + 'block_out_fwd', lambda: ops.block_out_fwd(gten, coef[:2].contiguous(), gten, None, 0.5, 1), 3.0 * P * c, 3 * P * c * es)
     timeit(tag + 'block_out_bwd', lambda: ops.block_out_bwd(gten, gten, gten, coef, None, None, 0.5, 1), 6.0 * P * c, 4 * P * c * es)
+    _, rm = ops.block_out_fwd(gten, coef[:2].contiguous(), gten, None, 0.5, 1, want_mask=True)
+    timeit(tag + 'block_out_bwd mask', lambda: ops.block_out_bwd(gten, None, gten, coef, None, None, 0.5, 1, relu_mask=rm), 6.0 * P * c, 3.06 * P * c * es)
+    timeit(tag + 'block_out_bwd mask nodres', lambda: ops.block_out_bwd(gten, None, gten, coef, None, None, 0.5, 1, relu_mask=rm, want_dres=False), 6.0 * P * c, 2.06 * P * c * es)
+    timeit(tag + 'block_out_bwd mask nodres p=0', lambda: ops.block_out_bwd(gten, None, gten, coef, None, None, 0.0, 1, relu_mask=rm, want_dres=False), 6.0 * P * c, 2.06 * P * c * es)
+    timeit(tag + 'block_out_fwd p=0', lambda: ops.block_out_fwd(gten, coef[:2].contiguous(), gten, None, 0.0, 1), 3.0 * P * c, 3 * P * c * es)
+    timeit(tag + 'affine2 (drop, mask)', lambda: ops.affine2(gten, gten, abc, 0.5, 1, relu_mask=rm), 4.0 * P * c, 3.06 * P * c * es)
     timeit(tag + 'affine2 (drop)', lambda: ops.affine2(gten, gten, abc, 0.5, 1), 4.0 * P * c, 3 * P * c * es)
     timeit(tag + 'affine2', lambda: ops.affine2(gten, gten, abc), 4.0 * P * c, 3 * P * c * es)
