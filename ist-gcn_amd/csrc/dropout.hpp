@@ -1,14 +1,23 @@
 // Counter-based dropout shared by the glue kernels (pointwise.hip) and the fused BatchNorm-backward input of the bottleneck
-// chain (bneck_rc.hip): Philox4x32-10 keyed by (seed, element index / 8); the backward pass regenerates the forward mask.
+// chain (bneck_rc.hip): Philox4x32 (7 rounds since round 5) keyed by (seed, element index / 8); the backward pass regenerates
+// the forward mask.
 #pragma once
 #include "common.hpp"
 
+// Philox4x32 (Salmon et al., SC'11) with PHILOX_ROUNDS rounds: 7 is the paper's fastest Crush-resistant variant (10 its
+// conservative default, which rounds 1-4 of this repository used); a round's hi / lo word pairs come from ONE 32 x 32 -> 64-bit
+// multiply each (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair -- both multiplies are quarter-rate instructions
+// and the generator, not HBM, bounded every kernel that draws a mask (affine2: 62.8 us with dropout, 45.7 without; round 5).
+#ifndef PHILOX_ROUNDS
+#define PHILOX_ROUNDS 7
+#endif
 __device__ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
   uint32_t c[4] = {c0, c1, 0x9E3779B9u, 0xBB67AE85u};
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+  for (int r = 0; r < PHILOX_ROUNDS; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

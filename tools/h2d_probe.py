@@ -39,9 +39,31 @@ def work(data):
     return z.float().sum() + data.sum()
 
 
-for name, it in (('resident batch', ((dx, y.to(d)) for _ in range(20))), ('DeviceStager', harness.DeviceStager(((x, y) for _ in range(20)), d))):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0
-    for data, label in it:
-        s = work(data); n += 1
-    torch.cuda.synchronize()
-    print('%-16s %6.2f ms per step over %d steps' % (name, (time.perf_counter() - t0) / n * 1e3, n))
+import types
+stats = {'sync': 0.0, 'memmove': 0.0, 'enqueue': 0.0, 'n': 0}
+_orig = harness.DeviceStager._stage
+
+
+def timed_stage(self, i, data, label):
+    hx, hy, dx, dy, ready, free = self._slot(i % self.depth, data, label)
+    t0 = time.perf_counter(); free.synchronize(); t1 = time.perf_counter()
+    harness._host_copy(hx, data); harness._host_copy(hy, label); t2 = time.perf_counter()
+    with torch.cuda.stream(self.stream):
+        dx.copy_(hx, non_blocking=True); dy.copy_(hy, non_blocking=True); ready.record(self.stream)
+    t3 = time.perf_counter()
+    stats['sync'] += t1 - t0; stats['memmove'] += t2 - t1; stats['enqueue'] += t3 - t2; stats['n'] += 1
+    return dx, dy, ready, free
+
+
+harness.DeviceStager._stage = timed_stage
+yd = y.to(d)
+for rep in range(2):
+    for name, mk in (('resident batch', lambda: ((dx, yd) for _ in range(20))), ('DeviceStager', lambda: harness.DeviceStager(((x, y) for _ in range(20)), d))):
+        for k in stats: stats[k] = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter(); n = 0; tw = 0.0
+        for data, label in mk():
+            a0 = time.perf_counter(); s = work(data); tw += time.perf_counter() - a0; n += 1
+        torch.cuda.synchronize()
+        tot = (time.perf_counter() - t0) / n * 1e3
+        extra = '' if not stats['n'] else '  | per step: free.synchronize %.2f ms, memmove %.2f, enqueue copies %.2f' % tuple(stats[k] / stats['n'] * 1e3 for k in ('sync', 'memmove', 'enqueue'))
+        print('%-16s %6.2f ms per step over %d steps (host time issuing the work %.2f ms per step)%s' % (name, tot, n, tw / n * 1e3, extra))
