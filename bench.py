@@ -287,10 +287,19 @@ def main():
         ops.PROFILE = []
         barrier()
         t0 = time.perf_counter()
-        for data, label in harness.DeviceStager(((xh, yh) for _ in range(args.steps)), dev):
+        stager = harness.DeviceStager(((xh, yh) for _ in range(args.steps)), dev)
+        t_issue = 0.0
+        for data, label in stager:
+            ti = time.perf_counter()
             loss = harness.train_step(model, opt, data, label, sync)
+            t_issue += time.perf_counter() - ti
         barrier()
         elapsed = time.perf_counter() - t0
+        if rank == 0:
+            nb = max(1, stager.timers['batches'])
+            sys.stderr.write('h2d: host ms per step -- issuing the training step %.2f, waiting for a free slot %.2f, copy into pinned memory '
+                             '%.2f, enqueueing the H2D copies %.2f\n' % (t_issue / args.steps * 1e3, stager.timers['wait_slot'] / nb * 1e3,
+                                                                        stager.timers['host_copy'] / nb * 1e3, stager.timers['enqueue'] / nb * 1e3))
     else:
         ops.PROFILE = []
         t0 = time.perf_counter()
