@@ -281,25 +281,52 @@ def main():
         for _ in range(args.steps):
             harness.train_step(model, opt, x, y, sync)
         barrier()
+    elif args.h2d and os.environ.get('ISTGCN_H2D_PLAIN') == '1':
+        # what processor/recognition.py:258 does: every batch moved from pageable host memory by a blocking .to(dev) on the
+        # compute stream (A/B against the stager; ISTGCN_H2D_PLAIN=1 python bench.py --h2d)
+        xh, yh = x.cpu(), y.cpu()
+        ops.PROFILE = []
+        barrier()
+        t0 = time.perf_counter()
+        t_copy = 0.0
+        for _ in range(args.steps):
+            tc = time.perf_counter()
+            data, label = xh.to(dev), yh.to(dev)
+            t_copy += time.perf_counter() - tc
+            loss = harness.train_step(model, opt, data, label, sync)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            sys.stderr.write('h2d plain: host ms per step in .to(dev): %.2f\n' % (t_copy / args.steps * 1e3))
     elif args.h2d:
         # the same K steps, every batch coming from pageable host memory (what a DataLoader hands over)
         xh, yh = x.cpu(), y.cpu()
         ops.PROFILE = []
         barrier()
         t0 = time.perf_counter()
-        stager = harness.DeviceStager(((xh, yh) for _ in range(args.steps)), dev)
-        t_issue = 0.0
-        for data, label in stager:
+        # (the first `depth` batches allocate the stager's pinned / device slots -- ~50 ms of hipHostMalloc each --: they run
+        #  untimed, the clock starts behind them)
+        stager = harness.DeviceStager(((xh, yh) for _ in range(args.steps + 3)), dev, depth=3)
+        t_issue, nb0 = 0.0, 0
+        for k, (data, label) in enumerate(stager):
+            if k == 3:
+                barrier()
+                ops.PROFILE = []
+                t0 = time.perf_counter()
+                t_issue = 0.0
+                tm0 = dict(stager.timers)
             ti = time.perf_counter()
             loss = harness.train_step(model, opt, data, label, sync)
             t_issue += time.perf_counter() - ti
         barrier()
         elapsed = time.perf_counter() - t0
         if rank == 0:
-            nb = max(1, stager.timers['batches'])
-            sys.stderr.write('h2d: host ms per step -- issuing the training step %.2f, waiting for a free slot %.2f, copy into pinned memory '
-                             '%.2f, enqueueing the H2D copies %.2f\n' % (t_issue / args.steps * 1e3, stager.timers['wait_slot'] / nb * 1e3,
-                                                                        stager.timers['host_copy'] / nb * 1e3, stager.timers['enqueue'] / nb * 1e3))
+            tm = {k2: stager.timers[k2] - tm0[k2] for k2 in tm0}
+            nb = max(1, tm['batches'])
+            sys.stderr.write('h2d: host ms per step -- issuing the training step %.2f, checking the slot %.2f, copy into pinned memory '
+                             '%.2f, enqueueing the H2D copies %.2f; blocked on a slot %d times\n' % (
+                                 t_issue / args.steps * 1e3, tm['wait_slot'] / nb * 1e3, tm['host_copy'] / nb * 1e3,
+                                 tm['enqueue'] / nb * 1e3, tm['blocked']))
     else:
         ops.PROFILE = []
         t0 = time.perf_counter()

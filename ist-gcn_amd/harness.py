@@ -446,7 +446,7 @@ class DeviceStager:
         self.batches, self.device, self.depth = batches, torch.device(device), max(2, int(depth))
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = {}
-        self.timers = {'wait_slot': 0.0, 'host_copy': 0.0, 'enqueue': 0.0, 'batches': 0}
+        self.timers = {'wait_slot': 0.0, 'host_copy': 0.0, 'enqueue': 0.0, 'batches': 0, 'blocked': 0}
 
     def _slot(self, i, data, label):
         key = (i, tuple(data.shape), tuple(label.shape))
@@ -467,11 +467,14 @@ class DeviceStager:
         import time
         t0 = time.perf_counter()
         hx, hy, dx, dy, ready, free = self._slot(i % self.depth, data, label)
-        # Two hazards, two waits.  The pinned buffer may be overwritten once the PREVIOUS copy out of it has run: a host wait on
+        # Two hazards, two waits.  The pinned buffer may be overwritten once the PREVIOUS copy out of it has run: a host check of
         # that copy's event (done long ago).  The device buffer may be overwritten once the step that read it has run: a
-        # DEVICE-side wait of the copy stream on `free` -- a host wait there (the first version) blocked the host for most of a
-        # step, every step, and the loop ran host-serialised: 17-22 ms per step against 11.8 resident (bench.py --h2d timers).
-        ready.synchronize()
+        # DEVICE-side wait of the copy stream on `free`.  (The first use of a slot allocates it -- ~50 ms of hipHostMalloc per
+        # 11.5 MB pinned buffer: a one-off that a 20-step measurement must not average in, bench.py --h2d starts its clock
+        # after `depth` batches.)
+        if not ready.query():                              # (normally complete two steps ago: no host wait)
+            ready.synchronize()
+            self.timers['blocked'] += 1
         t1 = time.perf_counter()
         _host_copy(hx, data)                               # (host-side cast to fp32 + copy into pinned memory)
         _host_copy(hy, label)
