@@ -859,7 +859,7 @@ int launch_T(GcnFwdParams& P, int grid_x_cap, hipStream_t stream) {
 }  // namespace
 
 // Round-1 kernel (gcn_fwd_small.hip), same arguments: serves fp32 storage (VALU aggregation either way; no LDS room for
-// the wave-specialised layout at full chunk width).  ISTGCN_GCN_V1=0/1 forces one kernel for A/B runs (before packing).
+// the wave-specialised layout at full chunk width).
 extern "C" int istgcn_gcn_fwd_v1(const void* x, const float* A, const void* Wp, const float* bterm,
                                  const void* addend, void* y, double* stats, int stats_rep, int* status,
                                  int NM, int Tin, int Tout, int Tlog, int V, int Cin, int Cout, int K,

@@ -1,4 +1,5 @@
-// Weight gradient of the temporal convolution, trunk layers in 16-bit storage: the lean form (round 4) of twg_ws
+// Weight gradient of the temporal convolution, trunk layers in 16-bit storage: the lean form (round 4) of round 2's
+// wave-specialised kernel `twg_ws` (deleted in round 5; its description is in DESIGN_HISTORY.md)
 // (tconv_wgrad.hip) -- the autograd of the (k,1) Conv2d of net/st_gcnold.py:165-175 with BatchNorm + ReLU in front of it:
 //
 //   dW[j][o][i] += sum_{n,m,v} dz[n, m, v, o] * pre(g[n, m + tap_off[j], v, i])          (stride 1, zero padding)

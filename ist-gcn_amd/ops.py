@@ -103,7 +103,7 @@ def _trace_dump():
 class trace:
     """`with ops.trace() as tr: ...; tr.kernels` -> {kernel symbol: launches} of every kernel the library launched inside
     the block (istgcn_trace, csrc/trace.hip: process-wide, test instrumentation; nests -- tests/conftest.py records every
-    GPU test's kernels around the test's own blocks).  `tr.ran('gcn_bwd_ws_kernel')`: a launched symbol contains that text."""
+    GPU test's kernels around the test's own blocks).  `tr.ran('gcn_rc_bwd_kernel')`: a launched symbol contains that text."""
     _depth = 0
 
     def __enter__(self):

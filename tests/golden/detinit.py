@@ -81,7 +81,8 @@ def subsample(name, t, n=SUB_N):
 WIDE_UNITS = [(64, 64, 25), (64, 128, 25), (128, 256, 25), (64, 64, 18)]     # (C_in, C_out, V); N = 2, T = 16, K = 3
 # (C_in, C_out, stride, V); residual, N = 2, T = 16.  Cases 3 / 4 (round 5): the 256-channel blocks of the trunk
 # (net/st_gcn_msgcn.py:60-72 layer list: 128 -> 256 at stride 2 with the 1 x 1 residual conv of st_gcnold.py:179-193, 256 -> 256)
-# -- where the graph conv's data gradient WITH the adjacency gradient runs its own kernel (gcn_bwd_ws)
+# -- where the graph conv's data gradient WITH the adjacency gradient ran a kernel of its own (round 2's gcn_bwd_ws) until
+# round 5 moved it onto the register-chained kernel
 WIDE_BLOCKS = [(64, 64, 1, 25), (64, 128, 2, 25), (64, 64, 1, 18), (128, 256, 2, 25), (256, 256, 1, 25)]
 WIDE_T = 16
 

@@ -388,6 +388,41 @@ def g45_models():
         json.dump(manifest, f, indent=0, sort_keys=True)
 
 
+# ----------------------------------------------------------------------------- G4L: a training step at the FULL clip length
+# the whole-model tests at bench size compared the HIP path with itself; the reference-pinned ones were N = 2
+# (eval) and (4, T = 48) (training).  G4L is one training step of each BASELINE model at its full clip length (T = 300; 600 for the
+# deep model) on 8 clips (4 for T = 600): logits, loss, every gradient norm -- the NM = 16 sequences fill 16 x 300 x 25 = 120 000
+# positions per layer, every kernel walks many tiles per workgroup.
+G4L = {'st_gcnold': 8, 'st_gcn_msgcn': 8, 'st_gcn_mstcn_1x1': 8, 'st_gcn_multi3_fix_3A_mstcn': 8, 'st_gcn_mstcn_1x1_deep': 4}
+
+
+def g4l_models():
+    import importlib
+    for tag, n in G4L.items():
+        modname, gargs, nc, (_, T, V) = MODELS[tag]
+        mod = importlib.import_module(modname)
+        torch.manual_seed(0)
+        m = mod.Model(3, nc, gargs, True, dropout=0)
+        sd = m.state_dict()
+        det_fill_(sd)
+        m.load_state_dict(sd)
+        xt = det_tensor('g4l.x.' + tag, (n, 3, T, V, 2))
+        lab = det_labels('g4l.lab.' + tag, n, nc)
+        m.train()
+        logits = m(xt)
+        loss = torch.nn.functional.cross_entropy(logits, lab)
+        loss.backward()
+        out = {'train_logits': logits, 'train_loss': loss.detach(), 'train_shape': np.asarray([n, 3, T, V, 2]),
+               'grad_norms': np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) for p in m.parameters()]),
+               'grad_none': np.asarray([p.grad is None for p in m.parameters()])}
+        for k in ('fcn.weight', 'edge_importance.0', 'st_gcn_networks.9.gcn.conv.weight', 'st_gcn_networks.9.gcn.branch.conv.weight',
+                  'data_bn.weight'):
+            p = dict(m.named_parameters()).get(k)
+            if p is not None and p.grad is not None:
+                _put(out, 'grad.' + k, p.grad, 4096)
+        save('model_g4l_%s.npz' % tag, **out)
+
+
 # ----------------------------------------------------------------------------- G6 inference / extract_feature
 def g6_extract_feature():
     """`extract_feature` (net/st_gcnold.py:98-120, caller processor/demo_offline.py:68-98) and the eval
@@ -483,7 +518,7 @@ def g8_mstcn():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7', 'g8', 'g2w', 'g3w']
+    what = sys.argv[1:] or ['g1', 'g2', 'g3', 'g45', 'g6', 'g7', 'g8', 'g2w', 'g3w', 'g4l']
     if 'g1' in what:
         g1_graph()
     if 'g2' in what:
@@ -500,6 +535,8 @@ if __name__ == '__main__':
         g8_mstcn()
     if 'g2w' in what:
         g2w_units()
+    if 'g4l' in what:
+        g4l_models()
     if 'g3w' in what:
         g3w_blocks()
     for w in what:

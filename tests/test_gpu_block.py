@@ -332,6 +332,43 @@ def test_model_train_step_fp32(golden, tag):
             assert diag('model_after_%s_%s' % (tag, k), sd[k[6:]], g[k], 1e-3) < 1e-3, k
 
 
+@pytest.mark.parametrize('tag', ['st_gcnold', 'st_gcn_msgcn', 'st_gcn_mstcn_1x1', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1_deep'])
+def test_model_full_clip_train_step_reference(golden, tag):
+    """G4L (round 5): one training step of every BASELINE model at its FULL clip length (8 clips x T = 300;
+    4 x T = 600 for the deep model) against the REFERENCE -- processor/recognition.py:273-283 on net/<tag>.py: logits and loss
+    to 1e-3, every parameter's gradient norm to 2e-3, a subsample of five gradient tensors element-wise, in fp32; the logits in
+    both 16-bit storage types.  16 (8) sequences x T x V positions per layer: every kernel walks several tiles per workgroup,
+    which the (4, T = 48) fixture of test_model_train_step_fp32 does not reach."""
+    g = golden('model_g4l_%s.npz' % tag)
+    shp = tuple(int(v) for v in g['train_shape'])
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        m, nc = _model(tag, dt)
+        x = det_tensor('g4l.x.' + tag, shp).to(dev())
+        lab = det_labels('g4l.lab.' + tag, shp[0], nc).to(dev())
+        m.train()
+        logits = m(x)
+        loss = F.cross_entropy(logits.float(), lab)
+        if dt != torch.float32:
+            from gpu_util import gate16
+            assert gate16('g4l_logits_%s %s' % (tag, str(dt)[6:]), l2rel(logits.float(), g['train_logits']), 3e-2 if dt == torch.bfloat16 else 6e-3)
+            continue
+        loss.backward()
+        assert diag('g4l_logits_' + tag, logits, g['train_logits'], 1e-3) < 1e-3
+        assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-3
+        params = list(m.parameters())
+        assert np.array_equal(np.asarray([p.grad is None for p in params]), g['grad_none'])
+        gn = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) for p in params])
+        bad = np.abs(gn - g['grad_norms']) > 2e-3 * np.maximum(1.0, g['grad_norms'])
+        assert not bad.any(), [(SD[tag + '#param_names'][i], gn[i], g['grad_norms'][i]) for i in np.flatnonzero(bad)[:8]]
+        named = dict(m.named_parameters())
+        n_sub = 0
+        for k in g.files:
+            if k.startswith('grad.') and not k.endswith('#norm'):
+                assert sub_close('g4l_%s_%s' % (tag, k), named[k[5:]].grad, g, k, 2e-3, dt), k
+                n_sub += 1
+        assert n_sub >= 3
+
+
 @pytest.mark.parametrize('tag', ['st_gcn_msgcn', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1'])
 def test_model_bf16_storage_close_to_fp32(golden, tag):
     """bf16 activations with fp32 accumulation / fp64 statistics against (a) the reference's fp32 logits and (b) the

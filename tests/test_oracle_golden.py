@@ -338,3 +338,25 @@ def test_mstcn_oracle_matches_reference(ci, golden):
         assert rel_err(m.train()(x), g['c%d.train' % ci]) < 1e-5
     assert rel_err(m.batchnorm2d.running_mean, g['c%d.running_mean' % ci]) < 1e-5
     assert rel_err(m.batchnorm2d.running_var, g['c%d.running_var' % ci]) < 1e-5
+
+
+def test_model_full_clip_train_step_st_gcn_msgcn(golden):
+    """G4L (round 5): one training step of BASELINE config 2's model at the FULL clip length (8 clips, T = 300): the oracle
+    against the reference's logits, loss and every gradient norm.  (One model here -- ~15 s of CPU; the GPU suite checks all five.)"""
+    tag = 'st_gcn_msgcn'
+    g = golden('model_g4l_%s.npz' % tag)
+    gargs, nc = MODEL_CFG[tag]
+    m = R.RefModel(tag, 3, nc, gargs, True, dropout=0)
+    m.load_state_dict(det_fill_(m.state_dict()))
+    shp = tuple(int(v) for v in g['train_shape'])
+    x = det_tensor('g4l.x.' + tag, shp)
+    lab = det_labels('g4l.lab.' + tag, shp[0], nc)
+    torch.set_num_threads(8)
+    m.train()
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, lab)
+    loss.backward()
+    assert rel_err(logits, g['train_logits']) < 1e-5 and abs(float(loss) - float(g['train_loss'])) < 1e-5
+    gn = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) for p in m.parameters()])
+    assert np.array_equal(np.asarray([p.grad is None for p in m.parameters()]), g['grad_none'])
+    assert np.allclose(gn, g['grad_norms'], rtol=2e-4, atol=1e-6)

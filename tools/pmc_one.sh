@@ -14,6 +14,6 @@ rocprofv3 --pmc SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_
   --kernel-trace --output-format csv -d $out/c -- $B > $out/run_c.log 2>&1 || { tail -5 $out/run_c.log; }
 cd $R
 python3 tools/pmc_parse.py $out > gpurun_out/pmcone_$tag.txt 2>&1
-grep -v "^    raw" gpurun_out/pmcone_$tag.txt | grep -A3 "rc_wgrad\|twg_ws\|gcn_rc" | cut -c1-250
+grep -v "^    raw" gpurun_out/pmcone_$tag.txt | grep -A3 "rc_wgrad\|twg_lean\|gcn_rc" | cut -c1-250
 grep "raw" gpurun_out/pmcone_$tag.txt | head -3 | cut -c1-900
 rm -rf $out
