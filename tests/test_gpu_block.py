@@ -350,7 +350,7 @@ def test_model_full_clip_train_step_reference(golden, tag):
         loss = F.cross_entropy(logits.float(), lab)
         if dt != torch.float32:
             from gpu_util import gate16
-            assert gate16('g4l_logits_%s %s' % (tag, str(dt)[6:]), l2rel(logits.float(), g['train_logits']), 3e-2 if dt == torch.bfloat16 else 6e-3)
+            assert gate16('g4l_logits_%s %s' % (tag, str(dt)[6:]), l2rel(logits.float(), g['train_logits']), 3e-3 if dt == torch.bfloat16 else 4e-4)      # (measured 1.0-1.1e-3 / 1.1-1.5e-4)
             continue
         loss.backward()
         assert diag('g4l_logits_' + tag, logits, g['train_logits'], 1e-3) < 1e-3
