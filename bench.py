@@ -200,6 +200,9 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # RCCL ('nccl' on ROCm) over xGMI; ISTGCN_DIST_BACKEND=gloo only to rehearse the multi-rank code path on one GPU
         backend = os.environ.get('ISTGCN_DIST_BACKEND', 'nccl')
+        # (this image's RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION: keep stdout for the one JSON line)
+        if os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION'):
+            os.environ['NCCL_DEBUG'] = 'WARN'
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
