@@ -589,7 +589,7 @@ extern "C" int istgcn_gcn_bwd_data(const void* dy, const void* x, const float* A
     // (round 5: 256 output channels WITH the adjacency gradient too -- H' transposed from H, gcn_rc_bwd.hip; the
     //  wave-specialised round-2 kernel that served them is gone)
     if (rc_on && V <= 32 && istgcn_gcn_bwd_rc_layout(Cin, Cout, K, dtype) &&
-        (Cin != 3 ? dx != nullptr : (!dx && dA && !addend))) {
+        (Cin != 3 ? dx != nullptr : (dA && !addend))) {      // (first layer: dA always, dx optional)
       const long long off = istgcn_gcn_bwd_rc_offset(Cin, Cout, K, dtype);
       if (off >= 0)
         return istgcn_gcn_bwd_data_rc(dy, x, A, pattern, reinterpret_cast<const char*>(Wb) + (size_t)off * 2, addend, addend_mask, dx, dA,

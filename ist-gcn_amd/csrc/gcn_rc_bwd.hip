@@ -62,9 +62,9 @@ __device__ static inline int perm23(int c) { return (c & ~12) | ((c & 4) << 1) |
 // (HIP: the second launch bound is WAVES PER SIMD -- 2 = the 8 waves of one workgroup per CU, 256 registers each)
 template <typename T, int SO, int K, int NCT, bool DA, int ADD, int CN>
 __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams P) {
-  // CN != 0: the models' first layer (CN = 3 input channels, net/st_gcnold.py:44).  Its input needs no gradient, so only
-  // the adjacency gradient is computed (no dx chain, no image, no stores): one zero-padded 32-channel tile per frame,
-  // x rows read with 16-bit loads.
+  // CN != 0: the models' first layer (CN = 3 input channels, net/st_gcnold.py:44): one zero-padded 32-channel tile per frame,
+  // x rows read with 16-bit loads.  The adjacency gradient always; dx (P.dx != NULL: the gradient of data_bn's weight and
+  // bias flows through it, st_gcnold.py:74-80) as 16-bit stores of the three valid columns, else no dx chain at all.
   static_assert(CN == 0 || (NCT == 1 && DA && ADD == 0 && CN <= 4), "narrow input: dA only");
   using E = Elem<T>;
   typedef typename E::frag frag_t;
@@ -223,7 +223,20 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
       }
     }
     if constexpr (RELOAD && TRI && SO >= 16) load_x(n2, t2, xf);      // (one x set: refilled right after its last use, like dy)
-    if constexpr (DX) {
+    if constexpr (DX && CN != 0) {
+      // narrow input (the 3-channel first layer, whose dx is the gradient of data_bn): rows of 2 * CN bytes -- 16-bit stores
+      // straight from the accumulator tile (lane = channel perm23(c) = c for c < 4, registers = rows); lanes of the zero
+      // padding and rows >= V fall outside the frame's descriptor
+      const size_t fo = ((size_t)fn * P.T + ft) * x_frm;
+      const rsrc_t ro = make_rsrc(dxg + fo, xfrm_b);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const unsigned off = c < CN ? (unsigned)(row * CN + c) * 2u : 0x7ffffff0u;
+        const uint32_t pk = pack2<T>(Y[i], 0.f);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pk & 0xffffu), ro, off, 0, 0);
+      }
+    } else if constexpr (DX) {
       // dx tile -> pair-row image (column c of the tile is channel perm23(c)) -> 16-byte row vectors -> HBM
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -349,7 +362,10 @@ __global__ __launch_bounds__(RC_NTH, 2) void gcn_rc_bwd_kernel(const RcBwdParams
   };
   typedef std::true_type yes;
   typedef std::false_type no;
-  if constexpr (CN != 0) walk(no{}, yes{}, yes{});
+  if constexpr (CN != 0) {
+    if (P.dx) walk(yes{}, yes{}, yes{});                      // (round 5: with dx -- the gradient data_bn needs)
+    else walk(no{}, yes{}, yes{});
+  }
   else if constexpr (!DA) walk(yes{}, no{}, yes{});
   else walk(yes{}, yes{}, std::integral_constant<bool, (SO <= 4)>{});
 
@@ -445,7 +461,7 @@ int rc_bwd_k(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
 
 template <typename T>
 int rc_bwd_first_layer(const RcBwdParams& P, int K, int grid_cap, hipStream_t stream) {
-  if (P.Cout != 64 || !P.dA || P.addend || P.dx) return ISTGCN_EINVAL;
+  if (P.Cout != 64 || !P.dA || P.addend) return ISTGCN_EINVAL;
   switch (K) {
     case 1: return rc_bwd_launch<T, 4, 1, 1, true, 0, 3>(P, grid_cap, stream);
     case 2: return rc_bwd_launch<T, 4, 2, 1, true, 0, 3>(P, grid_cap, stream);

@@ -367,18 +367,26 @@ def test_first_layer_adjacency_gradient_without_dx(ops, dt):
     istgcn_gcn_bwd_data with dx = NULL (16-bit storage) must give the same dA as the full call and as autograd."""
     NM, cin, cout, T, V, K = 5, 3, 64, 37, 25, 3
     gen = torch.Generator().manual_seed(77)
-    x = torch.randn(NM, cin, T, V, generator=gen).to(dt).float()
+    x = torch.randn(NM, cin, T, V, generator=gen).to(dt).float().requires_grad_(True)
     dy = torch.randn(NM, cout, T, V, generator=gen).to(dt).float()
-    W = torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5
+    W = (torch.randn(K * cout, cin, 1, 1, generator=gen) * cin ** -0.5).to(dt).float()
     A = (torch.rand(K, V, V, generator=gen) * (torch.rand(K, V, V, generator=gen) < 0.12)).requires_grad_(True)
     R.graph_einsum(torch.nn.functional.conv2d(x, W), A).backward(dy)
     d = dev()
     cap = int((A != 0).sum())
     args = (to_ntvc(dy).to(d, dt), A.detach().to(d), W.view(K, cout, cin).to(d))
-    dx0, dA0 = ops.gcn_bwd_data(*args, x=to_ntvc(x).to(d, dt), nnz_cap=cap)
-    dx1, dA1 = ops.gcn_bwd_data(*args, x=to_ntvc(x).to(d, dt), nnz_cap=cap, want_dx=False)
+    xd = to_ntvc(x.detach()).to(d, dt)
+    with ops.trace() as tr:
+        dx0, dA0 = ops.gcn_bwd_data(*args, x=xd, nnz_cap=cap)
+        dx1, dA1 = ops.gcn_bwd_data(*args, x=xd, nnz_cap=cap, want_dx=False)
     torch.cuda.synchronize()
     assert dx0 is not None and dx1 is None
+    # round 5: BOTH forms run the register-chained narrow kernel (dx is what data_bn's gradient flows through; the round-1
+    # kernel served it until then), and dx equals autograd's on the same 16-bit operands to the storage type's rounding
+    assert tr.ran('gcn_rc_bwd_kernel') and not tr.ran('_114gcn_bwd_kernel'), sorted(tr.kernels)
+    ref_dx = to_ntvc(x.grad)
+    e_dx = float((dx0.float().cpu() - ref_dx).norm() / ref_dx.norm())
+    assert dx0.shape == xd.shape and e_dx < (6e-3 if dt == torch.bfloat16 else 8e-4), e_dx
     ref = A.grad * (A.detach() != 0)
     assert diag('first_layer_dA_full_%s' % str(dt)[6:], dA0.cpu(), ref, 1e-2) < 1e-2
     assert diag('first_layer_dA_only_%s' % str(dt)[6:], dA1.cpu(), ref, 1e-2) < 1e-2
