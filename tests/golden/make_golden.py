@@ -394,11 +394,14 @@ def g45_models():
 # deep model) on 8 clips (4 for T = 600): logits, loss, every gradient norm -- the NM = 16 sequences fill 16 x 300 x 25 = 120 000
 # positions per layer, every kernel walks many tiles per workgroup.
 G4L = {'st_gcnold': 8, 'st_gcn_msgcn': 8, 'st_gcn_mstcn_1x1': 8, 'st_gcn_multi3_fix_3A_mstcn': 8, 'st_gcn_mstcn_1x1_deep': 4}
+# G4B: the SAME for BASELINE config 2 at its bench shape -- 64 clips x (3, 300, 25, 2) -- so that the step bench.py times has a
+# reference twin (about two minutes and 25 GB of host memory to generate; `make_golden.py g4b`)
+G4B = {'st_gcn_msgcn': 64}
 
 
-def g4l_models():
+def g4l_models(table=None, prefix='g4l'):
     import importlib
-    for tag, n in G4L.items():
+    for tag, n in (table or G4L).items():
         modname, gargs, nc, (_, T, V) = MODELS[tag]
         mod = importlib.import_module(modname)
         torch.manual_seed(0)
@@ -406,8 +409,8 @@ def g4l_models():
         sd = m.state_dict()
         det_fill_(sd)
         m.load_state_dict(sd)
-        xt = det_tensor('g4l.x.' + tag, (n, 3, T, V, 2))
-        lab = det_labels('g4l.lab.' + tag, n, nc)
+        xt = det_tensor(prefix + '.x.' + tag, (n, 3, T, V, 2))
+        lab = det_labels(prefix + '.lab.' + tag, n, nc)
         m.train()
         logits = m(xt)
         loss = torch.nn.functional.cross_entropy(logits, lab)
@@ -420,7 +423,7 @@ def g4l_models():
             p = dict(m.named_parameters()).get(k)
             if p is not None and p.grad is not None:
                 _put(out, 'grad.' + k, p.grad, 4096)
-        save('model_g4l_%s.npz' % tag, **out)
+        save('model_%s_%s.npz' % (prefix, tag), **out)
 
 
 # ----------------------------------------------------------------------------- G6 inference / extract_feature
@@ -537,6 +540,8 @@ if __name__ == '__main__':
         g2w_units()
     if 'g4l' in what:
         g4l_models()
+    if 'g4b' in what:
+        g4l_models(G4B, 'g4b')
     if 'g3w' in what:
         g3w_blocks()
     for w in what:

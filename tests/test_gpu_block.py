@@ -369,6 +369,52 @@ def test_model_full_clip_train_step_reference(golden, tag):
         assert n_sub >= 3
 
 
+def test_bench_shape_train_step_reference(golden):
+    """G4B (round 5): the training step bench.py times -- `net/st_gcn_msgcn.py`, 64 clips x (3, 300, 25, 2), BASELINE config 2 --
+    against the REFERENCE at exactly that shape (processor/recognition.py:273-283; fixture generated by running the reference
+    on the CPU: two minutes, 25 GB).  fp32 storage: logits and loss 1e-3, every gradient norm 2e-3, subsampled gradient
+    tensors 2e-3.  bf16 (the bench's storage type) and fp16: logits in relative L2, and the whole gradient's norm-weighted
+    error against the reference's gradient norms."""
+    tag = 'st_gcn_msgcn'
+    g = golden('model_g4b_%s.npz' % tag)
+    shp = tuple(int(v) for v in g['train_shape'])
+    assert shp == (64, 3, 300, 25, 2)
+    from gpu_util import gate16
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        m, nc = _model(tag, dt)
+        x = det_tensor('g4b.x.' + tag, shp).to(dev())
+        lab = det_labels('g4b.lab.' + tag, shp[0], nc).to(dev())
+        m.train()
+        logits = m(x)
+        loss = F.cross_entropy(logits.float(), lab)
+        # (float16 storage trains with the static loss scale of bench.py -- 65536 -- or the activation gradients of a 64-clip
+        #  mean loss underflow: measured 0.16 norm error without it, recognition.py's --half has no scale at all)
+        ls = 65536.0 if dt == torch.float16 else 1.0
+        (loss * ls).backward()
+        params = list(m.parameters())
+        gn = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) / ls for p in params])
+        if dt == torch.float32:
+            assert diag('g4b_logits', logits, g['train_logits'], 1e-3) < 1e-3
+            assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-3
+            assert np.array_equal(np.asarray([p.grad is None for p in params]), g['grad_none'])
+            bad = np.abs(gn - g['grad_norms']) > 2e-3 * np.maximum(1.0, g['grad_norms'])
+            assert not bad.any(), [(SD[tag + '#param_names'][i], gn[i], g['grad_norms'][i]) for i in np.flatnonzero(bad)[:8]]
+            named = dict(m.named_parameters())
+            for k in g.files:
+                if k.startswith('grad.') and not k.endswith('#norm'):
+                    assert sub_close('g4b_' + k, named[k[5:]].grad, g, k, 2e-3, dt), k
+        else:
+            name = str(dt)[6:]
+            assert gate16('g4b_logits ' + name, l2rel(logits.float(), g['train_logits']), 3e-3 if dt == torch.bfloat16 else 4e-4)
+            # every parameter's gradient NORM against the reference's (the norms of the reference are all the fixture holds of
+            # most tensors): relative error of the norm, weighted by the norm -- a 16-bit regression alarm, not a parity gate
+            w = g['grad_norms']
+            e = float(np.abs(gn - w).sum() / w.sum())
+            assert gate16('g4b_grad_norms ' + name, e, 1.2e-2 if dt == torch.bfloat16 else 4e-3)      # (measured 3.6-3.9e-3 / 1.3e-3)
+        del m, logits, loss
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('tag', ['st_gcn_msgcn', 'st_gcn_multi3_fix_3A_mstcn', 'st_gcn_mstcn_1x1'])
 def test_model_bf16_storage_close_to_fp32(golden, tag):
     """bf16 activations with fp32 accumulation / fp64 statistics against (a) the reference's fp32 logits and (b) the
