@@ -517,6 +517,22 @@ def g8_mstcn():
         out['c%d.running_mean' % ci] = m.batchnorm2d.running_mean
         out['c%d.running_var' % ci] = m.batchnorm2d.running_var
         out['c%d.shape' % ci] = np.asarray([N, C, T, V, stride])
+        # gradients (round 5; nothing upstream trains the class, autograd of its forward is the definition): loss =
+        # sum(y * r) on a FRESH module per mode, so that the running statistics above stay those of two updates
+        for mode in ('train', 'eval'):
+            m2 = MSTCN(C, 3, 9, 15, 0.0, stride=stride)
+            m2.load_state_dict(det_fill_(m2.state_dict()))
+            m2.train(mode == 'train')
+            xg = x.clone().requires_grad_(True)
+            y = m2(xg * 1.0, imp)                  # (the reference's ReLU / Dropout are in-place: not on a leaf)
+            r = det_tensor('g8.r.%d' % ci, tuple(y.shape))
+            (y * r).sum().backward()
+            out['c%d.%s.dx' % (ci, mode)] = xg.grad
+            out['c%d.%s.dW' % (ci, mode)] = m2.conv_b.weight.grad
+            out['c%d.%s.db' % (ci, mode)] = m2.conv_b.bias.grad
+            out['c%d.%s.dgamma' % (ci, mode)] = m2.batchnorm2d.weight.grad
+            out['c%d.%s.dbeta' % (ci, mode)] = m2.batchnorm2d.bias.grad
+            assert m2.conv_a.weight.grad is None and m2.conv_c.weight.grad is None
     save('mstcn_g8.npz', **out)
 
 

@@ -338,6 +338,20 @@ def test_mstcn_oracle_matches_reference(ci, golden):
         assert rel_err(m.train()(x), g['c%d.train' % ci]) < 1e-5
     assert rel_err(m.batchnorm2d.running_mean, g['c%d.running_mean' % ci]) < 1e-5
     assert rel_err(m.batchnorm2d.running_var, g['c%d.running_var' % ci]) < 1e-5
+    # gradients (round 5): autograd of the restatement against autograd of the reference, loss = sum(y * r), both modes
+    for mode in ('train', 'eval'):
+        m2 = R.RefMSTCN(C, 3, 9, 15, 0.0, stride=stride)
+        m2.load_state_dict(det_fill_(m2.state_dict()))
+        m2.train(mode == 'train')
+        xg = x.clone().requires_grad_(True)
+        y = m2(xg)
+        (y * det_tensor('g8.r.%d' % ci, tuple(y.shape))).sum().backward()
+        key = 'c%d.%s.' % (ci, mode)
+        assert rel_err(xg.grad, g[key + 'dx']) < 1e-5 and rel_err(m2.conv_b.weight.grad, g[key + 'dW']) < 1e-5
+        assert rel_err(m2.batchnorm2d.weight.grad, g[key + 'dgamma']) < 1e-5
+        assert rel_err(m2.batchnorm2d.bias.grad, g[key + 'dbeta']) < 1e-5
+        if mode == 'eval':
+            assert rel_err(m2.conv_b.bias.grad, g[key + 'db']) < 1e-5
 
 
 def test_model_full_clip_train_step_st_gcn_msgcn(golden):
