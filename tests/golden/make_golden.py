@@ -394,9 +394,10 @@ def g45_models():
 # deep model) on 8 clips (4 for T = 600): logits, loss, every gradient norm -- the NM = 16 sequences fill 16 x 300 x 25 = 120 000
 # positions per layer, every kernel walks many tiles per workgroup.
 G4L = {'st_gcnold': 8, 'st_gcn_msgcn': 8, 'st_gcn_mstcn_1x1': 8, 'st_gcn_multi3_fix_3A_mstcn': 8, 'st_gcn_mstcn_1x1_deep': 4}
-# G4B: the SAME for BASELINE config 2 at its bench shape -- 64 clips x (3, 300, 25, 2) -- so that the step bench.py times has a
-# reference twin (about two minutes and 25 GB of host memory to generate; `make_golden.py g4b`)
-G4B = {'st_gcn_msgcn': 64}
+# G4B: the SAME for BASELINE configs 2 and 4 at their bench shape -- 64 clips x (3, 300, 25, 2) -- so that the steps bench.py
+# times have a reference twin (`make_golden.py g4b`: two minutes each; 25 GB of host memory for config 2, 45 GB for config 4,
+# the full IST-GCN -- configs 3 and 5 at their 256 / 128 clips do not fit this container's 64 GB)
+G4B = {'st_gcn_msgcn': 64, 'st_gcn_multi3_fix_3A_mstcn': 64}
 
 
 def g4l_models(table=None, prefix='g4l'):

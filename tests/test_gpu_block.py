@@ -369,13 +369,14 @@ def test_model_full_clip_train_step_reference(golden, tag):
         assert n_sub >= 3
 
 
-def test_bench_shape_train_step_reference(golden):
-    """G4B (round 5): the training step bench.py times -- `net/st_gcn_msgcn.py`, 64 clips x (3, 300, 25, 2), BASELINE config 2 --
-    against the REFERENCE at exactly that shape (processor/recognition.py:273-283; fixture generated by running the reference
-    on the CPU: two minutes, 25 GB).  fp32 storage: logits and loss 1e-3, every gradient norm 2e-3, subsampled gradient
-    tensors 2e-3.  bf16 (the bench's storage type) and fp16: logits in relative L2, and the whole gradient's norm-weighted
-    error against the reference's gradient norms."""
-    tag = 'st_gcn_msgcn'
+@pytest.mark.parametrize('tag', ['st_gcn_msgcn', 'st_gcn_multi3_fix_3A_mstcn'])
+def test_bench_shape_train_step_reference(golden, tag):
+    """G4B (round 5): the training steps bench.py times -- `net/st_gcn_msgcn.py` (BASELINE config 2, the headline) and the full
+    IST-GCN `net/st_gcn_multi3_fix_3A_mstcn.py` (config 4), 64 clips x (3, 300, 25, 2) -- against the REFERENCE at exactly that
+    shape (processor/recognition.py:273-283; fixtures generated by running the reference on the CPU: two minutes and 25 / 45 GB
+    each).  fp32 storage: logits and loss 1e-3, every gradient norm 2e-3, subsampled gradient tensors 2e-3.  bf16 (the bench's
+    storage type) and fp16: logits in relative L2, and the whole gradient's norm-weighted error against the reference's
+    gradient norms."""
     g = golden('model_g4b_%s.npz' % tag)
     shp = tuple(int(v) for v in g['train_shape'])
     assert shp == (64, 3, 300, 25, 2)
@@ -394,7 +395,7 @@ def test_bench_shape_train_step_reference(golden):
         params = list(m.parameters())
         gn = np.asarray([0.0 if p.grad is None else float(p.grad.double().norm()) / ls for p in params])
         if dt == torch.float32:
-            assert diag('g4b_logits', logits, g['train_logits'], 1e-3) < 1e-3
+            assert diag('g4b_logits_' + tag, logits, g['train_logits'], 1e-3) < 1e-3
             assert abs(float(loss.detach()) - float(g['train_loss'])) < 1e-3
             assert np.array_equal(np.asarray([p.grad is None for p in params]), g['grad_none'])
             bad = np.abs(gn - g['grad_norms']) > 2e-3 * np.maximum(1.0, g['grad_norms'])
@@ -402,9 +403,9 @@ def test_bench_shape_train_step_reference(golden):
             named = dict(m.named_parameters())
             for k in g.files:
                 if k.startswith('grad.') and not k.endswith('#norm'):
-                    assert sub_close('g4b_' + k, named[k[5:]].grad, g, k, 2e-3, dt), k
+                    assert sub_close('g4b_%s_%s' % (tag, k), named[k[5:]].grad, g, k, 2e-3, dt), k
         else:
-            name = str(dt)[6:]
+            name = tag + ' ' + str(dt)[6:]
             assert gate16('g4b_logits ' + name, l2rel(logits.float(), g['train_logits']), 3e-3 if dt == torch.bfloat16 else 4e-4)
             # every parameter's gradient NORM against the reference's (the norms of the reference are all the fixture holds of
             # most tensors): relative error of the norm, weighted by the norm -- a 16-bit regression alarm, not a parity gate
